@@ -1,0 +1,568 @@
+// k_estimate.hip — float64 estimation stages, batched: flow model, feasibility, velocity least squares,
+// IMU propagation, lever-arm/rotation, Kalman predict/update, Monte-Carlo error simulation.  gfx950.
+//
+// These stages move a few KB per problem; they are launch/latency bound, so each kernel handles a whole batch
+// (one 256-thread block per problem for the reductions, one thread per problem for the 3-vector algebra).
+// The 3N x 3 least-squares problem is solved through its 3x3 normal equations, accumulated in fp64 with
+// wavefront shuffles (no MFMA: there is no dense contraction here), diagonalised by cyclic Jacobi:
+//   M = sum sA^2 (|p|^2 I - p p^T),  g = sum sA sB X^T X q,   v = sum_k q_k (q_k . g) / lambda_k
+// which also yields lstsq's singular values s = sqrt(lambda) and the rank.  The residual sum of squares is
+// recomputed in a second pass over the points (the closed form cancels catastrophically when R ~ 0).
+#include "ofk_internal.h"
+
+struct Acc { double m00, m01, m02, m11, m12, m22, g0, g1, g2, bb, cnt; };
+
+__device__ __forceinline__ void acc_zero(Acc &a) { a.m00 = a.m01 = a.m02 = a.m11 = a.m12 = a.m22 = a.g0 = a.g1 = a.g2 = a.bb = a.cnt = 0.0; }
+
+// p = (x,y,1); c = p x q  (= [p]x q)
+__device__ __forceinline__ void cross_p(double x, double y, double q0, double q1, double q2, double &c0, double &c1, double &c2)
+{
+    c0 = y * q2 - q1; c1 = q0 - x * q2; c2 = x * q1 - y * q0;
+}
+
+__device__ __forceinline__ void acc_point(Acc &a, double x, double y, double q0, double q1, double q2, double sA, double sB)
+{
+    double c0, c1, c2, t0, t1, t2;
+    cross_p(x, y, q0, q1, q2, c0, c1, c2);            // X q
+    cross_p(x, y, c0, c1, c2, t0, t1, t2);            // X X q = -X^T X q
+    const double pp = x * x + y * y + 1.0, sa2 = sA * sA, sab = sA * sB;
+    a.m00 += sa2 * (pp - x * x); a.m01 += sa2 * (-x * y); a.m02 += sa2 * (-x);
+    a.m11 += sa2 * (pp - y * y); a.m12 += sa2 * (-y);     a.m22 += sa2 * (pp - 1.0);
+    a.g0 -= sab * t0; a.g1 -= sab * t1; a.g2 -= sab * t2;
+    a.bb += sB * sB * (c0 * c0 + c1 * c1 + c2 * c2);
+    a.cnt += 1.0;
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// Sum `v` over the 256 threads of the block; result valid in every thread.  s_red: >= 4 doubles.
+__device__ __forceinline__ double block_sum(double v, double *s_red)
+{
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
+__device__ void acc_block_sum(Acc &a, double *s_red)
+{
+    a.m00 = block_sum(a.m00, s_red); a.m01 = block_sum(a.m01, s_red); a.m02 = block_sum(a.m02, s_red);
+    a.m11 = block_sum(a.m11, s_red); a.m12 = block_sum(a.m12, s_red); a.m22 = block_sum(a.m22, s_red);
+    a.g0 = block_sum(a.g0, s_red); a.g1 = block_sum(a.g1, s_red); a.g2 = block_sum(a.g2, s_red);
+    a.bb = block_sum(a.bb, s_red); a.cnt = block_sum(a.cnt, s_red);
+}
+
+// Cyclic Jacobi on a symmetric 3x3; eigenvalues descending in lam[], eigenvectors in columns of V.
+__device__ void jacobi3(double A[3][3], double lam[3], double V[3][3])
+{
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) V[i][j] = i == j ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 32; ++sweep) {
+        const double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
+        if (off == 0.0) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                const double apq = A[p][q];
+                if (apq == 0.0) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 3; ++k) { const double akp = A[k][p], akq = A[k][q]; A[k][p] = c * akp - s * akq; A[k][q] = s * akp + c * akq; }
+                for (int k = 0; k < 3; ++k) { const double apk = A[p][k], aqk = A[q][k]; A[p][k] = c * apk - s * aqk; A[q][k] = s * apk + c * aqk; }
+                for (int k = 0; k < 3; ++k) { const double vkp = V[k][p], vkq = V[k][q]; V[k][p] = c * vkp - s * vkq; V[k][q] = s * vkp + c * vkq; }
+            }
+    }
+    int o[3] = {0, 1, 2};
+    double d[3] = {A[0][0], A[1][1], A[2][2]};
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2 - i; ++j) if (d[o[j]] < d[o[j + 1]]) { const int t = o[j]; o[j] = o[j + 1]; o[j + 1] = t; }
+    double Vs[3][3];
+    for (int k = 0; k < 3; ++k) { lam[k] = d[o[k]]; for (int i = 0; i < 3; ++i) Vs[i][k] = V[i][o[k]]; }
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) V[i][j] = Vs[i][j];
+}
+
+// Solve from accumulated sums.  out8 = v[3], (residual filled later), rank, s[3].  Returns rank.
+__device__ int solve_from_acc(const Acc &a, double *v, double *s3)
+{
+    double A[3][3] = {{a.m00, a.m01, a.m02}, {a.m01, a.m11, a.m12}, {a.m02, a.m12, a.m22}};
+    double lam[3], V[3][3];
+    jacobi3(A, lam, V);
+    const double rows = 3.0 * a.cnt;
+    // lstsq's cut is s_k <= eps*max(M,N)*s_max; on the squared spectrum the resolvable floor is eps*lambda_max,
+    // so singular-value ratios below sqrt(eps*rows) count as zero ("rank").
+    const double tol = lam[0] * 2.220446049250313e-16 * (rows > 3.0 ? rows : 3.0);
+    int rank = 0;
+    v[0] = v[1] = v[2] = 0.0;
+    for (int k = 0; k < 3; ++k) {
+        s3[k] = lam[k] > 0.0 ? sqrt(lam[k]) : 0.0;
+        if (lam[k] > tol && lam[k] > 0.0) {
+            const double c = (V[0][k] * a.g0 + V[1][k] * a.g1 + V[2][k] * a.g2) / lam[k];
+            v[0] += c * V[0][k]; v[1] += c * V[1][k]; v[2] += c * V[2][k];
+            ++rank;
+        }
+    }
+    return rank;
+}
+
+__device__ __forceinline__ double resid_point(double x, double y, double q0, double q1, double q2, double sA, double sB,
+                                              const double *v)
+{
+    double c0, c1, c2, w0, w1, w2;
+    cross_p(x, y, q0, q1, q2, c0, c1, c2);
+    cross_p(x, y, v[0], v[1], v[2], w0, w1, w2);
+    const double r0 = sA * w0 - sB * c0, r1 = sA * w1 - sB * c1, r2 = sA * w2 - sB * c2;
+    return r0 * r0 + r1 * r1 + r2 * r2;
+}
+
+// per-point scalings of the three reference systems (see ofk.h)
+__device__ __forceinline__ void point_terms(int variant, double x, double y, double ux, double uy, const double *nrm,
+                                            const double *om, double d, double wgt, double &q0, double &q1, double &q2,
+                                            double &sA, double &sB)
+{
+    const double ndp = nrm[0] * x + nrm[1] * y + nrm[2];
+    if (variant == OFK_SOLVE_OFMODULE) {
+        q0 = ux; q1 = uy; q2 = 0.0;
+        sA = 1.0 / wgt; sB = sA / ndp;
+    } else {
+        double c0, c1, c2;
+        cross_p(x, y, om[0], om[1], om[2], c0, c1, c2);       // [p]x omega
+        q0 = ux + c0; q1 = uy + c1; q2 = c2;
+        if (variant == OFK_SOLVE_SIM) { sA = ndp; sB = d; } else { sA = 1.0; sB = d / ndp; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ generic batched solve
+__global__ __launch_bounds__(256) void k_solve(int variant, const double *__restrict__ x, const double *__restrict__ u,
+                                               const uint8_t *__restrict__ valid, int n, const double *__restrict__ d,
+                                               const double *__restrict__ nrm, const double *__restrict__ omega,
+                                               const double *__restrict__ t, const double *__restrict__ wgt,
+                                               double *__restrict__ out)
+{
+    __shared__ double s_red[4];
+    __shared__ double s_v[8];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const double *xb = x + (size_t)b * n * 2, *ub = u + (size_t)b * n * 2;
+    const uint8_t *vb = valid ? valid + (size_t)b * n : nullptr;
+    const double *wb = wgt ? wgt + (size_t)b * n : nullptr;
+    const double nb[3] = {nrm[3 * b], nrm[3 * b + 1], nrm[3 * b + 2]};
+    double ob[3] = {0, 0, 0};
+    if (omega) { ob[0] = omega[3 * b]; ob[1] = omega[3 * b + 1]; ob[2] = omega[3 * b + 2]; }
+    const double db = d ? d[b] : 1.0;
+    Acc a; acc_zero(a);
+    for (int i = tid; i < n; i += 256) {
+        if (vb && !vb[i]) continue;
+        double q0, q1, q2, sA, sB;
+        point_terms(variant, xb[2 * i], xb[2 * i + 1], ub[2 * i], ub[2 * i + 1], nb, ob, db, wb ? wb[i] : 1.0, q0, q1, q2, sA, sB);
+        acc_point(a, xb[2 * i], xb[2 * i + 1], q0, q1, q2, sA, sB);
+    }
+    acc_block_sum(a, s_red);
+    if (tid == 0) {
+        double v[3], s3[3];
+        const int rank = a.cnt > 0.0 ? solve_from_acc(a, v, s3) : 0;
+        if (a.cnt <= 0.0) { v[0] = v[1] = v[2] = 0.0; s3[0] = s3[1] = s3[2] = 0.0; }
+        s_v[0] = v[0]; s_v[1] = v[1]; s_v[2] = v[2]; s_v[3] = (double)rank; s_v[4] = s3[0]; s_v[5] = s3[1]; s_v[6] = s3[2];
+        s_v[7] = a.cnt;
+    }
+    __syncthreads();
+    const double v[3] = {s_v[0], s_v[1], s_v[2]};
+    double r = 0.0;
+    for (int i = tid; i < n; i += 256) {
+        if (vb && !vb[i]) continue;
+        double q0, q1, q2, sA, sB;
+        point_terms(variant, xb[2 * i], xb[2 * i + 1], ub[2 * i], ub[2 * i + 1], nb, ob, db, wb ? wb[i] : 1.0, q0, q1, q2, sA, sB);
+        r += resid_point(xb[2 * i], xb[2 * i + 1], q0, q1, q2, sA, sB, v);
+    }
+    r = block_sum(r, s_red);
+    if (tid == 0) {
+        double *o = out + (size_t)b * OFK_SOLVE_DOUBLES;
+        double vx = v[0], vy = v[1], vz = v[2];
+        if (t) {                                              // v - omega x t
+            const double *tb = t + 3 * b;
+            vx -= ob[1] * tb[2] - ob[2] * tb[1]; vy -= ob[2] * tb[0] - ob[0] * tb[2]; vz -= ob[0] * tb[1] - ob[1] * tb[0];
+        }
+        o[0] = vx; o[1] = vy; o[2] = vz; o[3] = r; o[4] = s_v[3]; o[5] = s_v[4]; o[6] = s_v[5]; o[7] = s_v[6];
+    }
+}
+
+void ofk_launch_solve(hipStream_t s, int variant, const double *x, const double *u, const uint8_t *valid, int batch,
+                      int n, const double *d, const double *nrm, const double *omega, const double *t,
+                      const double *wgt, double *out)
+{
+    hipLaunchKernelGGL(k_solve, dim3(batch), dim3(256), 0, s, variant, x, u, valid, n, d, nrm, omega, t, wgt, out);
+}
+
+// ------------------------------------------------------------------------------------------------ r_tilde (device form)
+__device__ __forceinline__ void rtilde_point(double x, double y, double ux, double uy, const double *n, const double *v,
+                                             double dist, double &r, double &dd)
+{
+    double vc0, vc1, vc2, uc0, uc1, uc2;
+    cross_p(x, y, v[0], v[1], v[2], vc0, vc1, vc2);
+    vc0 = -vc0; vc1 = -vc1; vc2 = -vc2;
+    cross_p(x, y, ux, uy, 0.0, uc0, uc1, uc2);
+    const double vn = sqrt(vc0 * vc0 + vc1 * vc1 + vc2 * vc2), un = sqrt(uc0 * uc0 + uc1 * uc1 + uc2 * uc2);
+    if (un * vn == 0.0) { r = 1.0; dd = 1.0; return; }
+    const double iun = 1.0 / un;
+    r = (vc0 * uc0 + vc1 * uc1 + vc2 * uc2) * iun / vn;
+    const double pn = x * n[0] + y * n[1] + n[2];
+    if (pn < 0.0) r = -r;
+    dd = pn * vn * iun / dist;
+}
+
+// ------------------------------------------------------------------------------------------------ frame-pair solve
+// One block per pair: x = (next - c) * scaling, u = (next - prev) * scaling for tracked points (node:229-235),
+// optional r_tilde filter (node:238-245), solve (node:257), lever arm + rotation (node:258).
+__global__ __launch_bounds__(256) void k_pairs_solve(const float *__restrict__ prev_pts, const float *__restrict__ next_pts,
+                                                     const uint8_t *__restrict__ status, const int *__restrict__ counts,
+                                                     int pts_stride, const double *__restrict__ sensors, int variant,
+                                                     int use_feas, double feas_T, double *__restrict__ records)
+{
+    __shared__ double s_red[4];
+    __shared__ double s_v[8];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const double *sn = sensors + (size_t)b * OFK_SENSOR_DOUBLES;
+    const double d = sn[0], nrm[3] = {sn[1], sn[2], sn[3]}, om[3] = {sn[4], sn[5], sn[6]};
+    const double scaling = sn[19], cx = sn[20], cy = sn[21], vp[3] = {sn[22], sn[23], sn[24]};
+    const int n = counts[b];
+    const float *pp = prev_pts + (size_t)b * pts_stride * 2, *np_ = next_pts + (size_t)b * pts_stride * 2;
+    const uint8_t *st = status + (size_t)b * pts_stride;
+    Acc a; acc_zero(a);
+    double tracked = 0.0;
+    for (int i = tid; i < n; i += 256) {
+        if (!st[i]) continue;
+        tracked += 1.0;
+        const double x = ((double)np_[2 * i] - cx) * scaling, y = ((double)np_[2 * i + 1] - cy) * scaling;
+        const double ux = ((double)np_[2 * i] - (double)pp[2 * i]) * scaling, uy = ((double)np_[2 * i + 1] - (double)pp[2 * i + 1]) * scaling;
+        if (use_feas) {
+            double r, dd;
+            rtilde_point(x, y, ux, uy, nrm, vp, d, r, dd);
+            if (!(r <= feas_T)) continue;
+        }
+        double q0, q1, q2, sA, sB;
+        point_terms(variant, x, y, ux, uy, nrm, om, d, 1.0, q0, q1, q2, sA, sB);
+        acc_point(a, x, y, q0, q1, q2, sA, sB);
+    }
+    acc_block_sum(a, s_red);
+    tracked = block_sum(tracked, s_red);
+    if (tid == 0) {
+        double v[3] = {0, 0, 0}, s3[3] = {0, 0, 0};
+        const int rank = a.cnt > 0.0 ? solve_from_acc(a, v, s3) : 0;
+        s_v[0] = v[0]; s_v[1] = v[1]; s_v[2] = v[2]; s_v[3] = (double)rank; s_v[4] = s3[0]; s_v[5] = s3[1]; s_v[6] = s3[2];
+    }
+    __syncthreads();
+    const double v[3] = {s_v[0], s_v[1], s_v[2]};
+    double r = 0.0;
+    for (int i = tid; i < n; i += 256) {
+        if (!st[i]) continue;
+        const double x = ((double)np_[2 * i] - cx) * scaling, y = ((double)np_[2 * i + 1] - cy) * scaling;
+        const double ux = ((double)np_[2 * i] - (double)pp[2 * i]) * scaling, uy = ((double)np_[2 * i + 1] - (double)pp[2 * i + 1]) * scaling;
+        if (use_feas) {
+            double rr, dd;
+            rtilde_point(x, y, ux, uy, nrm, vp, d, rr, dd);
+            if (!(rr <= feas_T)) continue;
+        }
+        double q0, q1, q2, sA, sB;
+        point_terms(variant, x, y, ux, uy, nrm, om, d, 1.0, q0, q1, q2, sA, sB);
+        r += resid_point(x, y, q0, q1, q2, sA, sB, v);
+    }
+    r = block_sum(r, s_red);
+    if (tid == 0) {
+        double *o = records + (size_t)b * OFK_RECORD_DOUBLES;
+        const double *R = sn + 7, *off = sn + 16;
+        // v_obs - [w]x offset, then rotate (node:258)
+        const double e0 = v[0] - (om[1] * off[2] - om[2] * off[1]);
+        const double e1 = v[1] - (om[2] * off[0] - om[0] * off[2]);
+        const double e2 = v[2] - (om[0] * off[1] - om[1] * off[0]);
+        o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = r; o[4] = s_v[3]; o[5] = s_v[4]; o[6] = s_v[5]; o[7] = s_v[6];
+        o[8] = R[0] * e0 + R[1] * e1 + R[2] * e2; o[9] = R[3] * e0 + R[4] * e1 + R[5] * e2; o[10] = R[6] * e0 + R[7] * e1 + R[8] * e2;
+        o[11] = a.cnt; o[12] = (double)n; o[13] = tracked; o[14] = 0.0; o[15] = 0.0;
+    }
+}
+
+void ofk_launch_pairs_solve(hipStream_t s, const float *prev_pts, const float *next_pts, const uint8_t *status,
+                            const int *counts, int pts_stride, const double *sensors, int variant, int use_feas,
+                            double feas_T, double *records, int batch)
+{
+    hipLaunchKernelGGL(k_pairs_solve, dim3(batch), dim3(256), 0, s, prev_pts, next_pts, status, counts, pts_stride, sensors,
+                       variant, use_feas, feas_T, records);
+}
+
+__global__ void k_records_f32(const double *__restrict__ rec, float *__restrict__ dst, int batch)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    const double *r = rec + (size_t)b * OFK_RECORD_DOUBLES;
+    float *o = dst + (size_t)b * 8;
+    o[0] = (float)r[0]; o[1] = (float)r[1]; o[2] = (float)r[2]; o[3] = (float)r[3];
+    o[4] = (float)r[11]; o[5] = (float)r[7]; o[6] = (float)r[4]; o[7] = (float)r[12];
+}
+
+void ofk_launch_records_f32(hipStream_t s, const double *records, float *dst, int batch)
+{
+    hipLaunchKernelGGL(k_records_f32, dim3((batch + 63) / 64), dim3(64), 0, s, records, dst, batch);
+}
+
+// ------------------------------------------------------------------------------------------------ flow model
+__global__ void k_flow_model(const double *__restrict__ x, int n, const double *__restrict__ v,
+                             const double *__restrict__ omega, const double *__restrict__ d,
+                             const double *__restrict__ nrm, const double *__restrict__ t, double *__restrict__ flow)
+{
+    const int b = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double *om = omega + 3 * b, *nn = nrm + 3 * b;
+    double v0 = v[3 * b], v1 = v[3 * b + 1], v2 = v[3 * b + 2];
+    if (t) {                                                  // v + omega x t (simulation.py:9)
+        const double *tb = t + 3 * b;
+        v0 += om[1] * tb[2] - om[2] * tb[1]; v1 += om[2] * tb[0] - om[0] * tb[2]; v2 += om[0] * tb[1] - om[1] * tb[0];
+    }
+    const double px = x[((size_t)b * n + i) * 2], py = x[((size_t)b * n + i) * 2 + 1];
+    const double k = (nn[0] * px + nn[1] * py + nn[2]) / d[b];
+    // omega x p
+    const double w0 = om[1] - om[2] * py, w1 = om[2] * px - om[0], w2 = om[0] * py - om[1] * px;
+    flow[((size_t)b * n + i) * 2] = k * (v0 - v2 * px) + (w0 - w2 * px);
+    flow[((size_t)b * n + i) * 2 + 1] = k * (v1 - v2 * py) + (w1 - w2 * py);
+}
+
+void ofk_launch_flow_model(hipStream_t s, const double *x, int batch, int n, const double *v, const double *omega,
+                           const double *d, const double *nrm, const double *t, double *flow)
+{
+    hipLaunchKernelGGL(k_flow_model, dim3((n + 255) / 256, batch), dim3(256), 0, s, x, n, v, omega, d, nrm, t, flow);
+}
+
+// ------------------------------------------------------------------------------------------------ feasibility
+__global__ void k_feasibility(int variant, const double *__restrict__ x, const double *__restrict__ u, int n,
+                              const double *__restrict__ nrm, const double *__restrict__ v,
+                              const double *__restrict__ dist, const double *__restrict__ omega,
+                              const double *__restrict__ t, double *__restrict__ r, double *__restrict__ dd)
+{
+    const int b = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t k = (size_t)b * n + i;
+    const double px = x[2 * k], py = x[2 * k + 1], ux = u[2 * k], uy = u[2 * k + 1];
+    const double *nn = nrm + 3 * b, *vv = v + 3 * b;
+    double rr, dv;
+    if (variant == OFK_FEAS_RTILDE) {
+        rtilde_point(px, py, ux, uy, nn, vv, dist[b], rr, dv);
+    } else if (variant == OFK_FEAS_LEGACY) {
+        double vc0, vc1, vc2, uc0, uc1, uc2;
+        cross_p(px, py, vv[0], vv[1], vv[2], vc0, vc1, vc2);
+        vc0 = -vc0; vc1 = -vc1; vc2 = -vc2;
+        cross_p(px, py, ux, uy, 0.0, uc0, uc1, uc2);
+        const double vn = sqrt(vc0 * vc0 + vc1 * vc1 + vc2 * vc2), iun = 1.0 / sqrt(uc0 * uc0 + uc1 * uc1 + uc2 * uc2);
+        rr = (vc0 * uc0 + vc1 * uc1 + vc2 * uc2) * iun / vn;
+        const double pn = px * nn[0] + py * nn[1] + nn[2];
+        if (pn < 0.0) rr = -rr;
+        dv = pn * vn * iun;
+    } else {                                                  // simulation.py:108-120
+        const double *om = omega + 3 * b, *tb = t + 3 * b;
+        const double l0 = vv[0] - (om[1] * tb[2] - om[2] * tb[1]), l1 = vv[1] - (om[2] * tb[0] - om[0] * tb[2]),
+                     l2 = vv[2] - (om[0] * tb[1] - om[1] * tb[0]);
+        const double w0 = om[1] - om[2] * py, w1 = om[2] * px - om[0], w2 = om[0] * py - om[1] * px;   // omega x p
+        double f0, f1, f2, g0, g1, g2;
+        cross_p(px, py, l0, l1, l2, f0, f1, f2);
+        cross_p(px, py, ux - w0, uy - w1, -w2, g0, g1, g2);
+        const double n1 = sqrt(f0 * f0 + f1 * f1 + f2 * f2), n2 = sqrt(g0 * g0 + g1 * g1 + g2 * g2);
+        rr = (f0 * g0 + f1 * g1 + f2 * g2) / (n1 * n2);
+        dv = n1 / n2 * (px * nn[0] + py * nn[1] + nn[2]);
+    }
+    r[k] = rr; dd[k] = dv;
+}
+
+void ofk_launch_feasibility(hipStream_t s, int variant, const double *x, const double *u, int batch, int n,
+                            const double *nrm, const double *v, const double *dist, const double *omega,
+                            const double *t, double *r, double *dd)
+{
+    hipLaunchKernelGGL(k_feasibility, dim3((n + 255) / 256, batch), dim3(256), 0, s, variant, x, u, n, nrm, v, dist, omega, t, r, dd);
+}
+
+// ------------------------------------------------------------------------------------------------ IMU propagation
+__global__ void k_imu(double *__restrict__ state, const double *__restrict__ msg, int batch)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    double *s = state + (size_t)b * OFK_IMU_STATE;
+    const double *m = msg + (size_t)b * OFK_IMU_MSG;
+    const double secs = m[0], nsecs = m[1], qx = m[2], qy = m[3], qz = m[4], qw = m[5];
+    double R[9];
+    R[0] = 1.0 - 2 * (qy * qy + qz * qz); R[1] = 2 * (qx * qy - qw * qz); R[2] = 2 * (qw * qy + qx * qz);
+    R[3] = 2 * (qx * qy + qw * qz); R[4] = 1.0 - 2 * (qx * qx + qz * qz); R[5] = 2 * (qy * qz - qw * qx);
+    R[6] = 2 * (qx * qz - qw * qy); R[7] = 2 * (qw * qx + qy * qz); R[8] = 1.0 - 2 * (qx * qx + qy * qy);
+    const double n0 = R[2], n1 = R[5], n2 = R[8];             // R [0,0,1]
+    if (s[5] != 0.0) {                                         // first message (node:72-75)
+        s[3] = nsecs / 1e9; s[4] = secs; s[5] = 0.0;
+    } else {
+        const double cur = (secs - s[4]) + nsecs / 1e9;
+        const double el = cur - s[3];
+        const double a0 = m[12] - 9.81 * n0, a1 = m[13] - 9.81 * n1, a2 = m[14] - 9.81 * n2;
+        s[0] = s[0] + (R[0] * a0 + R[1] * a1 + R[2] * a2) * el;
+        s[1] = s[1] + (R[3] * a0 + R[4] * a1 + R[5] * a2) * el;
+        s[2] = s[2] + (R[6] * a0 + R[7] * a1 + R[8] * a2) * el;
+        s[3] = cur;
+    }
+    for (int k = 0; k < 9; ++k) s[6 + k] = R[k];
+    s[15] = n0; s[16] = n1; s[17] = n2;
+    s[18] = m[6]; s[19] = m[7]; s[20] = m[8];
+    s[21] = m[9]; s[22] = m[10]; s[23] = m[11];
+}
+
+void ofk_launch_imu(hipStream_t s, double *state, const double *msg, int batch)
+{
+    hipLaunchKernelGGL(k_imu, dim3((batch + 63) / 64), dim3(64), 0, s, state, msg, batch);
+}
+
+__global__ void k_post_solve(const double *__restrict__ v_obs, const double *__restrict__ rot, const double *__restrict__ ang,
+                             const double *__restrict__ offset, int batch, double *__restrict__ v_uav)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    const double *v = v_obs + 3 * b, *R = rot + 9 * b, *w = ang + 3 * b, *o = offset + 3 * b;
+    const double e0 = v[0] - (w[1] * o[2] - w[2] * o[1]), e1 = v[1] - (w[2] * o[0] - w[0] * o[2]), e2 = v[2] - (w[0] * o[1] - w[1] * o[0]);
+    v_uav[3 * b] = R[0] * e0 + R[1] * e1 + R[2] * e2;
+    v_uav[3 * b + 1] = R[3] * e0 + R[4] * e1 + R[5] * e2;
+    v_uav[3 * b + 2] = R[6] * e0 + R[7] * e1 + R[8] * e2;
+}
+
+void ofk_launch_post_solve(hipStream_t s, const double *v_obs, const double *rot, const double *ang,
+                           const double *offset, int batch, double *v_uav)
+{
+    hipLaunchKernelGGL(k_post_solve, dim3((batch + 63) / 64), dim3(64), 0, s, v_obs, rot, ang, offset, batch, v_uav);
+}
+
+// ------------------------------------------------------------------------------------------------ Kalman filter
+#define KF_MAX 6
+__global__ void k_kf(int ns, int nm, int nc, const double *__restrict__ F, const double *__restrict__ Bm,
+                     const double *__restrict__ H, const double *__restrict__ Q, const double *__restrict__ Rm,
+                     double *__restrict__ xs, double *__restrict__ Ps, const double *__restrict__ us,
+                     const double *__restrict__ zs, int batch, int do_predict)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    double x[KF_MAX], P[KF_MAX][KF_MAX], T[KF_MAX][KF_MAX];
+    for (int i = 0; i < ns; ++i) { x[i] = xs[(size_t)b * ns + i]; for (int j = 0; j < ns; ++j) P[i][j] = Ps[((size_t)b * ns + i) * ns + j]; }
+    if (do_predict) {
+        double xn[KF_MAX];
+        for (int i = 0; i < ns; ++i) { double s = 0; for (int j = 0; j < ns; ++j) s += F[i * ns + j] * x[j]; xn[i] = s; }
+        if (Bm && us) for (int i = 0; i < ns; ++i) { double s = 0; for (int j = 0; j < nc; ++j) s += Bm[i * nc + j] * us[(size_t)b * nc + j]; xn[i] += s; }
+        for (int i = 0; i < ns; ++i) x[i] = xn[i];
+        for (int i = 0; i < ns; ++i) for (int j = 0; j < ns; ++j) { double s = 0; for (int k = 0; k < ns; ++k) s += F[i * ns + k] * P[k][j]; T[i][j] = s; }
+        for (int i = 0; i < ns; ++i) for (int j = 0; j < ns; ++j) { double s = 0; for (int k = 0; k < ns; ++k) s += T[i][k] * F[j * ns + k]; P[i][j] = s + Q[i * ns + j]; }
+    }
+    if (zs) {
+        double HP[KF_MAX][KF_MAX], S[KF_MAX][KF_MAX], K[KF_MAX][KF_MAX];      // HP: nm x ns, S: nm x nm, K: ns x nm
+        for (int i = 0; i < nm; ++i) for (int j = 0; j < ns; ++j) { double s = 0; for (int k = 0; k < ns; ++k) s += H[i * ns + k] * P[k][j]; HP[i][j] = s; }
+        for (int i = 0; i < nm; ++i) for (int j = 0; j < nm; ++j) { double s = 0; for (int k = 0; k < ns; ++k) s += HP[i][k] * H[j * ns + k]; S[i][j] = s + Rm[i * nm + j]; }
+        // solve S Y = HP (Y: nm x ns) by Gauss-Jordan with partial pivoting; K = Y^T
+        for (int c = 0; c < nm; ++c) {
+            int piv = c; double best = fabs(S[c][c]);
+            for (int r2 = c + 1; r2 < nm; ++r2) if (fabs(S[r2][c]) > best) { best = fabs(S[r2][c]); piv = r2; }
+            if (piv != c) {
+                for (int j = 0; j < nm; ++j) { const double tmp = S[c][j]; S[c][j] = S[piv][j]; S[piv][j] = tmp; }
+                for (int j = 0; j < ns; ++j) { const double tmp = HP[c][j]; HP[c][j] = HP[piv][j]; HP[piv][j] = tmp; }
+            }
+            const double inv = 1.0 / S[c][c];
+            for (int j = 0; j < nm; ++j) S[c][j] *= inv;
+            for (int j = 0; j < ns; ++j) HP[c][j] *= inv;
+            for (int r2 = 0; r2 < nm; ++r2) if (r2 != c) {
+                const double f = S[r2][c];
+                if (f != 0.0) {
+                    for (int j = 0; j < nm; ++j) S[r2][j] -= f * S[c][j];
+                    for (int j = 0; j < ns; ++j) HP[r2][j] -= f * HP[c][j];
+                }
+            }
+        }
+        for (int i = 0; i < ns; ++i) for (int j = 0; j < nm; ++j) K[i][j] = HP[j][i];
+        double innov[KF_MAX];
+        for (int i = 0; i < nm; ++i) { double s = 0; for (int k = 0; k < ns; ++k) s += H[i * ns + k] * x[k]; innov[i] = zs[(size_t)b * nm + i] - s; }
+        for (int i = 0; i < ns; ++i) { double s = 0; for (int j = 0; j < nm; ++j) s += K[i][j] * innov[j]; x[i] += s; }
+        // P = P - K (H P)   (H P recomputed from the prior P)
+        for (int i = 0; i < nm; ++i) for (int j = 0; j < ns; ++j) { double s = 0; for (int k = 0; k < ns; ++k) s += H[i * ns + k] * P[k][j]; T[i][j] = s; }
+        for (int i = 0; i < ns; ++i) for (int j = 0; j < ns; ++j) { double s = 0; for (int k = 0; k < nm; ++k) s += K[i][k] * T[k][j]; P[i][j] -= s; }
+    }
+    for (int i = 0; i < ns; ++i) { xs[(size_t)b * ns + i] = x[i]; for (int j = 0; j < ns; ++j) Ps[((size_t)b * ns + i) * ns + j] = P[i][j]; }
+}
+
+void ofk_launch_kf(hipStream_t s, int ns, int nm, int nc, const double *F, const double *Bm, const double *H,
+                   const double *Q, const double *Rm, double *x, double *P, const double *u, const double *z, int batch,
+                   int do_predict)
+{
+    hipLaunchKernelGGL(k_kf, dim3((batch + 63) / 64), dim3(64), 0, s, ns, nm, nc, F, Bm, H, Q, Rm, x, P, u, z, batch, do_predict);
+}
+
+// ------------------------------------------------------------------------------------------------ Monte-Carlo error simulation
+// One block per trial (simulation.py:36-66).  truth: v[0..2] omega[3..5] height[6] normal[7..9] t[10..12].
+__global__ __launch_bounds__(256) void k_of_simulation(const double *__restrict__ truth, const double *__restrict__ sig,
+                                                       const double *__restrict__ pos, const double *__restrict__ true_flow,
+                                                       int n, const double *__restrict__ z, double *__restrict__ v_obs,
+                                                       double *__restrict__ bound)
+{
+    __shared__ double s_red[4];
+    __shared__ double s_v[8];
+    const int trial = blockIdx.x, tid = threadIdx.x;
+    const double *zi = z + (size_t)trial * (10 + 4 * (size_t)n);
+    const double lv[3] = {truth[0], truth[1], truth[2]}, av[3] = {truth[3], truth[4], truth[5]}, hgt = truth[6];
+    const double nv[3] = {truth[7], truth[8], truth[9]}, tr[3] = {truth[10], truth[11], truth[12]};
+    const double ang[3] = {av[0] + sig[0] * zi[0], av[1] + sig[0] * zi[1], av[2] + sig[0] * zi[2]};
+    const double trn[3] = {tr[0] + sig[1] * zi[3], tr[1] + sig[1] * zi[4], tr[2] + sig[1] * zi[5]};
+    const double h_err = hgt + sig[2] * zi[6];
+    const double nn = sqrt(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
+    const double ne[3] = {nv[0] / nn, nv[1] / nn, nv[2] / nn};      // normal noise is discarded (simulation.py:46)
+    const double *zf = zi + 7, *zp = zi + 7 + 2 * (size_t)n;
+    Acc a; acc_zero(a);
+    for (int i = tid; i < n; i += 256) {
+        const double x = pos[2 * i] + sig[4] * zp[2 * i], y = pos[2 * i + 1] + sig[4] * zp[2 * i + 1];
+        const double ux = true_flow[2 * i] + sig[3] * zf[2 * i], uy = true_flow[2 * i + 1] + sig[3] * zf[2 * i + 1];
+        double q0, q1, q2, sA, sB;
+        point_terms(OFK_SOLVE_SIM, x, y, ux, uy, ne, ang, h_err, 1.0, q0, q1, q2, sA, sB);
+        acc_point(a, x, y, q0, q1, q2, sA, sB);
+    }
+    acc_block_sum(a, s_red);
+    if (tid == 0) {
+        double v[3], s3[3];
+        solve_from_acc(a, v, s3);
+        s_v[0] = v[0]; s_v[1] = v[1]; s_v[2] = v[2]; s_v[3] = s3[2];      // min singular value
+    }
+    __syncthreads();
+    const double smin = s_v[3];
+    double part2 = 0.0;
+    for (int i = tid; i < n; i += 256) {
+        const double xp0 = pos[2 * i], xp1 = pos[2 * i + 1];
+        const double dx0 = sig[4] * zp[2 * i], dx1 = sig[4] * zp[2 * i + 1];                 // dxp = (pos_err - pos, 0)
+        const double dd0 = sig[3] * zf[2 * i], dd1 = sig[3] * zf[2 * i + 1];                 // ddotx
+        // reference computes dxp / ddotx as differences of the perturbed and true values; reproduce that rounding
+        const double pe0 = xp0 + dx0, pe1 = xp1 + dx1, fe0 = true_flow[2 * i] + dd0, fe1 = true_flow[2 * i + 1] + dd1;
+        const double e0 = pe0 - xp0, e1 = pe1 - xp1, f0 = fe0 - true_flow[2 * i], f1 = fe1 - true_flow[2 * i + 1];
+        const double ndx = nv[0] * xp0 + nv[1] * xp1 + nv[2];
+        const double v_err = (h_err - hgt) / hgt * ndx + ((ne[0] - nv[0]) * xp0 + (ne[1] - nv[1]) * xp1 + (ne[2] - nv[2])) +
+                             (nv[0] * e0 + nv[1] * e1);
+        const double da[3] = {ang[0] - av[0], ang[1] - av[1], ang[2] - av[2]};
+        // d_err = ddotx + dxp x av + xp x da + dxp
+        const double c0 = e1 * av[2], c1 = -e0 * av[2], c2 = e0 * av[1] - e1 * av[0];         // (e0,e1,0) x av
+        double g0, g1, g2;
+        cross_p(xp0, xp1, da[0], da[1], da[2], g0, g1, g2);
+        const double de0 = f0 + c0 + g0 + e0, de1 = f1 + c1 + g1 + e1, de2 = c2 + g2;
+        const double w0 = v_err * lv[0] + hgt * de0, w1 = v_err * lv[1] + hgt * de1, w2 = v_err * lv[2] + hgt * de2;
+        double k0, k1, k2;
+        cross_p(xp0, xp1, w0, w1, w2, k0, k1, k2);
+        const double pe = sqrt(k0 * k0 + k1 * k1 + k2 * k2) / smin;
+        part2 += pe * pe;
+    }
+    part2 = block_sum(part2, s_red);
+    if (tid == 0) {
+        const double v0 = s_v[0] - (ang[1] * trn[2] - ang[2] * trn[1]);
+        const double v1 = s_v[1] - (ang[2] * trn[0] - ang[0] * trn[2]);
+        const double v2 = s_v[2] - (ang[0] * trn[1] - ang[1] * trn[0]);
+        v_obs[3 * trial] = v0; v_obs[3 * trial + 1] = v1; v_obs[3 * trial + 2] = v2;
+        const double avn = sqrt(av[0] * av[0] + av[1] * av[1] + av[2] * av[2]), trnorm = sqrt(tr[0] * tr[0] + tr[1] * tr[1] + tr[2] * tr[2]);
+        bound[trial] = sqrt(part2) + avn * sig[1] + sig[0] * trnorm + sig[0] * sig[1];
+    }
+}
+
+void ofk_launch_of_simulation(hipStream_t s, const double *truth, const double *sig, const double *pos,
+                              const double *true_flow, int n, const double *z, int trials, double *v_obs,
+                              double *bound)
+{
+    hipLaunchKernelGGL(k_of_simulation, dim3(trials), dim3(256), 0, s, truth, sig, pos, true_flow, n, z, v_obs, bound);
+}

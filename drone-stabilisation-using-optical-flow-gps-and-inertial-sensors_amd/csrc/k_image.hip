@@ -1,0 +1,169 @@
+// k_image.hip — dense u8 stages: BGR->gray, pyrDown, Scharr.  gfx950.
+//
+// All three are HBM-streaming integer kernels (no MFMA).  Layout: images of a batch live at
+// base + b*stride (stride 256-B aligned), rows tight (pitch = w).
+//   gray    : 16 px / thread, 3x dwordx4 loads + 1x dwordx4 store.
+//   pyrDown : 64x16 output tile / 256-thread block; source tile (136x35) staged into LDS with dword
+//             loads, separable 5-tap pass through a u16 LDS intermediate.
+//   scharr  : 64x16 output tile, 68x18 source tile in LDS, int16x2 (4 B/px) coalesced stores.
+#include "ofk_internal.h"
+
+__device__ __forceinline__ int reflect101(int i, int n)
+{
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) i = i < 0 ? -i : 2 * (n - 1) - i;
+    return i;
+}
+
+// ------------------------------------------------------------------------------------------------ gray
+__device__ __forceinline__ unsigned gray1(unsigned b, unsigned g, unsigned r)
+{
+    return (b * 3735u + g * 19235u + r * 9798u + 16384u) >> 15;
+}
+
+__global__ __launch_bounds__(256) void k_gray_bgr8(const uint8_t *__restrict__ bgr, size_t bgr_stride,
+                                                   uint8_t *__restrict__ gray, size_t gray_stride, int npx)
+{
+    const int b = blockIdx.y;
+    const uint8_t *src = bgr + (size_t)b * bgr_stride;
+    uint8_t *dst = gray + (size_t)b * gray_stride;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;       // group of 16 pixels
+    const int p0 = t * 16;
+    if (p0 >= npx) return;
+    if (p0 + 16 <= npx) {
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(src + (size_t)p0 * 3);
+        const uint4 a = s4[0], c = s4[1], d = s4[2];
+        const unsigned wv[12] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+        unsigned out[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned o = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int byte = (q * 4 + k) * 3;
+                const unsigned bb = (wv[byte >> 2] >> ((byte & 3) * 8)) & 255u;
+                const unsigned gg = (wv[(byte + 1) >> 2] >> (((byte + 1) & 3) * 8)) & 255u;
+                const unsigned rr = (wv[(byte + 2) >> 2] >> (((byte + 2) & 3) * 8)) & 255u;
+                o |= gray1(bb, gg, rr) << (8 * k);
+            }
+            out[q] = o;
+        }
+        *reinterpret_cast<uint4 *>(dst + p0) = make_uint4(out[0], out[1], out[2], out[3]);
+    } else {
+        for (int p = p0; p < npx; ++p) dst[p] = (uint8_t)gray1(src[3 * (size_t)p], src[3 * (size_t)p + 1], src[3 * (size_t)p + 2]);
+    }
+}
+
+void ofk_launch_gray(hipStream_t s, const uint8_t *bgr, size_t bgr_stride, uint8_t *gray, size_t gray_stride, int batch,
+                     int h, int w)
+{
+    const int npx = h * w;
+    const int groups = (npx + 15) / 16;
+    dim3 grid((groups + 255) / 256, batch);
+    hipLaunchKernelGGL(k_gray_bgr8, grid, dim3(256), 0, s, bgr, bgr_stride, gray, gray_stride, npx);
+}
+
+// ------------------------------------------------------------------------------------------------ pyrDown
+#define PD_TW 64
+#define PD_TH 16
+#define PD_SW 136                       // staged source columns: [2*ox0-4, 2*ox0+132)
+#define PD_SH (2 * PD_TH + 3)           // staged source rows:    [2*oy0-2, 2*oy0+2*TH+1)
+
+__global__ __launch_bounds__(256) void k_pyr_down(const uint8_t *__restrict__ src, size_t src_stride, int h, int w,
+                                                  uint8_t *__restrict__ dst, size_t dst_stride, int dh, int dw)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_src[PD_SH][PD_SW];
+    __shared__ uint16_t s_h[PD_SH][PD_TW];
+    const int b = blockIdx.z;
+    const uint8_t *img = src + (size_t)b * src_stride;
+    uint8_t *out = dst + (size_t)b * dst_stride;
+    const int ox0 = blockIdx.x * PD_TW, oy0 = blockIdx.y * PD_TH;
+    const int sx0 = 2 * ox0 - 4, sy0 = 2 * oy0 - 2;
+    const int tid = threadIdx.x;
+    const bool interior = sx0 >= 0 && sy0 >= 0 && sx0 + PD_SW <= w && sy0 + PD_SH <= h && (w & 3) == 0;
+    if (interior) {
+        for (int i = tid; i < PD_SH * (PD_SW / 4); i += 256) {
+            const int r = i / (PD_SW / 4), c4 = i % (PD_SW / 4);
+            const unsigned v = *reinterpret_cast<const unsigned *>(img + (size_t)(sy0 + r) * w + sx0 + c4 * 4);
+            *reinterpret_cast<unsigned *>(&s_src[r][c4 * 4]) = v;
+        }
+    } else {
+        for (int i = tid; i < PD_SH * PD_SW; i += 256) {
+            const int r = i / PD_SW, c = i % PD_SW;
+            s_src[r][c] = img[(size_t)reflect101(sy0 + r, h) * w + reflect101(sx0 + c, w)];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < PD_SH * PD_TW; i += 256) {
+        const int r = i / PD_TW, x = i % PD_TW;
+        const uint8_t *p = &s_src[r][2 * x + 2];          // source column 2*(ox0+x)-2 sits at staged column 2x+2
+        s_h[r][x] = (uint16_t)(p[0] + 4 * p[1] + 6 * p[2] + 4 * p[3] + p[4]);
+    }
+    __syncthreads();
+    for (int i = tid; i < PD_TH * PD_TW; i += 256) {
+        const int y = i / PD_TW, x = i % PD_TW;
+        const int oy = oy0 + y, ox = ox0 + x;
+        if (oy < dh && ox < dw) {
+            const int s = s_h[2 * y][x] + 4 * s_h[2 * y + 1][x] + 6 * s_h[2 * y + 2][x] + 4 * s_h[2 * y + 3][x] + s_h[2 * y + 4][x];
+            out[(size_t)oy * dw + ox] = (uint8_t)((s + 128) >> 8);
+        }
+    }
+}
+
+void ofk_launch_pyr_down(hipStream_t s, const uint8_t *src, size_t src_stride, int h, int w, uint8_t *dst,
+                         size_t dst_stride, int batch)
+{
+    const int dh = (h + 1) / 2, dw = (w + 1) / 2;
+    dim3 grid((dw + PD_TW - 1) / PD_TW, (dh + PD_TH - 1) / PD_TH, batch);
+    hipLaunchKernelGGL(k_pyr_down, grid, dim3(256), 0, s, src, src_stride, h, w, dst, dst_stride, dh, dw);
+}
+
+// ------------------------------------------------------------------------------------------------ Scharr
+#define SC_TW 64
+#define SC_TH 16
+#define SC_SW 72                        // staged columns [x0-4, x0+68)
+#define SC_SH (SC_TH + 2)
+
+__global__ __launch_bounds__(256) void k_scharr(const uint8_t *__restrict__ src, size_t src_stride, int h, int w,
+                                                int16_t *__restrict__ dxdy, size_t dst_stride_elems)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_src[SC_SH][SC_SW];
+    const int b = blockIdx.z;
+    const uint8_t *img = src + (size_t)b * src_stride;
+    int16_t *out = dxdy + (size_t)b * dst_stride_elems * 2;
+    const int x0 = blockIdx.x * SC_TW, y0 = blockIdx.y * SC_TH;
+    const int sx0 = x0 - 4, sy0 = y0 - 1;
+    const int tid = threadIdx.x;
+    const bool interior = sx0 >= 0 && sy0 >= 0 && sx0 + SC_SW <= w && sy0 + SC_SH <= h && (w & 3) == 0;
+    if (interior) {
+        for (int i = tid; i < SC_SH * (SC_SW / 4); i += 256) {
+            const int r = i / (SC_SW / 4), c4 = i % (SC_SW / 4);
+            *reinterpret_cast<unsigned *>(&s_src[r][c4 * 4]) =
+                *reinterpret_cast<const unsigned *>(img + (size_t)(sy0 + r) * w + sx0 + c4 * 4);
+        }
+    } else {
+        for (int i = tid; i < SC_SH * SC_SW; i += 256) {
+            const int r = i / SC_SW, c = i % SC_SW;
+            s_src[r][c] = img[(size_t)reflect101(sy0 + r, h) * w + reflect101(sx0 + c, w)];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < SC_TH * SC_TW; i += 256) {
+        const int y = i / SC_TW, x = i % SC_TW;
+        const int gy = y0 + y, gx = x0 + x;
+        if (gy < h && gx < w) {
+            const uint8_t *r0 = &s_src[y][x + 3], *r1 = &s_src[y + 1][x + 3], *r2 = &s_src[y + 2][x + 3];
+            const int dx = 3 * (r0[2] - r0[0]) + 10 * (r1[2] - r1[0]) + 3 * (r2[2] - r2[0]);
+            const int dy = 3 * (r2[0] - r0[0]) + 10 * (r2[1] - r0[1]) + 3 * (r2[2] - r0[2]);
+            const unsigned pk = ((unsigned)dx & 0xffffu) | ((unsigned)dy << 16);
+            *reinterpret_cast<unsigned *>(out + 2 * ((size_t)gy * w + gx)) = pk;
+        }
+    }
+}
+
+void ofk_launch_scharr(hipStream_t s, const uint8_t *src, size_t src_stride, int h, int w, int16_t *dxdy,
+                       size_t dst_stride_elems, int batch)
+{
+    dim3 grid((w + SC_TW - 1) / SC_TW, (h + SC_TH - 1) / SC_TH, batch);
+    hipLaunchKernelGGL(k_scharr, grid, dim3(256), 0, s, src, src_stride, h, w, dxdy, dst_stride_elems);
+}

@@ -1,0 +1,240 @@
+// k_lk.hip — pyramidal Lucas-Kanade (cv2.calcOpticalFlowPyrLK semantics), one wavefront per point.  gfx950.
+//
+// A 64-thread workgroup (= one wave) tracks one point through all pyramid levels, coarse to fine:
+//   * the (win+3)^2 neighbourhood of the previous-frame level is staged into LDS, the Scharr derivatives of its
+//     (win+1)^2 core are computed there (never materialised in HBM), and each lane keeps its <= NPL window
+//     pixels (I, Ix, Iy as int16) in registers;
+//   * a (win+1+2M)^2 region of the next-frame level is staged into LDS once per level and re-staged only when the
+//     window walks out of it, so Newton iterations touch LDS only;
+//   * the 2x2 normal matrix and the mismatch vector are exact integer sums reduced across the wave with
+//     shuffles (order-independent), converted to f32 once; the 2x2 solve is f32 with a fixed operation order.
+// Parity target: bit-identical to oracle/image_oracle.c:orc_lk_pyr.
+#include "ofk_internal.h"
+#include <float.h>
+
+#define LK_M 8                                   // margin of the staged next-frame region (pixels each side)
+
+__device__ __forceinline__ int reflect101(int i, int n)
+{
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) i = i < 0 ? -i : 2 * (n - 1) - i;
+    return i;
+}
+__device__ __forceinline__ int descale(int v, int n) { return (v + (1 << (n - 1))) >> n; }
+
+__device__ __forceinline__ long long wave_sum_i64(long long v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__device__ __forceinline__ void lk_weights(float a, float b, int &w00, int &w01, int &w10, int &w11)
+{
+    w00 = __float2int_rn((1.f - a) * (1.f - b) * 16384.f);
+    w01 = __float2int_rn(a * (1.f - b) * 16384.f);
+    w10 = __float2int_rn((1.f - a) * b * 16384.f);
+    w11 = 16384 - w00 - w01 - w10;
+}
+
+template <int WMAX>
+__global__ __launch_bounds__(64) void k_lk(const uint8_t *__restrict__ prev, const uint8_t *__restrict__ next,
+                                           size_t pyr_stride, ofk_levels lv, const float *__restrict__ prev_pts,
+                                           const int *__restrict__ counts, int pts_stride, int win, int max_count,
+                                           double eps2, double min_eig_thr, float *__restrict__ next_pts,
+                                           uint8_t *__restrict__ status, float *__restrict__ err)
+{
+    constexpr int NPL = (WMAX * WMAX + 63) / 64;               // window pixels per lane
+    constexpr int IW = WMAX + 3;                               // staged prev neighbourhood
+    constexpr int DW = WMAX + 1;                               // derivative core
+    constexpr int JW = WMAX + 1 + 2 * LK_M;                    // staged next region
+    __shared__ uint8_t s_I[IW * IW];
+    __shared__ unsigned s_D[DW * DW];
+    __shared__ uint8_t s_J[JW * JW];
+
+    const int b = blockIdx.y, p = blockIdx.x, lane = threadIdx.x;
+    if (p >= counts[b]) return;
+    const size_t pi = (size_t)b * pts_stride + p;
+    const float ptx = prev_pts[2 * pi], pty = prev_pts[2 * pi + 1];
+    const uint8_t *Pb = prev + (size_t)b * pyr_stride, *Nb = next + (size_t)b * pyr_stride;
+    const float half = (float)(win - 1) * 0.5f;
+    const int ww = win * win;
+    const int iw_ = win + 3, dw_ = win + 1, jw_ = win + 1 + 2 * LK_M;
+
+    int st = 1;
+    float errv = 0.f, nx = 0.f, ny = 0.f;
+    short pI[NPL], pIx[NPL], pIy[NPL];
+
+    for (int l = lv.n; l >= 0; --l) {
+        const int lh = lv.h[l], lw = lv.w[l];
+        const uint8_t *I = Pb + lv.off[l], *J = Nb + lv.off[l];
+        const float sc = (float)(1.0 / (double)(1 << l));
+        float px = ptx * sc, py = pty * sc, qx, qy;
+        if (l == lv.n) { qx = px; qy = py; } else { qx = nx * 2.f; qy = ny * 2.f; }
+        nx = qx; ny = qy;
+        px -= half; py -= half;
+        const int ipx = (int)floorf(px), ipy = (int)floorf(py);
+        if (ipx < -win || ipx >= lw || ipy < -win || ipy >= lh) {
+            if (l == 0) { st = 0; errv = 0.f; }
+            continue;
+        }
+        // stage prev neighbourhood (origin ipx-1, ipy-1) and its Scharr derivatives
+        __syncthreads();
+        for (int i = lane; i < iw_ * iw_; i += 64) {
+            const int r = i / iw_, c = i - r * iw_;
+            s_I[i] = I[(size_t)reflect101(ipy - 1 + r, lh) * lw + reflect101(ipx - 1 + c, lw)];
+        }
+        __syncthreads();
+        for (int i = lane; i < dw_ * dw_; i += 64) {
+            const int r = i / dw_, c = i - r * dw_;
+            const int X = ipx + c, Y = ipy + r;
+            unsigned pk = 0;
+            if (X >= 0 && X < lw && Y >= 0 && Y < lh) {       // derivative image has a constant-0 border
+                const uint8_t *r0 = s_I + r * iw_ + c, *r1 = r0 + iw_, *r2 = r1 + iw_;
+                const int dx = 3 * (r0[2] - r0[0]) + 10 * (r1[2] - r1[0]) + 3 * (r2[2] - r2[0]);
+                const int dy = 3 * (r2[0] - r0[0]) + 10 * (r2[1] - r0[1]) + 3 * (r2[2] - r0[2]);
+                pk = ((unsigned)dx & 0xffffu) | ((unsigned)dy << 16);
+            }
+            s_D[i] = pk;
+        }
+        __syncthreads();
+        int w00, w01, w10, w11;
+        lk_weights(px - (float)ipx, py - (float)ipy, w00, w01, w10, w11);
+        int a11 = 0, a12 = 0, a22 = 0;
+        long long A11s = 0, A12s = 0, A22s = 0;
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+            const int k = lane + 64 * j;
+            pI[j] = 0; pIx[j] = 0; pIy[j] = 0;
+            if (k < ww) {
+                const int y = k / win, x = k - y * win;
+                const uint8_t *i0 = s_I + (y + 1) * iw_ + x + 1, *i1 = i0 + iw_;
+                const int iv = descale(i0[0] * w00 + i0[1] * w01 + i1[0] * w10 + i1[1] * w11, 9);
+                const unsigned d00 = s_D[y * dw_ + x], d01 = s_D[y * dw_ + x + 1], d10 = s_D[(y + 1) * dw_ + x],
+                               d11 = s_D[(y + 1) * dw_ + x + 1];
+                const int ix = descale((int)(short)(d00 & 0xffffu) * w00 + (int)(short)(d01 & 0xffffu) * w01 +
+                                           (int)(short)(d10 & 0xffffu) * w10 + (int)(short)(d11 & 0xffffu) * w11, 14);
+                const int iy = descale(((int)d00 >> 16) * w00 + ((int)d01 >> 16) * w01 + ((int)d10 >> 16) * w10 +
+                                           ((int)d11 >> 16) * w11, 14);
+                pI[j] = (short)iv; pIx[j] = (short)ix; pIy[j] = (short)iy;
+                if (NPL <= 8) { a11 += ix * ix; a12 += ix * iy; a22 += iy * iy; }
+                else { A11s += (long long)ix * ix; A12s += (long long)ix * iy; A22s += (long long)iy * iy; }
+            }
+        }
+        if (NPL <= 8) { A11s = a11; A12s = a12; A22s = a22; }
+        A11s = wave_sum_i64(A11s); A12s = wave_sum_i64(A12s); A22s = wave_sum_i64(A22s);
+        const float A11 = (float)((double)A11s * 0x1p-20), A12 = (float)((double)A12s * 0x1p-20),
+                    A22 = (float)((double)A22s * 0x1p-20);
+        float D = A11 * A22 - A12 * A12;
+        const float dd = A11 - A22;
+        const float minEig = (A22 + A11 - sqrtf(dd * dd + 4.f * A12 * A12)) / (float)(2 * ww);
+        if ((double)minEig < min_eig_thr || D < FLT_EPSILON) {
+            if (l == 0) st = 0;
+            continue;
+        }
+        D = 1.f / D;
+        qx -= half; qy -= half;
+        float pdx = 0.f, pdy = 0.f;
+        int jx0 = 0, jy0 = 0;
+        bool jvalid = false;
+        int jwx = 0, jwy = 0;                                  // window origin inside the staged region
+        auto stage_J = [&](int iqx, int iqy) {
+            jx0 = iqx - LK_M; jy0 = iqy - LK_M;
+            __syncthreads();
+            for (int i = lane; i < jw_ * jw_; i += 64) {
+                const int r = i / jw_, c = i - r * jw_;
+                s_J[i] = J[(size_t)reflect101(jy0 + r, lh) * lw + reflect101(jx0 + c, lw)];
+            }
+            __syncthreads();
+            jvalid = true;
+        };
+        for (int j = 0; j < max_count; ++j) {
+            const int iqx = (int)floorf(qx), iqy = (int)floorf(qy);
+            if (iqx < -win || iqx >= lw || iqy < -win || iqy >= lh) {
+                if (l == 0) st = 0;
+                break;
+            }
+            if (!jvalid || iqx < jx0 || iqx > jx0 + 2 * LK_M || iqy < jy0 || iqy > jy0 + 2 * LK_M) stage_J(iqx, iqy);
+            jwx = iqx - jx0; jwy = iqy - jy0;
+            lk_weights(qx - (float)iqx, qy - (float)iqy, w00, w01, w10, w11);
+            int b1 = 0, b2 = 0;
+            long long B1 = 0, B2 = 0;
+#pragma unroll
+            for (int jj = 0; jj < NPL; ++jj) {
+                const int k = lane + 64 * jj;
+                if (k < ww) {
+                    const int y = k / win, x = k - y * win;
+                    const uint8_t *j0 = s_J + (jwy + y) * jw_ + jwx + x, *j1 = j0 + jw_;
+                    const int diff = descale(j0[0] * w00 + j0[1] * w01 + j1[0] * w10 + j1[1] * w11, 9) - pI[jj];
+                    if (NPL <= 8) { b1 += diff * pIx[jj]; b2 += diff * pIy[jj]; }
+                    else { B1 += (long long)diff * pIx[jj]; B2 += (long long)diff * pIy[jj]; }
+                }
+            }
+            if (NPL <= 8) { B1 = b1; B2 = b2; }
+            B1 = wave_sum_i64(B1); B2 = wave_sum_i64(B2);
+            const float fb1 = (float)((double)B1 * 0x1p-20), fb2 = (float)((double)B2 * 0x1p-20);
+            const float dx = (A12 * fb2 - A22 * fb1) * D, dy = (A12 * fb1 - A11 * fb2) * D;
+            qx += dx; qy += dy;
+            nx = qx + half; ny = qy + half;
+            if ((double)dx * (double)dx + (double)dy * (double)dy <= eps2) break;
+            if (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) {
+                nx -= dx * 0.5f; ny -= dy * 0.5f;
+                break;
+            }
+            pdx = dx; pdy = dy;
+        }
+        if (st && l == 0) {
+            const float ex = nx - half, ey = ny - half;
+            const int iex = (int)floorf(ex), iey = (int)floorf(ey);
+            if (iex < -win || iex >= lw || iey < -win || iey >= lh) { st = 0; continue; }
+            if (!jvalid || iex < jx0 || iex > jx0 + 2 * LK_M || iey < jy0 || iey > jy0 + 2 * LK_M) stage_J(iex, iey);
+            jwx = iex - jx0; jwy = iey - jy0;
+            lk_weights(ex - (float)iex, ey - (float)iey, w00, w01, w10, w11);
+            int se = 0;
+#pragma unroll
+            for (int jj = 0; jj < NPL; ++jj) {
+                const int k = lane + 64 * jj;
+                if (k < ww) {
+                    const int y = k / win, x = k - y * win;
+                    const uint8_t *j0 = s_J + (jwy + y) * jw_ + jwx + x, *j1 = j0 + jw_;
+                    const int diff = descale(j0[0] * w00 + j0[1] * w01 + j1[0] * w10 + j1[1] * w11, 9) - pI[jj];
+                    se += diff < 0 ? -diff : diff;
+                }
+            }
+            se = wave_sum_i32(se);
+            errv = (float)se / (float)(32 * ww);
+        }
+    }
+    if (lane == 0) {
+        next_pts[2 * pi] = nx; next_pts[2 * pi + 1] = ny;
+        status[pi] = (uint8_t)st;
+        err[pi] = st ? errv : 0.f;
+    }
+}
+
+void ofk_launch_lk(hipStream_t s, const uint8_t *prev, const uint8_t *next, size_t pyr_stride, const ofk_levels &lv,
+                   const float *prev_pts, const int *counts, int pts_stride, int win, int max_count, double eps,
+                   double min_eig_thr, float *next_pts, uint8_t *status, float *err, int batch)
+{
+    if (max_count < 0) max_count = 0;
+    if (max_count > 100) max_count = 100;
+    if (eps < 0) eps = 0;
+    if (eps > 10) eps = 10;
+    const double eps2 = eps * eps;
+    dim3 grid(pts_stride, batch);
+    if (win <= 15)
+        hipLaunchKernelGGL(k_lk<15>, grid, dim3(64), 0, s, prev, next, pyr_stride, lv, prev_pts, counts, pts_stride, win,
+                           max_count, eps2, min_eig_thr, next_pts, status, err);
+    else if (win <= 21)
+        hipLaunchKernelGGL(k_lk<21>, grid, dim3(64), 0, s, prev, next, pyr_stride, lv, prev_pts, counts, pts_stride, win,
+                           max_count, eps2, min_eig_thr, next_pts, status, err);
+    else
+        hipLaunchKernelGGL(k_lk<31>, grid, dim3(64), 0, s, prev, next, pyr_stride, lv, prev_pts, counts, pts_stride, win,
+                           max_count, eps2, min_eig_thr, next_pts, status, err);
+}

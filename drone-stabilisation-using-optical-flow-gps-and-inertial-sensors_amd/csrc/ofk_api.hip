@@ -1,0 +1,639 @@
+// ofk_api.hip — the C ABI of libofk.so (include/ofk.h): context lifecycle, host<->HBM plumbing, stage entry
+// points and the resident frame-pair pipeline.  No CPU fallback anywhere: every entry point launches HIP
+// kernels on the context's stream or returns an error.
+#include "ofk_internal.h"
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+static char g_create_err[512] = "";
+
+int ofk_fail(ofk_ctx *ctx, int code, const char *fmt, ...)
+{
+    char *dst = ctx ? ctx->errmsg : g_create_err;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(dst, 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+static size_t up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+ofk_levels ofk_make_levels(int h, int w, int win, int max_level)
+{
+    ofk_levels lv;
+    memset(&lv, 0, sizeof lv);
+    lv.h[0] = h; lv.w[0] = w; lv.off[0] = 0;
+    size_t off = up((size_t)h * w, 256);
+    int l = 0;
+    while (l < max_level && l < OFK_MAX_LEVELS - 1) {
+        const int nh = (lv.h[l] + 1) / 2, nw = (lv.w[l] + 1) / 2;
+        if (win > 0 && (nw <= win || nh <= win)) break;
+        ++l;
+        lv.h[l] = nh; lv.w[l] = nw; lv.off[l] = off;
+        off += up((size_t)nh * nw, 256);
+    }
+    lv.n = l;
+    return lv;
+}
+
+static size_t levels_bytes(int h, int w, int max_level)
+{
+    const ofk_levels lv = ofk_make_levels(h, w, 0, max_level);
+    return lv.off[lv.n] + up((size_t)lv.h[lv.n] * lv.w[lv.n], 256);
+}
+
+extern "C" int ofk_version(void) { return OFK_VERSION; }
+
+extern "C" const char *ofk_last_error(const ofk_ctx *ctx) { return ctx ? ctx->errmsg : g_create_err; }
+
+extern "C" int ofk_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int ofk_device_sync(void) { return hipDeviceSynchronize() == hipSuccess ? OFK_OK : OFK_E_HIP; }
+
+#define ALLOC(ptr, bytes)                                                                                     \
+    do {                                                                                                      \
+        hipError_t e_ = hipMalloc((void **)&(ptr), (bytes));                                                  \
+        if (e_ != hipSuccess) {                                                                               \
+            ofk_fail(nullptr, OFK_E_HIP, "hipMalloc(%zu bytes) for %s: %s", (size_t)(bytes), #ptr, hipGetErrorString(e_)); \
+            ofk_destroy(c);                                                                                   \
+            return OFK_E_HIP;                                                                                 \
+        }                                                                                                     \
+    } while (0)
+
+extern "C" int ofk_create(int device, int max_w, int max_h, int max_batch, int max_pts, int max_level, ofk_ctx **out)
+{
+    if (!out) return ofk_fail(nullptr, OFK_E_INVALID, "out is NULL");
+    *out = nullptr;
+    if (max_w < 16 || max_h < 16 || max_w > 16384 || max_h > 16384 || max_batch < 1 || max_pts < 1 || max_pts > 4096 ||
+        max_level < 0 || max_level > 8)
+        return ofk_fail(nullptr, OFK_E_INVALID, "ofk_create: bad limits (w %d h %d batch %d pts %d level %d)", max_w, max_h,
+                        max_batch, max_pts, max_level);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ofk_fail(nullptr, OFK_E_NOGPU, "no HIP device visible");
+    if (device < 0 || device >= ndev) return ofk_fail(nullptr, OFK_E_INVALID, "device %d out of range (%d visible)", device, ndev);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return ofk_fail(nullptr, OFK_E_HIP, "hipGetDeviceProperties failed");
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return ofk_fail(nullptr, OFK_E_NOGPU, "device %d is %s; libofk.so is built for gfx950 only", device, prop.gcnArchName);
+    if (hipSetDevice(device) != hipSuccess) return ofk_fail(nullptr, OFK_E_HIP, "hipSetDevice(%d) failed", device);
+
+    ofk_ctx *c = (ofk_ctx *)calloc(1, sizeof(ofk_ctx));
+    if (!c) return ofk_fail(nullptr, OFK_E_INVALID, "out of host memory");
+    c->device = device; c->max_w = max_w; c->max_h = max_h; c->max_batch = max_batch; c->max_pts = max_pts; c->max_level = max_level;
+    c->P = (size_t)max_w * max_h;
+    c->bgr_stride = up(c->P * 3, 256);
+    c->pyr_stride = levels_bytes(max_h, max_w, max_level);
+    c->img_stride = up(c->P, 64);
+    c->cand_cap = (int)(c->P / 4 < 4096 ? 4096 : c->P / 4);
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { free(c); return ofk_fail(nullptr, OFK_E_HIP, "hipStreamCreate failed"); }
+    const size_t B = (size_t)max_batch;
+    for (int k = 0; k < 2; ++k) { ALLOC(c->bgr[k], B * c->bgr_stride); ALLOC(c->pyr[k], B * c->pyr_stride); }
+    ALLOC(c->eig, B * c->img_stride * sizeof(float));
+    ALLOC(c->cand, B * (size_t)c->cand_cap * 8);
+    ALLOC(c->cand_count, B * 4); ALLOC(c->maxbits, B * 4);
+    ALLOC(c->pts_prev, B * max_pts * 8); ALLOC(c->pts_next, B * max_pts * 8);
+    ALLOC(c->status, B * max_pts); ALLOC(c->err, B * max_pts * 4); ALLOC(c->counts, B * 4);
+    ALLOC(c->sensors, B * OFK_SENSOR_DOUBLES * 8); ALLOC(c->records, B * OFK_RECORD_DOUBLES * 8);
+    ALLOC(c->dev_flags, 16);
+    hipMemsetAsync(c->dev_flags, 0, 16, c->stream);
+    hipMemsetAsync(c->counts, 0, B * 4, c->stream);
+    hipMemsetAsync(c->sensors, 0, B * OFK_SENSOR_DOUBLES * 8, c->stream);
+    c->ev_cap = 4096;
+    c->ev = (hipEvent_t *)calloc(c->ev_cap, sizeof(hipEvent_t));
+    c->ev_stage = (int *)calloc(c->ev_cap / 2, sizeof(int));
+    hipStreamSynchronize(c->stream);
+    *out = c;
+    return OFK_OK;
+}
+
+extern "C" int ofk_destroy(ofk_ctx *c)
+{
+    if (!c) return OFK_OK;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (int k = 0; k < 2; ++k) { if (c->bgr[k]) hipFree(c->bgr[k]); if (c->pyr[k]) hipFree(c->pyr[k]); }
+    void *ptrs[] = {c->eig, c->mask, c->deriv, c->cand, c->cand_count, c->maxbits, c->pts_prev, c->pts_next, c->status, c->err,
+                    c->counts, c->sensors, c->records, c->dev_flags, c->scratch};
+    for (void *p : ptrs) if (p) hipFree(p);
+    if (c->hstage) hipHostFree(c->hstage);
+    if (c->ev) { for (int i = 0; i < c->ev_cap; ++i) if (c->ev[i]) hipEventDestroy(c->ev[i]); free(c->ev); }
+    free(c->ev_stage);
+    if (c->stream) hipStreamDestroy(c->stream);
+    free(c);
+    return OFK_OK;
+}
+
+extern "C" int ofk_sync(ofk_ctx *c)
+{
+    if (!c) return OFK_E_INVALID;
+    OFK_HIP(c, hipStreamSynchronize(c->stream));
+    return OFK_OK;
+}
+
+int ofk_need_scratch(ofk_ctx *c, size_t bytes)
+{
+    if (bytes <= c->scratch_bytes) return OFK_OK;
+    if (c->scratch) { hipStreamSynchronize(c->stream); hipFree(c->scratch); c->scratch = nullptr; c->scratch_bytes = 0; }
+    bytes = up(bytes, 1 << 20);
+    OFK_HIP(c, hipMalloc(&c->scratch, bytes));
+    c->scratch_bytes = bytes;
+    return OFK_OK;
+}
+
+static int check_geom(ofk_ctx *c, int batch, int h, int w, const char *who)
+{
+    if (!c) return OFK_E_INVALID;
+    if (hipSetDevice(c->device) != hipSuccess) return ofk_fail(c, OFK_E_HIP, "hipSetDevice failed");
+    if (batch < 1 || batch > c->max_batch || h < 1 || w < 1 || (size_t)h * w > c->P || h > 16384 || w > 16384)
+        return ofk_fail(c, OFK_E_INVALID, "%s: batch %d / %dx%d exceeds the context (batch %d, %zu px)", who, batch, w, h, c->max_batch, c->P);
+    return OFK_OK;
+}
+
+// host [batch][bytes_per] (tight) <-> device base + b*stride
+static int h2d(ofk_ctx *c, void *dev, size_t stride, const void *host, size_t bytes_per, int batch)
+{
+    OFK_HIP(c, hipMemcpy2DAsync(dev, stride, host, bytes_per, bytes_per, batch, hipMemcpyHostToDevice, c->stream));
+    return OFK_OK;
+}
+static int d2h(ofk_ctx *c, void *host, const void *dev, size_t stride, size_t bytes_per, int batch)
+{
+    OFK_HIP(c, hipMemcpy2DAsync(host, bytes_per, dev, stride, bytes_per, batch, hipMemcpyDeviceToHost, c->stream));
+    OFK_HIP(c, hipStreamSynchronize(c->stream));
+    return OFK_OK;
+}
+static int check_launch(ofk_ctx *c, const char *who)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return ofk_fail(c, OFK_E_HIP, "%s: kernel launch failed: %s", who, hipGetErrorString(e));
+    return OFK_OK;
+}
+#define TRY(expr) do { int rc_ = (expr); if (rc_ != OFK_OK) return rc_; } while (0)
+
+static int lazy_mask(ofk_ctx *c)
+{
+    if (!c->mask) OFK_HIP(c, hipMalloc((void **)&c->mask, (size_t)c->max_batch * c->img_stride));
+    return OFK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ stage entry points
+extern "C" int ofk_gray_bgr8(ofk_ctx *c, const uint8_t *bgr, int batch, int h, int w, uint8_t *gray)
+{
+    TRY(check_geom(c, batch, h, w, "ofk_gray_bgr8"));
+    if (!bgr || !gray) return ofk_fail(c, OFK_E_INVALID, "ofk_gray_bgr8: NULL buffer");
+    const size_t px = (size_t)h * w;
+    TRY(h2d(c, c->bgr[0], c->bgr_stride, bgr, px * 3, batch));
+    ofk_launch_gray(c->stream, c->bgr[0], c->bgr_stride, c->pyr[0], c->pyr_stride, batch, h, w);
+    TRY(check_launch(c, "k_gray_bgr8"));
+    return d2h(c, gray, c->pyr[0], c->pyr_stride, px, batch);
+}
+
+extern "C" int ofk_pyr_down_u8(ofk_ctx *c, const uint8_t *src, int batch, int h, int w, uint8_t *dst)
+{
+    TRY(check_geom(c, batch, h, w, "ofk_pyr_down_u8"));
+    if (!src || !dst) return ofk_fail(c, OFK_E_INVALID, "ofk_pyr_down_u8: NULL buffer");
+    if (h < 2 || w < 2) return ofk_fail(c, OFK_E_INVALID, "ofk_pyr_down_u8: image smaller than 2x2");
+    const size_t px = (size_t)h * w, dpx = (size_t)((h + 1) / 2) * ((w + 1) / 2);
+    TRY(h2d(c, c->pyr[0], c->pyr_stride, src, px, batch));
+    ofk_launch_pyr_down(c->stream, c->pyr[0], c->pyr_stride, h, w, c->pyr[1], c->pyr_stride, batch);
+    TRY(check_launch(c, "k_pyr_down"));
+    return d2h(c, dst, c->pyr[1], c->pyr_stride, dpx, batch);
+}
+
+extern "C" int ofk_scharr_s16(ofk_ctx *c, const uint8_t *gray, int batch, int h, int w, int16_t *dxdy)
+{
+    TRY(check_geom(c, batch, h, w, "ofk_scharr_s16"));
+    if (!gray || !dxdy) return ofk_fail(c, OFK_E_INVALID, "ofk_scharr_s16: NULL buffer");
+    if (h < 2 || w < 2) return ofk_fail(c, OFK_E_INVALID, "ofk_scharr_s16: image smaller than 2x2");
+    if (!c->deriv) OFK_HIP(c, hipMalloc((void **)&c->deriv, (size_t)c->max_batch * c->img_stride * 4));
+    const size_t px = (size_t)h * w;
+    TRY(h2d(c, c->pyr[0], c->pyr_stride, gray, px, batch));
+    ofk_launch_scharr(c->stream, c->pyr[0], c->pyr_stride, h, w, c->deriv, c->img_stride, batch);
+    TRY(check_launch(c, "k_scharr"));
+    return d2h(c, dxdy, c->deriv, c->img_stride * 4, px * 4, batch);
+}
+
+static int check_block(ofk_ctx *c, int h, int w, int block)
+{
+    if (block < 1 || block > 45) return ofk_fail(c, OFK_E_INVALID, "block_size %d outside 1..45", block);
+    if (h <= block + 1 || w <= block + 1) return ofk_fail(c, OFK_E_INVALID, "image %dx%d too small for block_size %d", w, h, block);
+    return OFK_OK;
+}
+
+extern "C" int ofk_mineig_response(ofk_ctx *c, const uint8_t *gray, int batch, int h, int w, int block, float *eig)
+{
+    TRY(check_geom(c, batch, h, w, "ofk_mineig_response"));
+    if (!gray || !eig) return ofk_fail(c, OFK_E_INVALID, "ofk_mineig_response: NULL buffer");
+    TRY(check_block(c, h, w, block));
+    const size_t px = (size_t)h * w;
+    TRY(h2d(c, c->pyr[0], c->pyr_stride, gray, px, batch));
+    if (ofk_launch_mineig(c->stream, c->pyr[0], c->pyr_stride, h, w, block, c->eig, c->img_stride, nullptr, nullptr, 0, batch))
+        return ofk_fail(c, OFK_E_INVALID, "k_mineig: LDS tile too large for block_size %d", block);
+    TRY(check_launch(c, "k_mineig"));
+    return d2h(c, eig, c->eig, c->img_stride * 4, px * 4, batch);
+}
+
+static int check_select(ofk_ctx *c, int max_corners, double quality, double min_distance)
+{
+    if (max_corners < 1 || max_corners > c->max_pts) return ofk_fail(c, OFK_E_INVALID, "max_corners %d outside 1..%d", max_corners, c->max_pts);
+    if (!(quality > 0.0) || !(min_distance >= 0.0)) return ofk_fail(c, OFK_E_INVALID, "quality must be > 0 and min_distance >= 0");
+    return OFK_OK;
+}
+
+// device-side: eig (+mask) resident in ctx -> corners in pts_prev / counts
+static int run_select(ofk_ctx *c, bool have_max, const uint8_t *dmask, int batch, int h, int w, int max_corners, double quality,
+                      double min_distance)
+{
+    if (!have_max) {
+        OFK_HIP(c, hipMemsetAsync(c->maxbits, 0, (size_t)batch * 4, c->stream));
+        ofk_launch_maxbits(c->stream, c->eig, c->img_stride, dmask, c->img_stride, h, w, c->maxbits, batch);
+    }
+    OFK_HIP(c, hipMemsetAsync(c->cand_count, 0, (size_t)batch * 4, c->stream));
+    ofk_launch_nms(c->stream, c->eig, c->img_stride, dmask, c->img_stride, h, w, c->maxbits, quality, c->cand, c->cand_cap,
+                   c->cand_count, c->dev_flags, batch);
+    ofk_launch_select(c->stream, c->cand, c->cand_cap, c->cand_count, w, max_corners, (float)min_distance, c->pts_prev,
+                      c->max_pts, c->counts, batch);
+    return check_launch(c, "corner selection");
+}
+
+static int fetch_corners(ofk_ctx *c, int batch, int max_corners, float *pts, int *counts)
+{
+    int flags[4];
+    OFK_HIP(c, hipMemcpyAsync(flags, c->dev_flags, 16, hipMemcpyDeviceToHost, c->stream));
+    OFK_HIP(c, hipMemcpyAsync(counts, c->counts, (size_t)batch * 4, hipMemcpyDeviceToHost, c->stream));
+    TRY(d2h(c, pts, c->pts_prev, (size_t)c->max_pts * 8, (size_t)max_corners * 8, batch));
+    if (flags[0] & 1) {
+        hipMemsetAsync(c->dev_flags, 0, 16, c->stream);
+        return ofk_fail(c, OFK_E_CAPACITY, "corner candidates exceeded the per-image capacity (%d)", c->cand_cap);
+    }
+    return OFK_OK;
+}
+
+extern "C" int ofk_select_corners(ofk_ctx *c, const float *eig, const uint8_t *mask, int batch, int h, int w, int max_corners,
+                                  double quality, double min_distance, float *pts, int *counts)
+{
+    TRY(check_geom(c, batch, h, w, "ofk_select_corners"));
+    if (!eig || !pts || !counts) return ofk_fail(c, OFK_E_INVALID, "ofk_select_corners: NULL buffer");
+    if (h < 3 || w < 3) return ofk_fail(c, OFK_E_INVALID, "ofk_select_corners: image smaller than 3x3");
+    TRY(check_select(c, max_corners, quality, min_distance));
+    const size_t px = (size_t)h * w;
+    TRY(h2d(c, c->eig, c->img_stride * 4, eig, px * 4, batch));
+    const uint8_t *dmask = nullptr;
+    if (mask) { TRY(lazy_mask(c)); TRY(h2d(c, c->mask, c->img_stride, mask, px, batch)); dmask = c->mask; }
+    TRY(run_select(c, false, dmask, batch, h, w, max_corners, quality, min_distance));
+    return fetch_corners(c, batch, max_corners, pts, counts);
+}
+
+extern "C" int ofk_good_features(ofk_ctx *c, const uint8_t *gray, const uint8_t *mask, int batch, int h, int w, int max_corners,
+                                 double quality, double min_distance, int block, float *pts, int *counts)
+{
+    TRY(check_geom(c, batch, h, w, "ofk_good_features"));
+    if (!gray || !pts || !counts) return ofk_fail(c, OFK_E_INVALID, "ofk_good_features: NULL buffer");
+    TRY(check_block(c, h, w, block));
+    TRY(check_select(c, max_corners, quality, min_distance));
+    const size_t px = (size_t)h * w;
+    TRY(h2d(c, c->pyr[0], c->pyr_stride, gray, px, batch));
+    const uint8_t *dmask = nullptr;
+    if (mask) { TRY(lazy_mask(c)); TRY(h2d(c, c->mask, c->img_stride, mask, px, batch)); dmask = c->mask; }
+    OFK_HIP(c, hipMemsetAsync(c->maxbits, 0, (size_t)batch * 4, c->stream));
+    if (ofk_launch_mineig(c->stream, c->pyr[0], c->pyr_stride, h, w, block, c->eig, c->img_stride, c->maxbits, dmask, c->img_stride, batch))
+        return ofk_fail(c, OFK_E_INVALID, "k_mineig: LDS tile too large for block_size %d", block);
+    TRY(run_select(c, true, dmask, batch, h, w, max_corners, quality, min_distance));
+    return fetch_corners(c, batch, max_corners, pts, counts);
+}
+
+static int check_lk(ofk_ctx *c, int h, int w, int win, int max_level)
+{
+    if (win < 3 || win > 31 || (win & 1) == 0) return ofk_fail(c, OFK_E_INVALID, "win %d must be odd and in 3..31", win);
+    if (max_level < 0 || max_level > c->max_level) return ofk_fail(c, OFK_E_INVALID, "max_level %d outside 0..%d", max_level, c->max_level);
+    if (h <= win || w <= win) return ofk_fail(c, OFK_E_INVALID, "image %dx%d not larger than the LK window %d", w, h, win);
+    return OFK_OK;
+}
+
+// builds levels 1..L of both resident pyramids
+static void build_pyramids(ofk_ctx *c, const ofk_levels &lv, int batch, int which_mask)
+{
+    for (int k = 0; k < 2; ++k) {
+        if (!(which_mask & (1 << k))) continue;
+        for (int l = 1; l <= lv.n; ++l)
+            ofk_launch_pyr_down(c->stream, c->pyr[k] + lv.off[l - 1], c->pyr_stride, lv.h[l - 1], lv.w[l - 1],
+                                c->pyr[k] + lv.off[l], c->pyr_stride, batch);
+    }
+}
+
+extern "C" int ofk_lk_pyr(ofk_ctx *c, const uint8_t *prev, const uint8_t *next, int batch, int h, int w, const float *prev_pts,
+                          const int *counts, int pts_stride, int win, int max_level, int max_count, double eps, double min_eig_thr,
+                          float *next_pts, uint8_t *status, float *err)
+{
+    TRY(check_geom(c, batch, h, w, "ofk_lk_pyr"));
+    if (!prev || !next || !prev_pts || !counts || !next_pts || !status || !err) return ofk_fail(c, OFK_E_INVALID, "ofk_lk_pyr: NULL buffer");
+    TRY(check_lk(c, h, w, win, max_level));
+    if (pts_stride < 1 || pts_stride > c->max_pts) return ofk_fail(c, OFK_E_INVALID, "pts_stride %d outside 1..%d", pts_stride, c->max_pts);
+    for (int b = 0; b < batch; ++b)
+        if (counts[b] < 0 || counts[b] > pts_stride) return ofk_fail(c, OFK_E_INVALID, "counts[%d]=%d outside 0..%d", b, counts[b], pts_stride);
+    const size_t px = (size_t)h * w;
+    const ofk_levels lv = ofk_make_levels(h, w, win, max_level);
+    TRY(h2d(c, c->pyr[0], c->pyr_stride, prev, px, batch));
+    TRY(h2d(c, c->pyr[1], c->pyr_stride, next, px, batch));
+    TRY(h2d(c, c->pts_prev, (size_t)c->max_pts * 8, prev_pts, (size_t)pts_stride * 8, batch));
+    OFK_HIP(c, hipMemcpyAsync(c->counts, counts, (size_t)batch * 4, hipMemcpyHostToDevice, c->stream));
+    build_pyramids(c, lv, batch, 3);
+    ofk_launch_lk(c->stream, c->pyr[0], c->pyr[1], c->pyr_stride, lv, c->pts_prev, c->counts, c->max_pts, win, max_count, eps,
+                  min_eig_thr, c->pts_next, c->status, c->err, batch);
+    TRY(check_launch(c, "k_lk"));
+    OFK_HIP(c, hipMemcpy2DAsync(next_pts, (size_t)pts_stride * 8, c->pts_next, (size_t)c->max_pts * 8, (size_t)pts_stride * 8, batch,
+                                hipMemcpyDeviceToHost, c->stream));
+    OFK_HIP(c, hipMemcpy2DAsync(status, pts_stride, c->status, c->max_pts, pts_stride, batch, hipMemcpyDeviceToHost, c->stream));
+    return d2h(c, err, c->err, (size_t)c->max_pts * 4, (size_t)pts_stride * 4, batch);
+}
+
+// ------------------------------------------------------------------------------------------------ estimation entry points
+struct Bump {                                               // carves device scratch and uploads host arrays
+    ofk_ctx *c; char *base; size_t off; int rc;
+    double *put(const void *host, size_t bytes)
+    {
+        if (!host) return nullptr;
+        char *p = base + off;
+        off += up(bytes, 256);
+        if (rc == OFK_OK && hipMemcpyAsync(p, host, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = OFK_E_HIP;
+        return (double *)p;
+    }
+    double *take(size_t bytes) { char *p = base + off; off += up(bytes, 256); return (double *)p; }
+};
+static int get(ofk_ctx *c, void *host, const void *dev, size_t bytes)
+{
+    OFK_HIP(c, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    OFK_HIP(c, hipStreamSynchronize(c->stream));
+    return OFK_OK;
+}
+static int est_begin(ofk_ctx *c, size_t bytes, Bump &bp)
+{
+    if (!c) return OFK_E_INVALID;
+    if (hipSetDevice(c->device) != hipSuccess) return ofk_fail(c, OFK_E_HIP, "hipSetDevice failed");
+    TRY(ofk_need_scratch(c, bytes + 64 * 256));
+    bp.c = c; bp.base = (char *)c->scratch; bp.off = 0; bp.rc = OFK_OK;
+    return OFK_OK;
+}
+
+extern "C" int ofk_flow_model(ofk_ctx *c, const double *x, int batch, int n, const double *v, const double *omega, const double *d,
+                              const double *nrm, const double *t, double *flow)
+{
+    if (!c || !x || !v || !omega || !d || !nrm || !flow || batch < 1 || n < 1) return ofk_fail(c, OFK_E_INVALID, "ofk_flow_model: bad argument");
+    const size_t pb = (size_t)batch * n * 16;
+    Bump bp;
+    TRY(est_begin(c, 2 * pb + (size_t)batch * 256 * 5, bp));
+    double *dx = bp.put(x, pb), *dv = bp.put(v, batch * 24), *dom = bp.put(omega, batch * 24), *dd = bp.put(d, batch * 8),
+           *dn = bp.put(nrm, batch * 24), *dt = bp.put(t, batch * 24), *df = bp.take(pb);
+    if (bp.rc) return ofk_fail(c, OFK_E_HIP, "ofk_flow_model: upload failed");
+    ofk_launch_flow_model(c->stream, dx, batch, n, dv, dom, dd, dn, dt, df);
+    TRY(check_launch(c, "k_flow_model"));
+    return get(c, flow, df, pb);
+}
+
+extern "C" int ofk_feasibility(ofk_ctx *c, int variant, const double *x, const double *u, int batch, int n, const double *nrm,
+                               const double *v, const double *dist, const double *omega, const double *t, double *r, double *dd)
+{
+    if (!c || !x || !u || !nrm || !v || !r || !dd || batch < 1 || n < 1 || variant < 0 || variant > 2)
+        return ofk_fail(c, OFK_E_INVALID, "ofk_feasibility: bad argument");
+    if (variant == OFK_FEAS_RTILDE && !dist) return ofk_fail(c, OFK_E_INVALID, "ofk_feasibility: dist required");
+    if (variant == OFK_FEAS_SIM && (!omega || !t)) return ofk_fail(c, OFK_E_INVALID, "ofk_feasibility: omega and t required");
+    const size_t pb = (size_t)batch * n * 16, rb = (size_t)batch * n * 8;
+    Bump bp;
+    TRY(est_begin(c, 2 * pb + 2 * rb + (size_t)batch * 256 * 5, bp));
+    double *dx = bp.put(x, pb), *du = bp.put(u, pb), *dn = bp.put(nrm, batch * 24), *dv = bp.put(v, batch * 24),
+           *ddist = bp.put(dist, batch * 8), *dom = bp.put(omega, batch * 24), *dt = bp.put(t, batch * 24), *dr = bp.take(rb),
+           *ddd = bp.take(rb);
+    if (bp.rc) return ofk_fail(c, OFK_E_HIP, "ofk_feasibility: upload failed");
+    ofk_launch_feasibility(c->stream, variant, dx, du, batch, n, dn, dv, ddist, dom, dt, dr, ddd);
+    TRY(check_launch(c, "k_feasibility"));
+    TRY(get(c, r, dr, rb));
+    return get(c, dd, ddd, rb);
+}
+
+extern "C" int ofk_velocity_solve(ofk_ctx *c, int variant, const double *x, const double *u, const uint8_t *valid, int batch, int n,
+                                  const double *d, const double *nrm, const double *omega, const double *t, const double *wgt,
+                                  double *out)
+{
+    if (!c || !x || !u || !nrm || !out || batch < 1 || n < 1 || variant < 0 || variant > 2)
+        return ofk_fail(c, OFK_E_INVALID, "ofk_velocity_solve: bad argument");
+    if (variant == OFK_SOLVE_OFMODULE ? !wgt : (!d || !omega)) return ofk_fail(c, OFK_E_INVALID, "ofk_velocity_solve: missing input for variant %d", variant);
+    const size_t pb = (size_t)batch * n * 16;
+    Bump bp;
+    TRY(est_begin(c, 2 * pb + (size_t)batch * n * 9 + (size_t)batch * 256 * 6, bp));
+    double *dx = bp.put(x, pb), *du = bp.put(u, pb);
+    uint8_t *dval = (uint8_t *)bp.put(valid, (size_t)batch * n);
+    double *dd = bp.put(d, batch * 8), *dn = bp.put(nrm, batch * 24), *dom = bp.put(omega, batch * 24), *dt = bp.put(t, batch * 24),
+           *dw = bp.put(wgt, (size_t)batch * n * 8), *dout = bp.take((size_t)batch * OFK_SOLVE_DOUBLES * 8);
+    if (bp.rc) return ofk_fail(c, OFK_E_HIP, "ofk_velocity_solve: upload failed");
+    ofk_launch_solve(c->stream, variant, dx, du, dval, batch, n, dd, dn, dom, dt, dw, dout);
+    TRY(check_launch(c, "k_solve"));
+    return get(c, out, dout, (size_t)batch * OFK_SOLVE_DOUBLES * 8);
+}
+
+extern "C" int ofk_imu_propagate(ofk_ctx *c, double *state, const double *msg, int batch)
+{
+    if (!c || !state || !msg || batch < 1) return ofk_fail(c, OFK_E_INVALID, "ofk_imu_propagate: bad argument");
+    Bump bp;
+    TRY(est_begin(c, (size_t)batch * (OFK_IMU_STATE + OFK_IMU_MSG) * 8, bp));
+    double *ds = bp.put(state, (size_t)batch * OFK_IMU_STATE * 8), *dm = bp.put(msg, (size_t)batch * OFK_IMU_MSG * 8);
+    if (bp.rc) return ofk_fail(c, OFK_E_HIP, "ofk_imu_propagate: upload failed");
+    ofk_launch_imu(c->stream, ds, dm, batch);
+    TRY(check_launch(c, "k_imu"));
+    return get(c, state, ds, (size_t)batch * OFK_IMU_STATE * 8);
+}
+
+extern "C" int ofk_post_solve(ofk_ctx *c, const double *v_obs, const double *rotation, const double *ang, const double *offset,
+                              int batch, double *v_uav)
+{
+    if (!c || !v_obs || !rotation || !ang || !offset || !v_uav || batch < 1) return ofk_fail(c, OFK_E_INVALID, "ofk_post_solve: bad argument");
+    Bump bp;
+    TRY(est_begin(c, (size_t)batch * 24 * 8, bp));
+    double *dv = bp.put(v_obs, batch * 24), *dr = bp.put(rotation, batch * 72), *da = bp.put(ang, batch * 24),
+           *dof = bp.put(offset, batch * 24), *dout = bp.take(batch * 24);
+    if (bp.rc) return ofk_fail(c, OFK_E_HIP, "ofk_post_solve: upload failed");
+    ofk_launch_post_solve(c->stream, dv, dr, da, dof, batch, dout);
+    TRY(check_launch(c, "k_post_solve"));
+    return get(c, v_uav, dout, batch * 24);
+}
+
+extern "C" int ofk_kf_predict_update(ofk_ctx *c, int ns, int nm, int nc, const double *F, const double *Bm, const double *H,
+                                     const double *Q, const double *Rm, double *x, double *P, const double *u, const double *z,
+                                     int batch, int do_predict)
+{
+    if (!c || ns < 1 || ns > 6 || nm < 1 || nm > 6 || nc < 0 || nc > 6 || !F || !H || !Q || !Rm || !x || !P || batch < 1)
+        return ofk_fail(c, OFK_E_INVALID, "ofk_kf_predict_update: bad argument");
+    Bump bp;
+    TRY(est_begin(c, (size_t)batch * (ns + ns * ns + nc + nm) * 8 + 8 * 256 * 8, bp));
+    double *dF = bp.put(F, ns * ns * 8), *dB = (Bm && nc) ? bp.put(Bm, ns * nc * 8) : nullptr, *dH = bp.put(H, nm * ns * 8),
+           *dQ = bp.put(Q, ns * ns * 8), *dR = bp.put(Rm, nm * nm * 8), *dx = bp.put(x, (size_t)batch * ns * 8),
+           *dP = bp.put(P, (size_t)batch * ns * ns * 8), *du = (u && nc) ? bp.put(u, (size_t)batch * nc * 8) : nullptr,
+           *dz = bp.put(z, (size_t)batch * nm * 8);
+    if (bp.rc) return ofk_fail(c, OFK_E_HIP, "ofk_kf_predict_update: upload failed");
+    ofk_launch_kf(c->stream, ns, nm, nc, dF, dB, dH, dQ, dR, dx, dP, du, dz, batch, do_predict);
+    TRY(check_launch(c, "k_kf"));
+    TRY(get(c, x, dx, (size_t)batch * ns * 8));
+    return get(c, P, dP, (size_t)batch * ns * ns * 8);
+}
+
+extern "C" int ofk_of_simulation(ofk_ctx *c, const double *truth, const double *sig, const double *pos, const double *true_flow,
+                                 int n, const double *z, int trials, double *v_obs, double *bound)
+{
+    if (!c || !truth || !sig || !pos || !true_flow || !z || !v_obs || !bound || n < 1 || trials < 1)
+        return ofk_fail(c, OFK_E_INVALID, "ofk_of_simulation: bad argument");
+    const size_t zb = (size_t)trials * (10 + 4 * (size_t)n) * 8;
+    Bump bp;
+    TRY(est_begin(c, zb + (size_t)n * 32 + (size_t)trials * 32 + 8 * 256, bp));
+    double *dt = bp.put(truth, 13 * 8), *ds = bp.put(sig, 6 * 8), *dp = bp.put(pos, (size_t)n * 16), *df = bp.put(true_flow, (size_t)n * 16),
+           *dz = bp.put(z, zb), *dv = bp.take((size_t)trials * 24), *db = bp.take((size_t)trials * 8);
+    if (bp.rc) return ofk_fail(c, OFK_E_HIP, "ofk_of_simulation: upload failed");
+    ofk_launch_of_simulation(c->stream, dt, ds, dp, df, n, dz, trials, dv, db);
+    TRY(check_launch(c, "k_of_simulation"));
+    TRY(get(c, v_obs, dv, (size_t)trials * 24));
+    return get(c, bound, db, (size_t)trials * 8);
+}
+
+// ------------------------------------------------------------------------------------------------ resident pipeline
+extern "C" int ofk_pairs_upload(ofk_ctx *c, const uint8_t *prev_bgr, const uint8_t *next_bgr, int batch, int h, int w)
+{
+    TRY(check_geom(c, batch, h, w, "ofk_pairs_upload"));
+    if (!prev_bgr || !next_bgr) return ofk_fail(c, OFK_E_INVALID, "ofk_pairs_upload: NULL buffer");
+    const size_t px = (size_t)h * w;
+    TRY(h2d(c, c->bgr[0], c->bgr_stride, prev_bgr, px * 3, batch));
+    TRY(h2d(c, c->bgr[1], c->bgr_stride, next_bgr, px * 3, batch));
+    OFK_HIP(c, hipStreamSynchronize(c->stream));
+    c->cur_batch = batch; c->cur_h = h; c->cur_w = w;
+    return OFK_OK;
+}
+
+extern "C" int ofk_pairs_set_sensors(ofk_ctx *c, const double *sensors, int batch)
+{
+    if (!c || !sensors || batch < 1 || batch > c->max_batch) return ofk_fail(c, OFK_E_INVALID, "ofk_pairs_set_sensors: bad argument");
+    OFK_HIP(c, hipMemcpyAsync(c->sensors, sensors, (size_t)batch * OFK_SENSOR_DOUBLES * 8, hipMemcpyHostToDevice, c->stream));
+    OFK_HIP(c, hipStreamSynchronize(c->stream));
+    return OFK_OK;
+}
+
+struct StageTimer {
+    ofk_ctx *c; int stage; bool on;
+    StageTimer(ofk_ctx *c_, int st) : c(c_), stage(st), on(((c_->prof_mask >> st) & 1) && c_->ev_n + 2 <= c_->ev_cap)
+    {
+        if (!on) return;
+        if (!c->ev[c->ev_n]) hipEventCreate(&c->ev[c->ev_n]);
+        if (!c->ev[c->ev_n + 1]) hipEventCreate(&c->ev[c->ev_n + 1]);
+        hipEventRecord(c->ev[c->ev_n], c->stream);
+    }
+    ~StageTimer()
+    {
+        if (!on) return;
+        hipEventRecord(c->ev[c->ev_n + 1], c->stream);
+        c->ev_stage[c->ev_n / 2] = stage;
+        c->ev_n += 2;
+    }
+};
+
+extern "C" int ofk_pairs_run(ofk_ctx *c, const ofk_params *p)
+{
+    if (!c || !p) return OFK_E_INVALID;
+    if (c->cur_batch < 1) return ofk_fail(c, OFK_E_INVALID, "ofk_pairs_run: no resident frame pairs (call ofk_pairs_upload)");
+    if (hipSetDevice(c->device) != hipSuccess) return ofk_fail(c, OFK_E_HIP, "hipSetDevice failed");
+    const int B = c->cur_batch, h = c->cur_h, w = c->cur_w;
+    TRY(check_block(c, h, w, p->block_size));
+    TRY(check_select(c, p->max_corners, p->quality, p->min_distance));
+    TRY(check_lk(c, h, w, p->win, p->max_level));
+    if (p->solve_variant != OFK_SOLVE_NODE && p->solve_variant != OFK_SOLVE_SIM) return ofk_fail(c, OFK_E_INVALID, "solve_variant must be NODE or SIM");
+    const ofk_levels lv = ofk_make_levels(h, w, p->win, p->max_level);
+    {
+        StageTimer t(c, OFK_STAGE_GRAY);
+        ofk_launch_gray(c->stream, c->bgr[0], c->bgr_stride, c->pyr[0], c->pyr_stride, B, h, w);
+        ofk_launch_gray(c->stream, c->bgr[1], c->bgr_stride, c->pyr[1], c->pyr_stride, B, h, w);
+    }
+    {
+        StageTimer t(c, OFK_STAGE_PYR);
+        build_pyramids(c, lv, B, 3);
+    }
+    {
+        StageTimer t(c, OFK_STAGE_EIG);
+        hipMemsetAsync(c->maxbits, 0, (size_t)B * 4, c->stream);
+        hipMemsetAsync(c->cand_count, 0, (size_t)B * 4, c->stream);
+        if (ofk_launch_mineig(c->stream, c->pyr[0], c->pyr_stride, h, w, p->block_size, c->eig, c->img_stride, c->maxbits, nullptr, 0, B))
+            return ofk_fail(c, OFK_E_INVALID, "k_mineig: LDS tile too large for block_size %d", p->block_size);
+    }
+    {
+        StageTimer t(c, OFK_STAGE_NMS);
+        ofk_launch_nms(c->stream, c->eig, c->img_stride, nullptr, 0, h, w, c->maxbits, p->quality, c->cand, c->cand_cap, c->cand_count,
+                       c->dev_flags, B);
+    }
+    {
+        StageTimer t(c, OFK_STAGE_SELECT);
+        ofk_launch_select(c->stream, c->cand, c->cand_cap, c->cand_count, w, p->max_corners, (float)p->min_distance, c->pts_prev,
+                          c->max_pts, c->counts, B);
+    }
+    {
+        StageTimer t(c, OFK_STAGE_LK);
+        ofk_launch_lk(c->stream, c->pyr[0], c->pyr[1], c->pyr_stride, lv, c->pts_prev, c->counts, c->max_pts, p->win, p->max_count,
+                      p->eps, p->min_eig_thr, c->pts_next, c->status, c->err, B);
+    }
+    {
+        StageTimer t(c, OFK_STAGE_SOLVE);
+        ofk_launch_pairs_solve(c->stream, c->pts_prev, c->pts_next, c->status, c->counts, c->max_pts, c->sensors, p->solve_variant,
+                               p->use_feasibility, p->feas_T, c->records, B);
+    }
+    return check_launch(c, "ofk_pairs_run");
+}
+
+extern "C" int ofk_pairs_download(ofk_ctx *c, double *records, float *prev_pts, float *next_pts, uint8_t *status, float *err,
+                                  int *counts)
+{
+    if (!c || c->cur_batch < 1) return ofk_fail(c, OFK_E_INVALID, "ofk_pairs_download: nothing resident");
+    if (hipSetDevice(c->device) != hipSuccess) return ofk_fail(c, OFK_E_HIP, "hipSetDevice failed");
+    const int B = c->cur_batch;
+    const size_t np = (size_t)B * c->max_pts;
+    int flags[4];
+    OFK_HIP(c, hipMemcpyAsync(flags, c->dev_flags, 16, hipMemcpyDeviceToHost, c->stream));
+    if (records) OFK_HIP(c, hipMemcpyAsync(records, c->records, (size_t)B * OFK_RECORD_DOUBLES * 8, hipMemcpyDeviceToHost, c->stream));
+    if (prev_pts) OFK_HIP(c, hipMemcpyAsync(prev_pts, c->pts_prev, np * 8, hipMemcpyDeviceToHost, c->stream));
+    if (next_pts) OFK_HIP(c, hipMemcpyAsync(next_pts, c->pts_next, np * 8, hipMemcpyDeviceToHost, c->stream));
+    if (status) OFK_HIP(c, hipMemcpyAsync(status, c->status, np, hipMemcpyDeviceToHost, c->stream));
+    if (err) OFK_HIP(c, hipMemcpyAsync(err, c->err, np * 4, hipMemcpyDeviceToHost, c->stream));
+    if (counts) OFK_HIP(c, hipMemcpyAsync(counts, c->counts, (size_t)B * 4, hipMemcpyDeviceToHost, c->stream));
+    OFK_HIP(c, hipStreamSynchronize(c->stream));
+    if (flags[0] & 1) {
+        hipMemsetAsync(c->dev_flags, 0, 16, c->stream);
+        return ofk_fail(c, OFK_E_CAPACITY, "corner candidates exceeded the per-image capacity (%d)", c->cand_cap);
+    }
+    return OFK_OK;
+}
+
+extern "C" int ofk_pairs_export_records_f32(ofk_ctx *c, void *device_dst, int batch)
+{
+    if (!c || !device_dst || batch < 1 || batch > c->cur_batch) return ofk_fail(c, OFK_E_INVALID, "ofk_pairs_export_records_f32: bad argument");
+    ofk_launch_records_f32(c->stream, c->records, (float *)device_dst, batch);
+    return check_launch(c, "k_records_f32");
+}
+
+extern "C" int ofk_profile_enable(ofk_ctx *c, int stage_mask)
+{
+    if (!c) return OFK_E_INVALID;
+    c->prof_mask = stage_mask;
+    return OFK_OK;
+}
+
+extern "C" int ofk_profile_read(ofk_ctx *c, double *ms_total, int *launches)
+{
+    if (!c || !ms_total || !launches) return OFK_E_INVALID;
+    OFK_HIP(c, hipStreamSynchronize(c->stream));
+    for (int s = 0; s < OFK_N_STAGES; ++s) { ms_total[s] = 0.0; launches[s] = 0; }
+    for (int i = 0; i + 1 < c->ev_n; i += 2) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]) == hipSuccess) { ms_total[c->ev_stage[i / 2]] += ms; launches[c->ev_stage[i / 2]] += 1; }
+    }
+    c->ev_n = 0;
+    return OFK_OK;
+}

@@ -1,0 +1,102 @@
+// ofk_internal.h — context layout and kernel-launcher prototypes shared by the libofk.so sources.
+// gfx950 only (wave64, 160 KiB LDS/CU, 256 CUs in 8 XCDs).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "ofk.h"
+
+#define OFK_MAX_LEVELS 9            // level 0 .. 8
+#define OFK_CHUNK 4096              // candidates sorted per selection round (LDS resident)
+
+struct ofk_levels {
+    int n;                          // deepest level index in use (0..8)
+    int h[OFK_MAX_LEVELS], w[OFK_MAX_LEVELS];
+    size_t off[OFK_MAX_LEVELS];     // byte offset of level l inside one image's pyramid slab (256-B aligned)
+};
+
+struct ofk_ctx {
+    int device;
+    hipStream_t stream;
+    int max_w, max_h, max_batch, max_pts, max_level;
+    size_t P;                       // max_w * max_h
+    size_t bgr_stride;              // bytes between images in bgr[], 256-B aligned
+    size_t pyr_stride;              // bytes between images in pyr[], 256-B aligned (all levels of one image)
+    size_t img_stride;              // elements between images in eig/mask (P rounded up to 64)
+    int cand_cap;                   // candidate keys per image
+
+    uint8_t *bgr[2];                // [B][bgr_stride]            prev / next BGR frames
+    uint8_t *pyr[2];                // [B][pyr_stride]            gray pyramids (level 0 = gray frame)
+    float *eig;                     // [B][img_stride]            Shi-Tomasi response
+    uint8_t *mask;                  // [B][img_stride]            optional detection mask (lazily allocated)
+    int16_t *deriv;                 // [B][img_stride][2]         only for ofk_scharr_s16 (lazily allocated)
+    unsigned long long *cand;       // [B][cand_cap]              candidate keys (~value bits << 32 | linear index)
+    int *cand_count;                // [B]
+    unsigned int *maxbits;          // [B]                        bit pattern of max positive response
+    float *pts_prev, *pts_next;     // [B][max_pts][2]
+    uint8_t *status;                // [B][max_pts]
+    float *err;                     // [B][max_pts]
+    int *counts;                    // [B]                        corners per image
+    double *sensors;                // [B][OFK_SENSOR_DOUBLES]
+    double *records;                // [B][OFK_RECORD_DOUBLES]
+    int *dev_flags;                 // [4]                        device-side error flags (bit 0: candidate overflow)
+    void *scratch; size_t scratch_bytes;          // device scratch for the estimation entry points
+    void *hstage; size_t hstage_bytes;            // pinned host staging
+
+    int cur_batch, cur_h, cur_w;    // resident pair geometry (ofk_pairs_upload)
+    int prof_mask;
+    hipEvent_t *ev; int ev_cap, ev_n; int *ev_stage;   // pairs of events: start/stop
+    char errmsg[512];
+};
+
+// --- helpers (host)
+int ofk_fail(ofk_ctx *ctx, int code, const char *fmt, ...);
+#define OFK_HIP(ctx, call)                                                                       \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) return ofk_fail(ctx, OFK_E_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+ofk_levels ofk_make_levels(int h, int w, int win, int max_level);   // win <= 0: ignore the winSize stop rule
+int ofk_need_scratch(ofk_ctx *ctx, size_t bytes);
+
+// --- launchers (all asynchronous on `s`; pointers are device pointers)
+void ofk_launch_gray(hipStream_t s, const uint8_t *bgr, size_t bgr_stride, uint8_t *gray, size_t gray_stride, int batch,
+                     int h, int w);
+void ofk_launch_pyr_down(hipStream_t s, const uint8_t *src, size_t src_stride, int h, int w, uint8_t *dst,
+                         size_t dst_stride, int batch);
+void ofk_launch_scharr(hipStream_t s, const uint8_t *src, size_t src_stride, int h, int w, int16_t *dxdy,
+                       size_t dst_stride_elems, int batch);
+int  ofk_launch_mineig(hipStream_t s, const uint8_t *gray, size_t gray_stride, int h, int w, int block, float *eig,
+                       size_t eig_stride, unsigned int *maxbits, const uint8_t *mask, size_t mask_stride, int batch);
+void ofk_launch_maxbits(hipStream_t s, const float *eig, size_t eig_stride, const uint8_t *mask, size_t mask_stride,
+                        int h, int w, unsigned int *maxbits, int batch);
+void ofk_launch_nms(hipStream_t s, const float *eig, size_t eig_stride, const uint8_t *mask, size_t mask_stride, int h,
+                    int w, const unsigned int *maxbits, double quality, unsigned long long *cand, int cand_cap,
+                    int *cand_count, int *flags, int batch);
+void ofk_launch_select(hipStream_t s, unsigned long long *cand, int cand_cap, const int *cand_count, int w,
+                       int max_corners, float min_distance, float *pts, int pts_stride, int *counts, int batch);
+void ofk_launch_lk(hipStream_t s, const uint8_t *prev, const uint8_t *next, size_t pyr_stride, const ofk_levels &lv,
+                   const float *prev_pts, const int *counts, int pts_stride, int win, int max_count, double eps,
+                   double min_eig_thr, float *next_pts, uint8_t *status, float *err, int batch);
+void ofk_launch_pairs_solve(hipStream_t s, const float *prev_pts, const float *next_pts, const uint8_t *status,
+                            const int *counts, int pts_stride, const double *sensors, int variant, int use_feas,
+                            double feas_T, double *records, int batch);
+void ofk_launch_records_f32(hipStream_t s, const double *records, float *dst, int batch);
+
+void ofk_launch_flow_model(hipStream_t s, const double *x, int batch, int n, const double *v, const double *omega,
+                           const double *d, const double *nrm, const double *t, double *flow);
+void ofk_launch_feasibility(hipStream_t s, int variant, const double *x, const double *u, int batch, int n,
+                            const double *nrm, const double *v, const double *dist, const double *omega,
+                            const double *t, double *r, double *dd);
+void ofk_launch_solve(hipStream_t s, int variant, const double *x, const double *u, const uint8_t *valid, int batch,
+                      int n, const double *d, const double *nrm, const double *omega, const double *t,
+                      const double *wgt, double *out);
+void ofk_launch_imu(hipStream_t s, double *state, const double *msg, int batch);
+void ofk_launch_post_solve(hipStream_t s, const double *v_obs, const double *rot, const double *ang,
+                           const double *offset, int batch, double *v_uav);
+void ofk_launch_kf(hipStream_t s, int ns, int nm, int nc, const double *F, const double *Bm, const double *H,
+                   const double *Q, const double *Rm, double *x, double *P, const double *u, const double *z, int batch,
+                   int do_predict);
+void ofk_launch_of_simulation(hipStream_t s, const double *truth, const double *sig, const double *pos,
+                              const double *true_flow, int n, const double *z, int trials, double *v_obs,
+                              double *bound);

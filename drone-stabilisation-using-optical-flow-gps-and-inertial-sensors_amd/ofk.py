@@ -1,0 +1,412 @@
+"""ofk.py — ctypes binding of libofk.so (include/ofk.h), numpy in / numpy out.
+
+This is the only place the package touches native code.  There is no CPU fallback: if the
+shared library is missing or no gfx950 device is usable, importing succeeds (so that
+CPU-only tooling can inspect the package) but the first call raises OfkError.
+"""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libofk.so")
+
+OK, E_INVALID, E_HIP, E_CAPACITY, E_NOGPU = 0, -1, -2, -3, -4
+SOLVE_NODE, SOLVE_SIM, SOLVE_OFMODULE = 0, 1, 2
+FEAS_RTILDE, FEAS_LEGACY, FEAS_SIM = 0, 1, 2
+SENSOR_DOUBLES, RECORD_DOUBLES, SOLVE_DOUBLES = 28, 16, 8
+IMU_STATE, IMU_MSG = 24, 15
+STAGES = ("gray", "pyr", "eig", "nms", "select", "lk", "solve")
+
+# every entry point include/ofk.h declares (tests/test_abi.py checks the library exports them all)
+SYMBOLS = (
+    "ofk_version", "ofk_last_error", "ofk_device_count", "ofk_create", "ofk_destroy", "ofk_sync", "ofk_device_sync",
+    "ofk_gray_bgr8", "ofk_pyr_down_u8", "ofk_scharr_s16", "ofk_mineig_response", "ofk_select_corners",
+    "ofk_good_features", "ofk_lk_pyr", "ofk_flow_model", "ofk_feasibility", "ofk_velocity_solve", "ofk_imu_propagate",
+    "ofk_post_solve", "ofk_kf_predict_update", "ofk_of_simulation", "ofk_pairs_upload", "ofk_pairs_set_sensors",
+    "ofk_pairs_run", "ofk_pairs_download", "ofk_pairs_export_records_f32", "ofk_profile_enable", "ofk_profile_read",
+)
+
+
+class OfkError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libofk error {code}: {msg}")
+        self.code = code
+
+
+class Params(C.Structure):
+    _fields_ = [("max_corners", C.c_int), ("quality", C.c_double), ("min_distance", C.c_double), ("block_size", C.c_int),
+                ("win", C.c_int), ("max_level", C.c_int), ("max_count", C.c_int), ("eps", C.c_double),
+                ("min_eig_thr", C.c_double), ("solve_variant", C.c_int), ("use_feasibility", C.c_int), ("feas_T", C.c_double)]
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def load_library():
+    """Loads libofk.so and declares the signatures.  Raises OfkError if the library is not built."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise OfkError(E_NOGPU, f"{LIB_PATH} not built (run `make -C {os.path.join(_HERE, 'csrc')}` or "
+                                    "__graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        vp, i, d = C.c_void_p, C.c_int, C.c_double
+        L.ofk_version.restype = i
+        L.ofk_last_error.restype = C.c_char_p; L.ofk_last_error.argtypes = [vp]
+        L.ofk_device_count.restype = i
+        L.ofk_create.argtypes = [i, i, i, i, i, i, C.POINTER(vp)]
+        L.ofk_destroy.argtypes = [vp]; L.ofk_sync.argtypes = [vp]
+        L.ofk_gray_bgr8.argtypes = [vp, vp, i, i, i, vp]
+        L.ofk_pyr_down_u8.argtypes = [vp, vp, i, i, i, vp]
+        L.ofk_scharr_s16.argtypes = [vp, vp, i, i, i, vp]
+        L.ofk_mineig_response.argtypes = [vp, vp, i, i, i, i, vp]
+        L.ofk_select_corners.argtypes = [vp, vp, vp, i, i, i, i, d, d, vp, vp]
+        L.ofk_good_features.argtypes = [vp, vp, vp, i, i, i, i, d, d, i, vp, vp]
+        L.ofk_lk_pyr.argtypes = [vp, vp, vp, i, i, i, vp, vp, i, i, i, i, d, d, vp, vp, vp]
+        L.ofk_flow_model.argtypes = [vp, vp, i, i, vp, vp, vp, vp, vp, vp]
+        L.ofk_feasibility.argtypes = [vp, i, vp, vp, i, i, vp, vp, vp, vp, vp, vp, vp]
+        L.ofk_velocity_solve.argtypes = [vp, i, vp, vp, vp, i, i, vp, vp, vp, vp, vp, vp]
+        L.ofk_imu_propagate.argtypes = [vp, vp, vp, i]
+        L.ofk_post_solve.argtypes = [vp, vp, vp, vp, vp, i, vp]
+        L.ofk_kf_predict_update.argtypes = [vp, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i]
+        L.ofk_of_simulation.argtypes = [vp, vp, vp, vp, vp, i, vp, i, vp, vp]
+        L.ofk_pairs_upload.argtypes = [vp, vp, vp, i, i, i]
+        L.ofk_pairs_set_sensors.argtypes = [vp, vp, i]
+        L.ofk_pairs_run.argtypes = [vp, C.POINTER(Params)]
+        L.ofk_pairs_download.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+        L.ofk_pairs_export_records_f32.argtypes = [vp, vp, i]
+        L.ofk_profile_enable.argtypes = [vp, i]
+        L.ofk_profile_read.argtypes = [vp, vp, vp]
+        for s in SYMBOLS:
+            if s != "ofk_last_error":
+                getattr(L, s).restype = i
+        _lib = L
+        return L
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _arr(a, dtype, shape=None):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    if shape is not None and a.shape != tuple(shape):
+        a = np.ascontiguousarray(np.broadcast_to(a, shape))
+    return a
+
+
+def _opt(a, dtype, shape):
+    return None if a is None else _arr(a, dtype, shape)
+
+
+class Context:
+    """One device + one HIP stream + all device buffers.  Calls are serialised by an internal lock
+    (the C library is not thread-safe; rospy invokes callbacks from several threads)."""
+
+    def __init__(self, device=0, max_w=1920, max_h=1080, max_batch=1, max_pts=512, max_level=3):
+        self._L = load_library()
+        self._h = C.c_void_p()
+        self._lock = threading.RLock()
+        rc = self._L.ofk_create(device, max_w, max_h, max_batch, max_pts, max_level, C.byref(self._h))
+        if rc != OK:
+            raise OfkError(rc, self._L.ofk_last_error(None).decode())
+        self.device, self.max_w, self.max_h = device, max_w, max_h
+        self.max_batch, self.max_pts, self.max_level = max_batch, max_pts, max_level
+        self._resident = None
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.ofk_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _ck(self, rc):
+        if rc != OK:
+            raise OfkError(rc, self._L.ofk_last_error(self._h).decode())
+
+    def sync(self):
+        with self._lock:
+            self._ck(self._L.ofk_sync(self._h))
+
+    # ------------------------------------------------------------------ image stages
+    @staticmethod
+    def _batched(img, nd):
+        img = np.asarray(img)
+        single = img.ndim == nd
+        return (img[None] if single else img), single
+
+    def gray_bgr8(self, bgr):
+        bgr, single = self._batched(bgr, 3)
+        bgr = _arr(bgr, np.uint8)
+        B, h, w, ch = bgr.shape
+        if ch != 3:
+            raise ValueError("expected [..., h, w, 3] BGR")
+        out = np.empty((B, h, w), np.uint8)
+        with self._lock:
+            self._ck(self._L.ofk_gray_bgr8(self._h, _p(bgr), B, h, w, _p(out)))
+        return out[0] if single else out
+
+    def pyr_down(self, src):
+        src, single = self._batched(src, 2)
+        src = _arr(src, np.uint8)
+        B, h, w = src.shape
+        out = np.empty((B, (h + 1) // 2, (w + 1) // 2), np.uint8)
+        with self._lock:
+            self._ck(self._L.ofk_pyr_down_u8(self._h, _p(src), B, h, w, _p(out)))
+        return out[0] if single else out
+
+    def scharr(self, gray):
+        gray, single = self._batched(gray, 2)
+        gray = _arr(gray, np.uint8)
+        B, h, w = gray.shape
+        out = np.empty((B, h, w, 2), np.int16)
+        with self._lock:
+            self._ck(self._L.ofk_scharr_s16(self._h, _p(gray), B, h, w, _p(out)))
+        return out[0] if single else out
+
+    def mineig(self, gray, block_size):
+        gray, single = self._batched(gray, 2)
+        gray = _arr(gray, np.uint8)
+        B, h, w = gray.shape
+        out = np.empty((B, h, w), np.float32)
+        with self._lock:
+            self._ck(self._L.ofk_mineig_response(self._h, _p(gray), B, h, w, int(block_size), _p(out)))
+        return out[0] if single else out
+
+    def select_corners(self, eig, max_corners, quality, min_distance, mask=None):
+        eig, single = self._batched(eig, 2)
+        eig = _arr(eig, np.float32)
+        B, h, w = eig.shape
+        mask = _opt(mask, np.uint8, (B, h, w))
+        pts = np.zeros((B, max_corners, 2), np.float32); cnt = np.zeros(B, np.int32)
+        with self._lock:
+            self._ck(self._L.ofk_select_corners(self._h, _p(eig), _p(mask), B, h, w, int(max_corners), float(quality),
+                                                float(min_distance), _p(pts), _p(cnt)))
+        return (pts[0], int(cnt[0])) if single else (pts, cnt)
+
+    def good_features(self, gray, max_corners, quality, min_distance, block_size, mask=None):
+        """Batched goodFeaturesToTrack.  Returns (pts [B,max_corners,2] f32, counts [B]) or, for a single
+        image, the OpenCV-shaped (N,1,2) float32 array."""
+        gray, single = self._batched(gray, 2)
+        gray = _arr(gray, np.uint8)
+        B, h, w = gray.shape
+        mask = _opt(mask, np.uint8, (B, h, w))
+        pts = np.zeros((B, max_corners, 2), np.float32); cnt = np.zeros(B, np.int32)
+        with self._lock:
+            self._ck(self._L.ofk_good_features(self._h, _p(gray), _p(mask), B, h, w, int(max_corners), float(quality),
+                                               float(min_distance), int(block_size), _p(pts), _p(cnt)))
+        if single:
+            n = int(cnt[0])
+            return pts[0, :n].reshape(n, 1, 2).copy()
+        return pts, cnt
+
+    def lk_pyr(self, prev, nxt, prev_pts, counts=None, win=15, max_level=3, max_count=20, eps=0.03, min_eig_thr=1e-4):
+        """Batched calcOpticalFlowPyrLK.  Single image: prev_pts (N,1,2)/(N,2) -> (next (N,1,2), status (N,1), err (N,1)).
+        Batch: prev_pts [B,S,2] + counts [B] -> (next [B,S,2], status [B,S], err [B,S])."""
+        prev, single = self._batched(prev, 2)
+        nxt, _ = self._batched(nxt, 2)
+        prev = _arr(prev, np.uint8); nxt = _arr(nxt, np.uint8)
+        B, h, w = prev.shape
+        if single:
+            pp = _arr(prev_pts, np.float32).reshape(1, -1, 2)
+            counts = np.array([pp.shape[1]], np.int32)
+        else:
+            pp = _arr(prev_pts, np.float32)
+            counts = _arr(counts, np.int32, (B,))
+        S = pp.shape[1]
+        if S == 0:
+            z = np.zeros((0, 1, 2), np.float32)
+            return z, np.zeros((0, 1), np.uint8), np.zeros((0, 1), np.float32)
+        nxt_pts = np.zeros((B, S, 2), np.float32); st = np.zeros((B, S), np.uint8); err = np.zeros((B, S), np.float32)
+        with self._lock:
+            self._ck(self._L.ofk_lk_pyr(self._h, _p(prev), _p(nxt), B, h, w, _p(pp), _p(counts), S, int(win), int(max_level),
+                                        int(max_count), float(eps), float(min_eig_thr), _p(nxt_pts), _p(st), _p(err)))
+        if single:
+            return nxt_pts[0].reshape(S, 1, 2), st[0].reshape(S, 1), err[0].reshape(S, 1)
+        return nxt_pts, st, err
+
+    # ------------------------------------------------------------------ estimation
+    def flow_model(self, x, v, omega, d, nrm, t=None):
+        x = _arr(x, np.float64)
+        single = x.ndim == 2
+        if single:
+            x = x[None]
+        B, n, _ = x.shape
+        v = _arr(v, np.float64, (B, 3)); omega = _arr(omega, np.float64, (B, 3)); nrm = _arr(nrm, np.float64, (B, 3))
+        d = _arr(d, np.float64, (B,)); t = _opt(t, np.float64, (B, 3))
+        out = np.empty((B, n, 2), np.float64)
+        if n:
+            with self._lock:
+                self._ck(self._L.ofk_flow_model(self._h, _p(x), B, n, _p(v), _p(omega), _p(d), _p(nrm), _p(t), _p(out)))
+        return out[0] if single else out
+
+    def feasibility(self, variant, x, u, nrm, v, dist=None, omega=None, t=None):
+        x = _arr(x, np.float64); u = _arr(u, np.float64)
+        single = x.ndim == 2
+        if single:
+            x = x[None]; u = u[None]
+        B, n, _ = x.shape
+        nrm = _arr(nrm, np.float64, (B, 3)); v = _arr(v, np.float64, (B, 3))
+        dist = _opt(dist, np.float64, (B,)); omega = _opt(omega, np.float64, (B, 3)); t = _opt(t, np.float64, (B, 3))
+        r = np.empty((B, n), np.float64); dd = np.empty((B, n), np.float64)
+        if n:
+            with self._lock:
+                self._ck(self._L.ofk_feasibility(self._h, int(variant), _p(x), _p(u), B, n, _p(nrm), _p(v), _p(dist), _p(omega),
+                                                 _p(t), _p(r), _p(dd)))
+        return (r[0], dd[0]) if single else (r, dd)
+
+    def velocity_solve(self, variant, x, u, d=None, nrm=None, omega=None, t=None, wgt=None, valid=None):
+        """Returns out [B,8] = v[3], residual SS, rank, s[3] (single problem: [8])."""
+        x = _arr(x, np.float64); u = _arr(u, np.float64)
+        single = x.ndim == 2
+        if single:
+            x = x[None]; u = u[None]
+        B, n, _ = x.shape
+        u = _arr(u[..., :2], np.float64)
+        nrm = _arr(nrm, np.float64, (B, 3))
+        d = _opt(d, np.float64, (B,)); omega = _opt(omega, np.float64, (B, 3)); t = _opt(t, np.float64, (B, 3))
+        wgt = _opt(wgt, np.float64, (B, n)); valid = _opt(valid, np.uint8, (B, n))
+        out = np.zeros((B, SOLVE_DOUBLES), np.float64)
+        if n:
+            with self._lock:
+                self._ck(self._L.ofk_velocity_solve(self._h, int(variant), _p(x), _p(u), _p(valid), B, n, _p(d), _p(nrm),
+                                                    _p(omega), _p(t), _p(wgt), _p(out)))
+        return out[0] if single else out
+
+    def imu_propagate(self, state, msg):
+        state = _arr(state, np.float64).copy(); msg = _arr(msg, np.float64)
+        single = state.ndim == 1
+        s2 = state.reshape(-1, IMU_STATE); m2 = msg.reshape(-1, IMU_MSG)
+        with self._lock:
+            self._ck(self._L.ofk_imu_propagate(self._h, _p(s2), _p(m2), len(s2)))
+        return s2[0] if single else s2
+
+    def post_solve(self, v_obs, rotation, ang, offset):
+        v_obs = _arr(v_obs, np.float64)
+        single = v_obs.ndim == 1
+        v2 = v_obs.reshape(-1, 3); B = len(v2)
+        R = _arr(np.asarray(rotation, np.float64).reshape(-1, 9), np.float64, (B, 9))
+        ang = _arr(ang, np.float64, (B, 3)); offset = _arr(offset, np.float64, (B, 3))
+        out = np.empty((B, 3), np.float64)
+        with self._lock:
+            self._ck(self._L.ofk_post_solve(self._h, _p(v2), _p(R), _p(ang), _p(offset), B, _p(out)))
+        return out[0] if single else out
+
+    def kf_predict_update(self, F, H, Q, R, x, P, B=None, u=None, z=None, do_predict=True):
+        F = _arr(F, np.float64); H = _arr(H, np.float64); Q = _arr(Q, np.float64); R = _arr(R, np.float64)
+        ns = F.shape[0]; nm = H.shape[0]
+        x = _arr(x, np.float64).copy(); P = _arr(P, np.float64).copy()
+        single = x.ndim == 1
+        x2 = x.reshape(-1, ns); batch = len(x2); P2 = P.reshape(batch, ns, ns)
+        nc = 0
+        if B is not None and u is not None:
+            B = _arr(B, np.float64); nc = B.shape[1]; u = _arr(u, np.float64, (batch, nc))
+        else:
+            B = None; u = None
+        z = _opt(z, np.float64, (batch, nm))
+        with self._lock:
+            self._ck(self._L.ofk_kf_predict_update(self._h, ns, nm, nc, _p(F), _p(B), _p(H), _p(Q), _p(R), _p(x2), _p(P2), _p(u),
+                                                   _p(z), batch, 1 if do_predict else 0))
+        return (x2[0], P2[0]) if single else (x2, P2)
+
+    def of_simulation(self, truth, sig, pos, true_flow, z):
+        truth = _arr(truth, np.float64, (13,)); sig = _arr(sig, np.float64, (6,))
+        pos = _arr(pos, np.float64); true_flow = _arr(true_flow, np.float64)
+        n = len(pos)
+        z = _arr(z, np.float64).reshape(-1, 10 + 4 * n)
+        trials = len(z)
+        v = np.empty((trials, 3), np.float64); bound = np.empty(trials, np.float64)
+        with self._lock:
+            self._ck(self._L.ofk_of_simulation(self._h, _p(truth), _p(sig), _p(pos), _p(true_flow), n, _p(z), trials, _p(v), _p(bound)))
+        return v, bound
+
+    # ------------------------------------------------------------------ resident frame-pair pipeline
+    def pairs_upload(self, prev_bgr, next_bgr):
+        prev_bgr, _ = self._batched(prev_bgr, 3); next_bgr, _ = self._batched(next_bgr, 3)
+        prev_bgr = _arr(prev_bgr, np.uint8); next_bgr = _arr(next_bgr, np.uint8)
+        B, h, w, ch = prev_bgr.shape
+        if ch != 3 or next_bgr.shape != prev_bgr.shape:
+            raise ValueError("expected two [B,h,w,3] BGR batches of equal shape")
+        with self._lock:
+            self._ck(self._L.ofk_pairs_upload(self._h, _p(prev_bgr), _p(next_bgr), B, h, w))
+        self._resident = (B, h, w)
+
+    def pairs_set_sensors(self, sensors):
+        s = _arr(sensors, np.float64).reshape(-1, SENSOR_DOUBLES)
+        with self._lock:
+            self._ck(self._L.ofk_pairs_set_sensors(self._h, _p(s), len(s)))
+
+    def pairs_run(self, params):
+        with self._lock:
+            self._ck(self._L.ofk_pairs_run(self._h, C.byref(params)))
+
+    def pairs_download(self, points=True):
+        B = self._resident[0]; S = self.max_pts
+        rec = np.empty((B, RECORD_DOUBLES), np.float64)
+        if points:
+            pp = np.empty((B, S, 2), np.float32); npts = np.empty((B, S, 2), np.float32)
+            st = np.empty((B, S), np.uint8); err = np.empty((B, S), np.float32)
+        else:
+            pp = npts = st = err = None
+        cnt = np.empty(B, np.int32)
+        with self._lock:
+            self._ck(self._L.ofk_pairs_download(self._h, _p(rec), _p(pp), _p(npts), _p(st), _p(err), _p(cnt)))
+        return dict(records=rec, prev_pts=pp, next_pts=npts, status=st, err=err, counts=cnt)
+
+    def pairs_export_records_f32(self, device_ptr, batch):
+        with self._lock:
+            self._ck(self._L.ofk_pairs_export_records_f32(self._h, C.c_void_p(int(device_ptr)), int(batch)))
+
+    def profile_enable(self, mask):
+        self._ck(self._L.ofk_profile_enable(self._h, int(mask)))
+
+    def profile_read(self):
+        ms = np.zeros(len(STAGES), np.float64); n = np.zeros(len(STAGES), np.int32)
+        with self._lock:
+            self._ck(self._L.ofk_profile_read(self._h, _p(ms), _p(n)))
+        return {s: (float(ms[i]), int(n[i])) for i, s in enumerate(STAGES)}
+
+
+def make_sensors(batch, d=1.0, normal=(0, 0, 1), omega=(0, 0, 0), rotation=None, offset=(0, 0, 0.1), scaling=0.01,
+                 cx=0.0, cy=0.0, v_prior=(0, 0, 0)):
+    """Builds the [batch][28] sensor records ofk_pairs_set_sensors takes (layout: include/ofk.h)."""
+    s = np.zeros((batch, SENSOR_DOUBLES), np.float64)
+    s[:, 0] = d; s[:, 1:4] = normal; s[:, 4:7] = omega
+    s[:, 7:16] = np.eye(3).ravel() if rotation is None else np.asarray(rotation, np.float64).reshape(-1, 9)
+    s[:, 16:19] = offset; s[:, 19] = scaling; s[:, 20] = cx; s[:, 21] = cy; s[:, 22:25] = v_prior
+    return s
+
+
+_default = None
+_default_lock = threading.Lock()
+
+
+def default_context(min_w=0, min_h=0, min_pts=0, min_level=0):
+    """Process-wide context used by the of_library / cv2-style facade; grown on demand."""
+    global _default
+    with _default_lock:
+        c = _default
+        if c is None or c.max_w * c.max_h < min_w * min_h or c.max_pts < min_pts or c.max_level < min_level:
+            w = max(min_w, c.max_w if c else 1920); h = max(min_h, c.max_h if c else 1080)
+            pts = max(min_pts, c.max_pts if c else 512); lvl = max(min_level, c.max_level if c else 5)
+            if c is not None:
+                c.close()
+            _default = Context(int(os.environ.get("OFK_DEVICE", "0")), w, h, 1, pts, lvl)
+        return _default

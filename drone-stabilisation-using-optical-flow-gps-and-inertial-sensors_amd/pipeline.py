@@ -1,0 +1,78 @@
+"""pipeline.py — batched, HBM-resident frame-pair pipeline: BGR pair -> gray -> pyramids -> Shi-Tomasi corners
+-> pyramidal LK -> centre/scale -> (feasibility) -> least-squares body velocity -> lever arm + rotation.
+
+It strings together, for a batch of independent frame pairs, exactly the stage order of the reference's
+offline prototype (optical_flow_experiments/of_module.py:36-152) and of the node's main loop
+(velocity_measurment_node:226-261), every stage a HIP kernel (libofk.so, ofk_pairs_run).
+"""
+from dataclasses import dataclass
+
+import numpy as np
+
+try:
+    from . import ofk
+except ImportError:      # package directory put on sys.path directly
+    import ofk
+
+
+@dataclass
+class PipelineConfig:
+    max_corners: int = 500
+    quality: float = 0.01
+    min_distance: float = 10.0
+    block_size: int = 7
+    win: int = 15
+    max_level: int = 3
+    max_count: int = 20
+    eps: float = 0.03
+    min_eig_thr: float = 1e-4
+    solve_variant: int = ofk.SOLVE_NODE
+    use_feasibility: bool = False
+    feas_T: float = 0.0
+
+    # the three parameter sets the reference carries inline
+    @classmethod
+    def node(cls):               # velocity_measurment_node:96-107
+        return cls(max_corners=100, quality=0.7, min_distance=10, block_size=12, win=15, max_level=3, max_count=20, eps=0.03)
+
+    @classmethod
+    def of_module(cls):          # optical_flow_experiments/of_module.py:12-23
+        return cls(max_corners=50, quality=0.3, min_distance=20, block_size=32, win=15, max_level=3, max_count=10, eps=0.5)
+
+    @classmethod
+    def evaluate_exp(cls):       # flight_experiments/evaluate_exp.py:37-48
+        return cls(max_corners=20, quality=0.7, min_distance=10, block_size=7, win=15, max_level=3, max_count=20, eps=0.03)
+
+    @classmethod
+    def baseline_1080p(cls):     # BASELINE.json configs[1]: 500 corners, 3-level pyramid
+        return cls(max_corners=500, quality=0.01, min_distance=10, block_size=7, win=15, max_level=3, max_count=20, eps=0.03)
+
+    def to_params(self):
+        return ofk.Params(int(self.max_corners), float(self.quality), float(self.min_distance), int(self.block_size),
+                          int(self.win), int(self.max_level), int(self.max_count), float(self.eps), float(self.min_eig_thr),
+                          int(self.solve_variant), 1 if self.use_feasibility else 0, float(self.feas_T))
+
+
+class FlowPipeline:
+    def __init__(self, width, height, batch=1, cfg=None, device=0):
+        self.cfg = cfg or PipelineConfig.baseline_1080p()
+        self.batch = batch
+        self.ctx = ofk.Context(device, width, height, batch, max(1, self.cfg.max_corners), max(0, self.cfg.max_level))
+        self._params = self.cfg.to_params()
+
+    def upload(self, prev_bgr, next_bgr, sensors):
+        self.ctx.pairs_upload(prev_bgr, next_bgr)
+        self.ctx.pairs_set_sensors(sensors)
+
+    def run_async(self):
+        self.ctx.pairs_run(self._params)
+
+    def sync(self):
+        self.ctx.sync()
+
+    def run(self, points=True):
+        self.run_async()
+        return self.ctx.pairs_download(points=points)
+
+    def close(self):
+        self.ctx.close()

@@ -1,0 +1,88 @@
+"""simulation.py — drop-in for the functions of numerical_simulation/simulation.py, batched on the GPU.
+
+Same names and positional signatures: generate_test_data (:7-12), solve_lgs (:15-30), feasibility (:108-120),
+of_simulation (:36-66).  The reference's module-level globals `iterations` and `true_flow` (read by
+of_simulation) are module attributes here as well.  Noise: the reference draws from an unseeded np.random; here
+the standard-normal tensor is drawn on the host in the reference's draw order (optionally seeded, or passed in)
+and all `iterations` trials are solved by one launch of k_of_simulation.
+"""
+import numpy as np
+
+try:
+    from . import ofk
+except ImportError:
+    import ofk
+
+iterations = 100
+true_flow = None
+rng = None            # set to np.random.default_rng(seed) for reproducible sweeps
+
+
+def generate_test_data(x, v, omega, d, n, t):
+    return ofk.default_context().flow_model(np.asarray(x, np.float64)[:, :2], v, omega, float(np.ravel(d)[0]), n, t)
+
+
+def solve_lgs(x, u, d, n, omega, t):
+    """Returns (v - omega x t, R, s) like the reference; R has shape (1,) (empty when rank < 3 or N < 2)."""
+    try:
+        x = np.asarray(x, np.float64)
+        out = ofk.default_context().velocity_solve(ofk.SOLVE_SIM, x[:, :2], np.asarray(u, np.float64)[:, :2],
+                                                   d=float(np.ravel(d)[0]), nrm=n, omega=omega, t=t)
+        rank = int(out[4])
+        R = np.array([out[3]]) if (rank == 3 and 3 * len(x) > 3) else np.empty(0)
+        return out[:3].copy(), R, out[5:8].copy()
+    except ofk.OfkError:
+        raise
+    except Exception:     # reference: bare except around lstsq (simulation.py:29-30)
+        return np.zeros(3), 10000 * np.ones(3 * len(x)), np.array([0, 0, 0])
+
+
+def feasibility(position, linear_velocity, flow, angular_velocity, translation, normal):
+    r, length = ofk.default_context().feasibility(ofk.FEAS_SIM, np.asarray(position, np.float64)[:, :2],
+                                                  np.asarray(flow, np.float64)[:, :2], normal, linear_velocity,
+                                                  omega=angular_velocity, t=translation)
+    return np.array([r, length])
+
+
+def draw_noise(n_points, trials, generator=None):
+    g = generator or rng or np.random.default_rng()
+    return g.standard_normal((trials, 10 + 4 * n_points))
+
+
+def of_simulation(linear_velocity, angular_velocity, height_above_gr, normal_vector, translation, pos, ang_vel_sig,
+                  translation_sig, height_sig, flow_sig, position_sig, normal_sig, z=None):
+    """Returns (v_obs [iterations,3], feasible [2,N] of the last trial, R [iterations]) like the reference."""
+    pos = np.asarray(pos, np.float64)
+    tf = np.asarray(true_flow, np.float64)
+    if z is None:
+        z = draw_noise(len(pos), iterations)
+    z = np.asarray(z, np.float64).reshape(-1, 10 + 4 * len(pos))
+    truth = np.concatenate([np.asarray(linear_velocity, np.float64), np.asarray(angular_velocity, np.float64),
+                            [float(height_above_gr)], np.asarray(normal_vector, np.float64), np.asarray(translation, np.float64)])
+    sig = np.array([ang_vel_sig, translation_sig, height_sig, flow_sig, position_sig, normal_sig], np.float64)
+    v_obs, bound = ofk.default_context().of_simulation(truth, sig, pos, tf, z)
+    # feasibility of the last trial's perturbed inputs (simulation.py:65)
+    zl = z[-1]; N = len(pos)
+    ang = np.asarray(angular_velocity, np.float64) + sig[0] * zl[0:3]
+    tr = np.asarray(translation, np.float64) + sig[1] * zl[3:6]
+    fl = tf + sig[3] * zl[7:7 + 2 * N].reshape(N, 2)
+    pe = pos + sig[4] * zl[7 + 2 * N:7 + 4 * N].reshape(N, 2)
+    nv = np.asarray(normal_vector, np.float64)
+    feas = feasibility(pe, linear_velocity, fl, ang, tr, nv / np.linalg.norm(nv))
+    return v_obs, feas, bound
+
+
+def sweep_flow_errors(data, linear_velocity, angular_velocity, height_above_gr, normal_vector, translation, sigmas,
+                      k=100, trials=100, generator=None):
+    """The "Effect of flow errors" driver (simulation.py:183-202): k sigma-steps, flow_sig = 0.001 i,
+    position_sig = sqrt(2)/1000 i; returns np.append(v_mean, v_std) laid out like the saved .npy files."""
+    global true_flow, iterations
+    true_flow = generate_test_data(data, linear_velocity, angular_velocity, height_above_gr, normal_vector, translation)
+    iterations = trials
+    v_mean = np.zeros((k, 3)); v_std = np.zeros((k, 3))
+    for i in range(k):
+        v_obs, _, _ = of_simulation(linear_velocity, angular_velocity, height_above_gr, normal_vector, translation, data,
+                                    sigmas["ang_vel_sig"], sigmas["translation_sig"], sigmas["height_sig"], 0.001 * i,
+                                    np.sqrt(2) / 1000 * i, sigmas["normal_sig"], z=draw_noise(len(data), trials, generator))
+        v_mean[i] = v_obs.mean(axis=0); v_std[i] = v_obs.std(axis=0)
+    return np.append(v_mean, v_std)

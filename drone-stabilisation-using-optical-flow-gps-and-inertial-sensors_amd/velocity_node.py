@@ -1,0 +1,237 @@
+"""velocity_node.py — the reference's ROS node `velocity_measurment_node`, with its numpy loops and (commented-out)
+OpenCV calls running on the HIP kernels.
+
+Module level: generate_test_data (node:25-29), solve_lgs (node:30-42), feasible (node:44-50).
+Class optical_fusion (node:52-267): same attributes, flags, callbacks (call_dist / call_imu / call_optical), topic
+names and printed output.  Differences, all deliberate:
+  * rospy is optional: `optical_fusion(spin=False)` builds the state without ROS so the node logic is testable;
+    `step()` is one iteration of the reference's busy loop (node:226-267).
+  * `synthetic_test=True` (default) reproduces the node AS SHIPPED: 4 hard-coded features (node:123), flow
+    overwritten by generate_test_data (node:236), feasibility forced to -1 (node:240).  With
+    `synthetic_test=False` the pipeline the reference keeps inside ''' blocks runs instead: goodFeaturesToTrack
+    on the first frame (node:120), calcOpticalFlowPyrLK between frames (node:133-136), re-detection with a
+    circle mask when few features remain (node:157-173), the real flow and the real r_tilde filter.
+  * callbacks and step() snapshot shared state under one lock (the reference races, node:61-177 vs :226-267).
+"""
+import copy
+import threading
+import time
+
+import numpy as np
+
+try:
+    from . import ofk, cv2_hip as cv2, of_library as of
+except ImportError:
+    import ofk
+    import cv2_hip as cv2
+    import of_library as of
+
+try:                                    # ROS is optional (absent in this image)
+    import rospy
+    from cv_bridge import CvBridge
+    from sensor_msgs.msg import CompressedImage, Image, Imu, Range
+except ImportError:
+    rospy = None
+    CvBridge = CompressedImage = Image = Imu = Range = None
+
+
+def generate_test_data(x, v, omega, d, n):
+    """node:25-29 — forward flow model, one thread per point (k_flow_model)."""
+    x = np.asarray(x, np.float64)
+    if len(x) == 0:
+        return np.zeros((0, 2))
+    return ofk.default_context().flow_model(x[:, :2], v, omega, float(d), n)
+
+
+def solve_lgs(x, u, d, n, omega):
+    """node:30-42 — returns np.linalg.lstsq's 4-tuple (v, R, rank, s): R has shape (1,) when rank == 3 and
+    3N > 3, else is empty.  On failure the reference returns the 2-tuple (zeros(3), 10000*ones(3N)) from a bare
+    except (node:41-42); that path is kept for non-finite results."""
+    x = np.asarray(x, np.float64); u = np.asarray(u, np.float64)
+    out = ofk.default_context().velocity_solve(ofk.SOLVE_NODE, x[:, :2], u[:, :2], d=float(d), nrm=n, omega=omega)
+    if not np.all(np.isfinite(out)):
+        return np.zeros(3), 10000 * np.ones(3 * len(x))
+    rank = int(out[4])
+    R = np.array([out[3]]) if (rank == 3 and 3 * len(x) > 3) else np.empty(0)
+    return out[:3].copy(), R, rank, out[5:8].copy()
+
+
+def feasible(x, v, omega, T, u, d, n):
+    """node:44-50 (reference not executable: uses v_cr/u_cr before definition, returns nothing).  The evident
+    intent — parallelity and distance of each point given the lever-arm corrected velocity — is returned."""
+    x = np.asarray(x, np.float64); u = np.asarray(u, np.float64)
+    ve = np.asarray(v, np.float64) + np.cross(omega, T)
+    v_cross = np.cross(np.concatenate([x[:, :2], np.ones((len(x), 1))], 1), ve[None, :])
+    u_cross = np.cross(np.concatenate([x[:, :2], np.zeros((len(x), 1))], 1), np.concatenate([u[:, :2], np.zeros((len(x), 1))], 1))
+    vn = np.linalg.norm(v_cross, axis=1); un = np.linalg.norm(u_cross, axis=1)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        par = np.where(vn * un != 0, np.einsum("ni,ni->n", v_cross, u_cross) / (vn * un), 1.0)
+        dist = np.where(un != 0, (np.concatenate([x[:, :2], np.ones((len(x), 1))], 1) @ np.asarray(n, np.float64)) * vn / un / d, 0.0)
+    return par, dist
+
+
+class optical_fusion:
+    # parameters the reference sets inline (node:96-107, :182, :241)
+    min_feat = 20
+    max_feat = 100
+    feature_params = dict(qualityLevel=0.7, minDistance=10, blockSize=12)
+    lk_params = dict(winSize=(15, 15), maxLevel=3, criteria=(cv2.TERM_CRITERIA_EPS | cv2.TERM_CRITERIA_COUNT, 20, 0.03))
+    scaling = 0.01
+    T = 0.0
+
+    def call_dist(self, data):
+        """node:55-58 — reads the range and discards it (self.d stays 0.75)."""
+        distance = data.range  # noqa: F841
+
+    def call_imu(self, data):
+        """node:61-89 — quaternion -> R, normal, dead-reckoning between optical fixes (k_imu)."""
+        w, q, a, st = data.angular_velocity, data.orientation, data.linear_acceleration, data.header.stamp
+        cov = data.angular_velocity_covariance
+        msg = np.array([st.secs, st.nsecs, q.x, q.y, q.z, q.w, w.x, w.y, w.z, cov[0], cov[4], cov[8], a.x, a.y, a.z], np.float64)
+        with self._lock:
+            state = np.zeros(ofk.IMU_STATE)
+            state[0:3] = self.vel; state[3] = self.old_time; state[4] = self.time_zero; state[5] = 1.0 if self.first_imu_ else 0.0
+            if self.got_vel_ and not self.first_imu_:
+                keep_vel = np.array(self.vel, np.float64)
+            else:
+                keep_vel = None
+            state = self._ctx().imu_propagate(state, msg)
+            self.vel = state[0:3].copy() if keep_vel is None else keep_vel
+            self.old_time = float(state[3]); self.time_zero = state[4] if self.first_imu_ is False else int(state[4])
+            self.first_imu_ = False
+            self.rotation = state[6:15].reshape(3, 3).copy(); self.normal = state[15:18].copy()
+            self.ang = state[18:21].copy(); self.ang_err = state[21:24].copy()
+            self.got_ang_vel_ = True
+
+    def _decode(self, image_raw):
+        if isinstance(image_raw, np.ndarray):
+            return image_raw
+        if CvBridge is None:
+            raise RuntimeError("cv_bridge is not available: pass BGR numpy frames to call_optical")
+        return CvBridge().compressed_imgmsg_to_cv2(image_raw, 'bgr8')
+
+    def call_optical(self, image_raw):
+        """node:92-177 — image callback."""
+        with self._lock:
+            if self.got_picture_:
+                return
+            image = self._decode(image_raw)
+            image_gray = cv2.cvtColor(image, cv2.COLOR_BGR2GRAY)
+            old_pos = np.asarray(self.feat, np.float32).reshape((len(self.feat), 1, 2))
+            if self.first:
+                if self.synthetic_test:
+                    first_feat = np.array([[-401, 300], [399, -300], [400, 301], [-400, -299]])       # node:123
+                else:
+                    found = cv2.goodFeaturesToTrack(image_gray, mask=None, maxCorners=self.max_feat, **self.feature_params)
+                    first_feat = np.zeros((0, 2)) if found is None else found
+                self.feat = np.asarray(first_feat).reshape((len(first_feat), 2))
+                self.feat_err = np.zeros(len(first_feat))
+            else:
+                if not self.synthetic_test and len(old_pos):
+                    new_pos, status, new_pos_err = cv2.calcOpticalFlowPyrLK(self.old_pic, image_gray, old_pos, None, **self.lk_params)
+                    ok = status.reshape(-1) == 1
+                    self.feat = new_pos[ok].reshape((-1, 2))
+                    self.feat_err = new_pos_err[ok]
+                    self.flow = new_pos[ok] - old_pos[ok]
+                self.init = False
+                self.got_picture_ = True
+                if not self.synthetic_test and len(self.feat) <= self.min_feat:                       # node:157-173
+                    ft_mask = np.ones_like(image_gray)
+                    of.circles(self.feat, ft_mask, 30)
+                    new = cv2.goodFeaturesToTrack(image_gray, mask=ft_mask, maxCorners=self.max_feat - len(self.feat), **self.feature_params)
+                    if new is not None:
+                        self.feat = np.append(self.feat, new.reshape(len(new), 2), axis=0)
+                        self.flow = np.append(np.asarray(self.flow).reshape(-1, 1, 2), np.zeros((len(new), 1, 2), np.float32), axis=0)
+            self.old_pic = image_gray
+            self.first = False
+
+    def _ctx(self):
+        return ofk.default_context()
+
+    def step(self):
+        """One pass of the reference's main loop body (node:226-267).  Returns v_obs or None."""
+        with self._lock:
+            if not (self.got_picture_ and not self.init):
+                return None
+            translation = of.pix_trans((320, 240))
+            x = copy.deepcopy(self.feat).astype(float)
+            x[:, 0] = (x[:, 0] - translation[0]) * self.scaling
+            x[:, 1] = (x[:, 1] - translation[1]) * self.scaling
+            u = np.asarray(self.flow, np.float64).reshape(len(self.flow), 2) * self.scaling
+            if self.synthetic_test:
+                u = generate_test_data(x, np.array([1, 1, 1]), np.array([0, 0, 0]), self.d, np.array([0, 0, 1]))   # node:236
+            if len(u) != len(x):
+                self.got_picture_ = False
+                return None
+            feasibility, dummy_d = of.r_tilde(x, u, self.normal, self.vel, self.d)
+            if self.synthetic_test:
+                feasibility = -1 * np.ones(len(x))                                                                  # node:240
+            keep = feasibility <= self.T
+            x = x[keep]; u = u[keep]; dummy_d = dummy_d[keep]
+            self.feat = self.feat[keep]
+            if not self.synthetic_test:
+                self.flow = np.asarray(self.flow).reshape(-1, 1, 2)[keep]
+            v_obs = None
+            if len(x) >= 3:
+                v_obs, R, rank, s = solve_lgs(x, u, self.d, self.normal, self.ang)
+                v_uav = self._ctx().post_solve(v_obs, self.rotation, self.ang, self.offset)                        # node:258
+                print('    '.join(map(str, v_obs)))
+                self.vel = v_uav
+                self.last_residual, self.last_rank, self.last_s = R, rank, s
+            self.got_picture_ = False
+            return v_obs
+
+    def __init__(self, spin=True, synthetic_test=True):
+        self._lock = threading.RLock()
+        self.synthetic_test = synthetic_test
+        self.vel = np.array([0.1, 0.1, 0.1])
+        self.vel_err = np.array([0.1, 0.1, 0.1])
+        self.feat = np.ones((1, 2))
+        self.feat_err = np.ones((1, 1))
+        self.flow = np.zeros((1, 1, 2))
+        self.flow_err = np.zeros((1, 1, 2))
+        self.ang = np.array([0, 0, 0])
+        self.ang_err = np.zeros((3, 3))
+        self.d = 0.75
+        self.d_err = 0
+        self.rotation = np.array([[1, 0, 0], [0, 1, 0], [0, 0, 1]])
+        self.old_pic = np.zeros((480, 640))
+        self.old_time = 0
+        self.time_zero = 0
+        self.offset = np.array([0, 0, 0.1])
+        self.normal = np.array([0, 0, 1])
+        self.normal_err = np.array([0, 0, 1])
+        self.init = True
+        self.first = True
+        self.first_imu_ = True
+        self.got_normal_ = False
+        self.got_vel_ = False
+        self.got_picture_ = False
+        self.got_ang_vel_ = False
+        if not spin:
+            return
+        if rospy is None:
+            raise RuntimeError("rospy is not installed: construct optical_fusion(spin=False) and drive call_* / step() yourself")
+        rospy.Subscriber('/mavros/imu/data', Imu, self.call_imu)
+        rospy.Subscriber('/camerav2_1280x960/image_raw/compressed', CompressedImage, self.call_optical)
+        rospy.Subscriber('/mavros/distance_sensor/hrlv_ez4_pub', Range, self.call_dist)
+        self.visualize = rospy.Publisher('visualisation', Image, queue_size=1)
+        while not rospy.is_shutdown():
+            if self.step() is None:
+                time.sleep(0.0005)          # the reference spins hot; yield the GIL to the callback threads
+
+
+def main():
+    print('++')
+    if rospy is None:
+        raise SystemExit("velocity_measurment_node needs ROS (rospy, cv_bridge, sensor_msgs)")
+    rospy.init_node('velocity_calc')
+    print('--')
+    try:
+        optical_fusion()
+    except rospy.ROSInterruptException:
+        pass
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,201 @@
+/*
+ * include/ofk.h — C ABI of libofk.so, the MI355X (gfx950) implementation of the
+ * optical-flow -> ego-velocity hot path of
+ * liquidcronos/Drone-stabilisation-using-Optical-Flow-Gps-and-Inertial-Sensors.
+ *
+ * The reference has no FFI for this path: it is Python calling cv2 / numpy.  The entry
+ * points below are therefore what a ctypes binding in the reference's own files would
+ * call in place of each cv2 / numpy call (file:line of the call being replaced is given
+ * per function; paths relative to the reference root; "node" = velocity_measurment_node).
+ * INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++ or torch types, no exceptions.
+ *   - Every function returns 0 on success or a negative OFK_E_* code; the text of the
+ *     last error is available from ofk_last_error().
+ *   - Image buffers are C-contiguous: gray [batch][h][w] u8, BGR [batch][h][w][3] u8,
+ *     points [batch][stride][2] f32 as (x = column, y = row) — the layout of OpenCV's
+ *     (N,1,2) float32 arrays.
+ *   - Unless a parameter is documented as a DEVICE pointer, buffers are caller-owned
+ *     HOST memory; the library copies to/from device memory it owns inside the context.
+ *   - One context = one device + one HIP stream.  Not thread-safe: the caller serialises
+ *     calls on a context (the Python facade holds a lock).
+ *   - There is no CPU fallback: every entry point runs HIP kernels or fails.
+ */
+#ifndef OFK_H
+#define OFK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OFK_VERSION 100          /* 0.1.0 */
+
+#define OFK_OK            0
+#define OFK_E_INVALID    -1      /* bad argument / exceeds what the context was created for */
+#define OFK_E_HIP        -2      /* a HIP runtime call failed (see ofk_last_error) */
+#define OFK_E_CAPACITY   -3      /* a device-side list overflowed its capacity */
+#define OFK_E_NOGPU      -4      /* no usable gfx950 device */
+
+typedef struct ofk_ctx ofk_ctx;
+
+/* ---------------------------------------------------------------- lifecycle */
+int         ofk_version(void);
+const char *ofk_last_error(const ofk_ctx *ctx);      /* ctx may be NULL: error of the last failed ofk_create */
+int         ofk_device_count(void);
+/* max_w/max_h: largest frame; max_batch: frame pairs per call; max_pts: corners per frame;
+ * max_level: deepest LK pyramid level (0..8). */
+int         ofk_create(int device, int max_w, int max_h, int max_batch, int max_pts, int max_level, ofk_ctx **out);
+int         ofk_destroy(ofk_ctx *ctx);
+int         ofk_sync(ofk_ctx *ctx);                   /* hipStreamSynchronize on the context's stream */
+int         ofk_device_sync(void);                    /* hipDeviceSynchronize */
+
+/* ------------------------------------------------- stage entry points (host buffers, synchronous) */
+
+/* cv2.cvtColor(img, cv2.COLOR_BGR2GRAY) — of_module.py:40,80; node:113; evaluate_exp.py:65,85; of_library.py:236,248.
+ * Y = (3735 B + 19235 G + 9798 R + 16384) >> 15. */
+int ofk_gray_bgr8(ofk_ctx *ctx, const uint8_t *bgr, int batch, int h, int w, uint8_t *gray);
+
+/* One pyrDown step of the pyramid cv2.calcOpticalFlowPyrLK builds (of_module.py:88; node:133; evaluate_exp.py:98):
+ * separable [1 4 6 4 1]/16, REFLECT_101, dst = ((h+1)/2, (w+1)/2). */
+int ofk_pyr_down_u8(ofk_ctx *ctx, const uint8_t *src, int batch, int h, int w, uint8_t *dst);
+
+/* Scharr derivatives of one pyramid level as calcOpticalFlowPyrLK computes them (same call sites):
+ * dxdy [batch][h][w][2] int16 = (dx, dy), REFLECT_101 at the image border. */
+int ofk_scharr_s16(ofk_ctx *ctx, const uint8_t *gray, int batch, int h, int w, int16_t *dxdy);
+
+/* Shi-Tomasi response inside cv2.goodFeaturesToTrack (of_module.py:44,86; node:120,163; evaluate_exp.py:66,106;
+ * of_library.py:238): Sobel-3 -> structure tensor box(block_size) -> min eigenvalue, f32 map [batch][h][w].
+ * block_size 1..45. */
+int ofk_mineig_response(ofk_ctx *ctx, const uint8_t *gray, int batch, int h, int w, int block_size, float *eig);
+
+/* Selection half of cv2.goodFeaturesToTrack: > quality*max, 3x3 local max, sort (value desc, index asc),
+ * greedy min-distance, top max_corners.  mask (nullable) [batch][h][w] u8, 0 = excluded.
+ * pts [batch][max_corners][2] f32, counts [batch]. max_corners in 1..ctx max_pts. */
+int ofk_select_corners(ofk_ctx *ctx, const float *eig, const uint8_t *mask, int batch, int h, int w, int max_corners,
+                       double quality, double min_distance, float *pts, int *counts);
+
+/* cv2.goodFeaturesToTrack(gray, mask=mask, maxCorners, qualityLevel, minDistance, blockSize) — same call sites. */
+int ofk_good_features(ofk_ctx *ctx, const uint8_t *gray, const uint8_t *mask, int batch, int h, int w, int max_corners,
+                      double quality, double min_distance, int block_size, float *pts, int *counts);
+
+/* cv2.calcOpticalFlowPyrLK(prev, next, prevPts, None, winSize=(win,win), maxLevel, criteria=(EPS|COUNT, max_count, eps))
+ * — of_module.py:88; node:133; evaluate_exp.py:98; of_library.py:249.
+ * prev_pts/next_pts [batch][pts_stride][2] f32, counts [batch] (points used per image, <= pts_stride),
+ * status [batch][pts_stride] u8, err [batch][pts_stride] f32.  win odd, 3..31. */
+int ofk_lk_pyr(ofk_ctx *ctx, const uint8_t *prev, const uint8_t *next, int batch, int h, int w, const float *prev_pts,
+               const int *counts, int pts_stride, int win, int max_level, int max_count, double eps, double min_eig_thr,
+               float *next_pts, uint8_t *status, float *err);
+
+/* ------------------------------------------------- estimation (float64, batched over `batch` independent problems) */
+
+/* generate_test_data(x, v, omega, d, n[, t]) — node:25-29; simulation.py:7-12.
+ * x [batch][n][2]; v, omega, nrm, t [batch][3] (t nullable = no lever arm); d [batch]; flow [batch][n][2]. */
+int ofk_flow_model(ofk_ctx *ctx, const double *x, int batch, int n, const double *v, const double *omega, const double *d,
+                   const double *nrm, const double *t, double *flow);
+
+#define OFK_FEAS_RTILDE  0   /* of.r_tilde(x,u,n,v,dist)            of_library.py:365-386 (node:238) */
+#define OFK_FEAS_LEGACY  1   /* 4-arg r_tilde, no guard, no /dist    sensor_precision_experiments/pixhawk_pure_IMU/of_library.py:365-380 (of_module.py:125) */
+#define OFK_FEAS_SIM     2   /* feasibility(pos,v,flow,omega,t,n)    simulation.py:108-120 */
+/* x,u [batch][n][2]; nrm,v [batch][3]; dist [batch] (RTILDE only); omega,t [batch][3] (SIM only, else nullable);
+ * r,dd [batch][n]. */
+int ofk_feasibility(ofk_ctx *ctx, int variant, const double *x, const double *u, int batch, int n, const double *nrm,
+                    const double *v, const double *dist, const double *omega, const double *t, double *r, double *dd);
+
+#define OFK_SOLVE_NODE      0   /* node:30-42 / evaluate_exp.py:18-31: A_i=[p]x,        b_i=[p]x(u+[p]x w)/(n.p) */
+#define OFK_SOLVE_SIM       1   /* simulation.py:15-30:               A_i=[p]x (n.p),  b_i=[p]x(u+[p]x w)        */
+#define OFK_SOLVE_OFMODULE  2   /* of_module.py:139-146:              A_i=[p]x/w_i,    b_i=A_i u_i/(n.p), no omega, no d */
+#define OFK_SOLVE_DOUBLES   8   /* out per problem: v[3], residual SS, rank, s[3] (singular values, descending) */
+/* x,u [batch][n][2]; valid (nullable) [batch][n] u8, 0 = skip the point; d [batch]; nrm, omega [batch][3];
+ * t (nullable) [batch][3]: subtract omega x t from v (simulation.py:28, evaluate_exp.py:29);
+ * wgt (OFMODULE only) [batch][n] per-point distance.  Fewer than 1 valid point -> rank 0, v = 0. */
+int ofk_velocity_solve(ofk_ctx *ctx, int variant, const double *x, const double *u, const uint8_t *valid, int batch, int n,
+                       const double *d, const double *nrm, const double *omega, const double *t, const double *wgt,
+                       double *out);
+
+/* optical_fusion.call_imu — node:61-89, batched over independent IMU streams, one message each.
+ * state [batch][OFK_IMU_STATE]: vel[3], old_time, time_zero, first(0/1), rotation[9], normal[3], ang[3], ang_err[3]
+ * msg   [batch][OFK_IMU_MSG]  : secs, nsecs, qx,qy,qz,qw, wx,wy,wz, cov0,cov4,cov8, ax,ay,az */
+#define OFK_IMU_STATE 24
+#define OFK_IMU_MSG   15
+int ofk_imu_propagate(ofk_ctx *ctx, double *state, const double *msg, int batch);
+
+/* node:258 — v_uav = R (v_obs - [w]x offset).  v_obs, ang, offset [batch][3]; rotation [batch][9]; v_uav [batch][3]. */
+int ofk_post_solve(ofk_ctx *ctx, const double *v_obs, const double *rotation, const double *ang, const double *offset,
+                   int batch, double *v_uav);
+
+/* cv2.KalmanFilter(ns, nm, nc).predict(control) then .correct(measurement) — of_module.py:63-76,122,152
+ * (the reference uses ns=nm=nc=3 with F=B=H=I; ns<=6, nm<=6, nc<=6 supported, row-major matrices shared by the batch).
+ * x [batch][ns], P [batch][ns][ns] are updated in place; B/u nullable (no control); z nullable (predict only);
+ * do_predict = 0 skips the predict step. */
+int ofk_kf_predict_update(ofk_ctx *ctx, int ns, int nm, int nc, const double *F, const double *Bm, const double *H,
+                          const double *Q, const double *Rm, double *x, double *P, const double *u, const double *z,
+                          int batch, int do_predict);
+
+/* of_simulation(...) — simulation.py:36-66 with the np.random.normal draws supplied by the caller:
+ * z [trials][10+4n] standard normals in the reference's draw order (omega 3, t 3, height 1, flow 2n, position 2n,
+ * normal 3 — drawn and discarded, simulation.py:45-46).  truth = v[3], omega[3], height, normal[3], t[3] (13);
+ * sig = ang_vel, translation, height, flow, position, normal (6).  pos, true_flow [n][2].
+ * v_obs [trials][3], bound [trials] (analytic error bound, simulation.py:56-64). */
+int ofk_of_simulation(ofk_ctx *ctx, const double *truth, const double *sig, const double *pos, const double *true_flow,
+                      int n, const double *z, int trials, double *v_obs, double *bound);
+
+/* ------------------------------------------------- resident frame-pair pipeline (the benchmarked path) */
+
+typedef struct ofk_params {
+    int    max_corners;      /* goodFeaturesToTrack maxCorners (<= ctx max_pts) */
+    double quality;          /* qualityLevel */
+    double min_distance;     /* minDistance */
+    int    block_size;       /* blockSize */
+    int    win;              /* LK winSize (square) */
+    int    max_level;        /* LK maxLevel */
+    int    max_count;        /* LK criteria COUNT */
+    double eps;              /* LK criteria EPS */
+    double min_eig_thr;      /* LK minEigThreshold (1e-4) */
+    int    solve_variant;    /* OFK_SOLVE_NODE / OFK_SOLVE_SIM */
+    int    use_feasibility;  /* 1: keep points with r_tilde <= feas_T (node:238-245) using sensors' prior velocity */
+    double feas_T;
+} ofk_params;
+
+/* Per-pair sensor record, [batch][OFK_SENSOR_DOUBLES] doubles:
+ * 0 d (plane distance)  1-3 normal  4-6 omega  7-15 rotation (row-major)  16-18 offset (lever arm, node:204)
+ * 19 scaling (node:182)  20 cx  21 cy (of.pix_trans, node:229)  22-24 prior velocity (feasibility)  25-27 reserved */
+#define OFK_SENSOR_DOUBLES 28
+/* Per-pair result record, [batch][OFK_RECORD_DOUBLES] doubles:
+ * 0-2 v_obs  3 residual SS  4 rank  5-7 singular values  8-10 v_uav (node:258)  11 points used in the solve
+ * 12 corners detected  13 points tracked (status==1)  14-15 reserved */
+#define OFK_RECORD_DOUBLES 16
+
+/* Copies a batch of BGR frame pairs into the context's device buffers (host -> HBM). */
+int ofk_pairs_upload(ofk_ctx *ctx, const uint8_t *prev_bgr, const uint8_t *next_bgr, int batch, int h, int w);
+int ofk_pairs_set_sensors(ofk_ctx *ctx, const double *sensors, int batch);
+/* Runs gray -> pyramids -> corners -> LK -> centre/scale -> (feasibility) -> solve -> post-solve for every resident
+ * pair.  Asynchronous on the context's stream; call ofk_sync / ofk_pairs_download to wait. */
+int ofk_pairs_run(ofk_ctx *ctx, const ofk_params *p);
+/* Any output pointer may be NULL.  records [batch][16] f64; prev_pts/next_pts [batch][max_corners][2] f32;
+ * status [batch][max_corners] u8; err [batch][max_corners] f32; counts [batch]. */
+int ofk_pairs_download(ofk_ctx *ctx, double *records, float *prev_pts, float *next_pts, uint8_t *status, float *err,
+                       int *counts);
+/* Writes the batch's velocity records as float32 [batch][8] = {vx,vy,vz,residual,n_used,s_min,rank,corners} to a
+ * DEVICE pointer owned by the caller (the buffer an RCCL all_gather sends), asynchronously on the context's stream. */
+int ofk_pairs_export_records_f32(ofk_ctx *ctx, void *device_dst, int batch);
+
+/* Per-stage HIP-event timing on the context's stream. */
+#define OFK_STAGE_GRAY    0
+#define OFK_STAGE_PYR     1
+#define OFK_STAGE_EIG     2
+#define OFK_STAGE_NMS     3
+#define OFK_STAGE_SELECT  4
+#define OFK_STAGE_LK      5
+#define OFK_STAGE_SOLVE   6
+#define OFK_N_STAGES      7
+int ofk_profile_enable(ofk_ctx *ctx, int stage_mask);   /* bit s set: bracket stage s with hipEvents in ofk_pairs_run */
+/* Sums the events recorded since the last call (synchronises the stream). ms_total and launches have OFK_N_STAGES entries. */
+int ofk_profile_read(ofk_ctx *ctx, double *ms_total, int *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OFK_H */

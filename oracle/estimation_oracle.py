@@ -1,0 +1,232 @@
+"""oracle/estimation_oracle.py — numpy restatement of the reference's estimation math.
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg; the product package never imports it.
+
+Parity PINNED: every function below follows the cited reference lines and is checked in
+tests/test_oracle_golden.py against tests/golden/reference_numpy.npz, which was produced
+by running the reference's own functions (tests/golden/make_golden.py).  The Kalman
+filter (cv2.KalmanFilter, of_module.py:63-76) is the exception: OpenCV is absent, so
+`kf_predict` / `kf_correct` restate the textbook recursion —
+parity unpinned for that one.
+
+The per-point Python loops of the reference are vectorised; rows are stacked in the same
+order and the same `np.linalg.lstsq` (LAPACK gelsd) call is made, so results agree with
+the reference to rounding (checked at 1e-12).
+"""
+import numpy as np
+
+
+def pix_trans(img_dim):
+    """of_library.py:31-43 — centre offset per axis: d/2 if even else (d+1)/2 (true division, py3)."""
+    tx = img_dim[0] / 2 if img_dim[0] % 2 == 0 else (img_dim[0] + 1) / 2
+    ty = img_dim[1] / 2 if img_dim[1] % 2 == 0 else (img_dim[1] + 1) / 2
+    return tx, ty
+
+
+def _hom(x):
+    x = np.asarray(x, dtype=np.float64)
+    return np.concatenate([x, np.ones((len(x), 1))], axis=1)
+
+
+def generate_test_data(x, v, omega, d, n, t=None):
+    """velocity_measurment_node:25-29 (t=None) / simulation.py:7-12 (lever arm t)."""
+    v = np.asarray(v, dtype=np.float64)
+    omega = np.asarray(omega, dtype=np.float64)
+    n = np.asarray(n, dtype=np.float64)
+    if t is not None:
+        v = v + np.cross(omega, t)
+    p = _hom(x)
+    wxp = np.cross(omega[None, :], p)
+    flow = (p @ n)[:, None] / d * (v[None, :] - v[2] * p) + (wxp - wxp[:, 2:3] * p)
+    return flow[:, :2]
+
+
+def _xhat(x):
+    """Stack of [p]x matrices, (N,3,3): [[0,-1,y],[1,0,-x],[-y,x,0]] (node :35)."""
+    x = np.asarray(x, dtype=np.float64)
+    N = len(x)
+    X = np.zeros((N, 3, 3))
+    X[:, 0, 1] = -1.0; X[:, 0, 2] = x[:, 1]
+    X[:, 1, 0] = 1.0;  X[:, 1, 2] = -x[:, 0]
+    X[:, 2, 0] = -x[:, 1]; X[:, 2, 1] = x[:, 0]
+    return X
+
+
+def _system(x, u, n, omega):
+    x = np.asarray(x, dtype=np.float64); u = np.asarray(u, dtype=np.float64)
+    X = _xhat(x)
+    u3 = np.concatenate([u[:, :2], np.zeros((len(x), 1))], axis=1)
+    inner = u3 + np.einsum("nij,j->ni", X, np.asarray(omega, dtype=np.float64))
+    b = np.einsum("nij,nj->ni", X, inner)
+    ndotp = _hom(x) @ np.asarray(n, dtype=np.float64)
+    return X, b, ndotp
+
+
+def solve_lgs_node(x, u, d, n, omega):
+    """velocity_measurment_node:30-42 — A_i=[p]x, b_i=[p]x(u+[p]x w)/(n.p); lstsq(A, B*d) -> (v,R,rank,s)."""
+    X, b, ndotp = _system(x, u, n, omega)
+    A = X.reshape(-1, 3)
+    B = (b / ndotp[:, None]).reshape(-1)
+    return np.linalg.lstsq(A, B * d, rcond=None)
+
+
+def solve_lgs_sim(x, u, d, n, omega, t):
+    """simulation.py:15-30 — A_i=[p]x (n.p), b_i=[p]x(u+[p]x w); returns (v - w x t, R, s)."""
+    X, b, ndotp = _system(x, u, n, omega)
+    A = (X * ndotp[:, None, None]).reshape(-1, 3)
+    v, R, rank, s = np.linalg.lstsq(A, b.reshape(-1) * d, rcond=None)
+    return v - np.cross(omega, t), R, s
+
+
+def solve_lgs_eval(x, u, d, n, omega, t):
+    """evaluate_exp.py:18-31 — node system, then v - w x t; returns (v, R)."""
+    v, R, rank, s = solve_lgs_node(x, u, d, n, omega)
+    return v - np.cross(omega, t), R
+
+
+def solve_of_module(x3, u3, dist, n):
+    """of_module.py:139-146 — A_i=[p]x/dist_i, b_i=A_i u_i/(n.p) (u is a 3-vector, no omega term)."""
+    x3 = np.asarray(x3, dtype=np.float64); u3 = np.asarray(u3, dtype=np.float64)
+    Ai = _xhat(x3[:, :2]) / np.asarray(dist, dtype=np.float64)[:, None, None]
+    bi = np.einsum("nij,nj->ni", Ai, u3) / (x3 @ np.asarray(n, dtype=np.float64))[:, None]
+    return np.linalg.lstsq(Ai.reshape(-1, 3), bi.reshape(-1), rcond=None)
+
+
+def r_tilde(x, u, n, v, dist):
+    """of_library.py:365-386 — feasibility cosine r and distance ratio d per point."""
+    p = _hom(x)
+    u3 = np.concatenate([np.asarray(u, dtype=np.float64)[:, :2], np.zeros((len(p), 1))], axis=1)
+    vc = -np.cross(p, np.asarray(v, dtype=np.float64)[None, :])
+    uc = np.cross(p, u3)
+    vn = np.linalg.norm(vc, axis=1); un = np.linalg.norm(uc, axis=1)
+    zero = (un * vn) == 0
+    with np.errstate(divide="ignore", invalid="ignore"):
+        r = np.einsum("ni,ni->n", vc, uc) * (1.0 / un) / vn
+        pn = p @ np.asarray(n, dtype=np.float64)
+        r = np.where(pn < 0, -r, r)
+        dd = pn * vn * (1.0 / un) / dist
+    r = np.where(zero, 1.0, r)
+    dd = np.where(zero, 1.0, dd)
+    return r, dd
+
+
+def r_tilde_legacy(x3, u3, n, v):
+    """sensor_precision_experiments/pixhawk_pure_IMU/of_library.py:365-380 — 4-arg form on homogeneous
+    3-vectors, no zero guard, no /dist (the variant of_module.py:125 calls)."""
+    x3 = np.asarray(x3, dtype=np.float64); u3 = np.asarray(u3, dtype=np.float64)
+    vc = -np.cross(x3, np.asarray(v, dtype=np.float64)[None, :])
+    uc = np.cross(x3, u3)
+    vn = np.linalg.norm(vc, axis=1); iun = 1.0 / np.linalg.norm(uc, axis=1)
+    r = np.einsum("ni,ni->n", vc, uc) * iun / vn
+    pn = x3 @ np.asarray(n, dtype=np.float64)
+    r = np.where(pn < 0, -r, r)
+    return r, pn * vn * iun
+
+
+def feasibility_sim(position, linear_velocity, flow, angular_velocity, translation, normal):
+    """simulation.py:108-120 — returns array([parallelity, length])."""
+    p = _hom(position)
+    w = np.asarray(angular_velocity, dtype=np.float64)
+    f3 = np.concatenate([np.asarray(flow, dtype=np.float64)[:, :2], np.zeros((len(p), 1))], axis=1)
+    fac1 = np.cross(p, (np.asarray(linear_velocity, dtype=np.float64) - np.cross(w, translation))[None, :])
+    fac2 = np.cross(p, f3 - np.cross(w[None, :], p))
+    n1 = np.linalg.norm(fac1, axis=1); n2 = np.linalg.norm(fac2, axis=1)
+    par = np.einsum("ni,ni->n", fac1, fac2) / (n1 * n2)
+    length = n1 / n2 * (p @ np.asarray(normal, dtype=np.float64))
+    return np.array([par, length])
+
+
+def static_immobile(newpos, oldpos, maxspeed, distance, dummy_value):
+    """of_library.py:88-92."""
+    speed = np.abs(newpos - oldpos) < (maxspeed / distance)
+    dummy = oldpos != dummy_value
+    stable = speed * dummy
+    return stable[:, :, 0] * stable[:, :, 1]
+
+
+def quat_to_rot(qx, qy, qz, qw):
+    """velocity_measurment_node:66-68."""
+    return np.array([[1.0 - 2 * (qy ** 2 + qz ** 2), 2 * (qx * qy - qw * qz), 2 * (qw * qy + qx * qz)],
+                     [2 * (qx * qy + qw * qz), 1.0 - 2 * (qx ** 2 + qz ** 2), 2 * (qy * qz - qw * qx)],
+                     [2 * (qx * qz - qw * qy), 2 * (qw * qx + qy * qz), 1.0 - 2 * (qx ** 2 + qy ** 2)]])
+
+
+def imu_step(state, secs, nsecs, q, ang, ang_cov_diag, acc):
+    """velocity_measurment_node:61-89 (call_imu).  `state` is a dict with vel, old_time, time_zero, first;
+    returns the updated dict (+ rotation, normal, ang, ang_err).  got_vel_ is always False (node :260-262
+    toggles a local)."""
+    st = dict(state)
+    st["ang"] = np.asarray(ang, dtype=np.float64)
+    st["ang_err"] = np.asarray(ang_cov_diag, dtype=np.float64)
+    R = quat_to_rot(*q)
+    st["rotation"] = R
+    st["normal"] = R @ np.array([0.0, 0.0, 1.0])
+    if st["first"]:
+        st["old_time"] = float(nsecs) / 10 ** 9
+        st["time_zero"] = secs
+        st["first"] = False
+    else:
+        current = float(secs - st["time_zero"]) + float(nsecs) / 10 ** 9
+        elapsed = current - st["old_time"]
+        st["vel"] = st["vel"] + R @ (np.asarray(acc, dtype=np.float64) - 9.81 * st["normal"]) * elapsed
+        st["old_time"] = float(current)
+    return st
+
+
+def post_solve(v_obs, rotation, ang, offset):
+    """velocity_measurment_node:258 — v_uav = R (v_obs - [w]x offset)."""
+    W = np.array([[0, -ang[2], ang[1]], [ang[2], 0, -ang[0]], [-ang[1], ang[0], 0]], dtype=np.float64)
+    return rotation @ (np.asarray(v_obs, dtype=np.float64) - W @ np.asarray(offset, dtype=np.float64))
+
+
+# ---- Kalman filter (cv2.KalmanFilter semantics, float64 as the reference assigns float64 matrices;
+#      of_module.py:63-76,122,152).  PARITY UNPINNED (OpenCV absent).
+def kf_predict(x, P, F, Q, B=None, u=None):
+    x = F @ x
+    if B is not None and u is not None:
+        x = x + B @ u
+    P = F @ P @ F.T + Q
+    return x, P
+
+
+def kf_correct(x, P, H, Rm, z):
+    S = H @ P @ H.T + Rm
+    K = np.linalg.solve(S, H @ P).T
+    x = x + K @ (z - H @ x)
+    P = P - K @ H @ P
+    return x, P
+
+
+def of_simulation(linear_velocity, angular_velocity, height_above_gr, normal_vector, translation, pos, true_flow,
+                  sig, z, iterations):
+    """simulation.py:36-66 with the np.random.normal draws replaced by a flat tensor of standard normals `z`
+    consumed in the reference's draw order: per iteration 3 (omega), 3 (t), 1 (height), 2N (flow),
+    2N (position), 3 (normal; drawn then discarded, simulation.py:45-46).
+    sig = (ang_vel_sig, translation_sig, height_sig, flow_sig, position_sig, normal_sig).
+    Returns v_obs (iterations,3), analytic bound R (iterations,), last feasibility (2,N)."""
+    N = len(pos)
+    per = 3 + 3 + 1 + 2 * N + 2 * N + 3
+    z = np.asarray(z, dtype=np.float64).reshape(iterations, per)
+    v_obs = np.zeros((iterations, 3)); Rb = np.zeros(iterations)
+    lv = np.asarray(linear_velocity, dtype=np.float64); av = np.asarray(angular_velocity, dtype=np.float64)
+    nv = np.asarray(normal_vector, dtype=np.float64); tr = np.asarray(translation, dtype=np.float64)
+    feas = None
+    for i in range(iterations):
+        zi = z[i]; o = 0
+        ang_err = av + sig[0] * zi[o:o + 3]; o += 3
+        tr_err = tr + sig[1] * zi[o:o + 3]; o += 3
+        h_err = height_above_gr + sig[2] * zi[o:o + 1]; o += 1
+        flow_err = true_flow + sig[3] * zi[o:o + 2 * N].reshape(N, 2); o += 2 * N
+        pos_err = pos + sig[4] * zi[o:o + 2 * N].reshape(N, 2); o += 2 * N
+        normal_err = nv / np.linalg.norm(nv)
+        v_obs[i], Res, singular = solve_lgs_sim(pos_err, flow_err, h_err, normal_err, ang_err, tr_err)
+        xp = _hom(pos)
+        dxp = _hom(pos_err) - xp
+        ddotx = np.concatenate([flow_err - true_flow, np.zeros((N, 1))], axis=1)
+        v_err = (h_err - height_above_gr) / height_above_gr * (xp @ nv) + xp @ (normal_err - nv) + dxp @ nv
+        d_err = ddotx + np.cross(dxp, av[None, :]) + np.cross(xp, (ang_err - av)[None, :]) + dxp
+        part = np.linalg.norm(np.cross(xp, v_err[:, None] * lv[None, :] + height_above_gr * d_err), axis=1) / np.amin(singular)
+        Rb[i] = np.sqrt(np.sum(part ** 2)) + np.linalg.norm(av) * sig[1] + sig[0] * np.linalg.norm(tr) + sig[0] * sig[1]
+        feas = feasibility_sim(pos_err, lv, flow_err, ang_err, tr_err, normal_err)
+    return v_obs, feas, Rb

@@ -1,0 +1,207 @@
+"""GPU parity, image stages: every HIP kernel is compared BIT-EXACTLY with oracle/image_oracle.c through the
+C ABI (ctypes).  The oracle's image semantics are parity-unpinned w.r.t. OpenCV (absent); see its header."""
+import numpy as np
+import pytest
+
+from oracle import image_oracle as io
+
+pytestmark = pytest.mark.gpu
+
+
+def rand_u8(shape, seed):
+    return np.random.default_rng(seed).integers(0, 256, shape, dtype=np.uint8)
+
+
+def textured(h, w, seed, pkg):
+    from of_amd import synth
+    return np.clip(np.rint(synth.make_texture(h, w, seed)), 0, 255).astype(np.uint8)
+
+
+SHAPES = [(240, 320), (33, 47), (135, 241), (480, 640), (1080, 1920)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_gray(gpu_ctx, shape):
+    bgr = rand_u8((2,) + shape + (3,), 1)
+    got = gpu_ctx.gray_bgr8(bgr)
+    for b in range(2):
+        assert np.array_equal(got[b], io.gray_bgr8(bgr[b]))
+    # KATs: white stays white, pure channels hit the coefficient table
+    kat = np.zeros((1, 16, 16, 3), np.uint8); kat[0, 0] = 255; kat[0, 1, :, 0] = 255; kat[0, 2, :, 1] = 255; kat[0, 3, :, 2] = 255
+    g = gpu_ctx.gray_bgr8(kat)[0]
+    assert g[0, 0] == 255 and g[1, 0] == 29 and g[2, 0] == 150 and g[3, 0] == 76 and g[4, 0] == 0
+
+
+@pytest.mark.parametrize("shape", SHAPES + [(16, 17), (2, 2), (3, 300)])
+def test_pyr_down(gpu_ctx, shape):
+    src = rand_u8((2,) + shape, 2)
+    got = gpu_ctx.pyr_down(src)
+    for b in range(2):
+        assert np.array_equal(got[b], io.pyr_down(src[b]))
+    assert np.all(gpu_ctx.pyr_down(np.full(shape, 77, np.uint8)) == 77)
+
+
+@pytest.mark.parametrize("shape", SHAPES + [(2, 2), (5, 130)])
+def test_scharr(gpu_ctx, shape):
+    src = rand_u8((2,) + shape, 3)
+    got = gpu_ctx.scharr(src)
+    for b in range(2):
+        assert np.array_equal(got[b], io.scharr(src[b]))
+
+
+@pytest.mark.parametrize("block", [3, 7, 12, 32])
+@pytest.mark.parametrize("shape", [(240, 320), (97, 131), (480, 640)])
+def test_mineig_bit_exact(gpu_ctx, pkg, shape, block):
+    imgs = np.stack([rand_u8(shape, 4), textured(shape[0], shape[1], 5, pkg)])
+    got = gpu_ctx.mineig(imgs, block)
+    for b in range(2):
+        ref = io.mineig(imgs[b], block)
+        assert np.array_equal(got[b].view(np.uint32), ref.view(np.uint32)), f"max diff {np.abs(got[b] - ref).max()}"
+
+
+def test_mineig_1080p_and_invariance(gpu_ctx, pkg):
+    img = textured(1080, 1920, 6, pkg)
+    got = gpu_ctx.mineig(img, 7)
+    assert np.array_equal(got.view(np.uint32), io.mineig(img, 7).view(np.uint32))
+    # response is invariant under intensity inversion (gradients flip sign, products do not)
+    assert np.array_equal(gpu_ctx.mineig(255 - img, 7).view(np.uint32), got.view(np.uint32))
+    assert np.all(gpu_ctx.mineig(np.full((64, 64), 9, np.uint8), 7) == 0)
+
+
+def corners_equal(gpu_ctx, img, mc, q, md, bs, mask=None):
+    got = gpu_ctx.good_features(img, mc, q, md, bs, mask=mask)
+    ref = io.good_features(img, mc, q, md, bs, mask=mask)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert np.array_equal(got, ref)
+    return got
+
+
+PARAMS = [(50, 0.3, 20, 32), (100, 0.7, 10, 12), (20, 0.7, 10, 7), (500, 0.01, 10, 7), (2000, 0.001, 3, 3), (300, 0.05, 0, 5)]
+
+
+@pytest.mark.parametrize("mc,q,md,bs", PARAMS)
+def test_good_features_param_sets(gpu_ctx, pkg, mc, q, md, bs):
+    for seed, shape in [(7, (480, 640)), (8, (240, 320))]:
+        pts = corners_equal(gpu_ctx, textured(shape[0], shape[1], seed, pkg), mc, q, md, bs)
+        assert len(pts) > 0
+
+
+def test_good_features_1080p_500(gpu_ctx, pkg):
+    pts = corners_equal(gpu_ctx, textured(1080, 1920, 9, pkg), 500, 0.01, 10, 7)
+    assert len(pts) == 500
+
+
+def test_good_features_many_candidates_chunked(gpu_ctx):
+    """Noise image at a tiny quality level: tens of thousands of candidates, several 4096-key selection rounds."""
+    img = rand_u8((480, 640), 10)
+    eig = io.mineig(img, 3)
+    _, ncand = io.select_corners(eig, 2000, 1e-4, 12.0)
+    assert ncand > 3 * 4096
+    pts = corners_equal(gpu_ctx, img, 2000, 1e-4, 12.0, 3)
+    assert len(pts) > 1000
+
+
+def test_good_features_ties_mask_and_empty(gpu_ctx):
+    # checkerboard: massive exact ties -> exercises the (value desc, index asc) order
+    yy, xx = np.mgrid[0:240, 0:320]
+    chk = (((yy // 16) + (xx // 16)) % 2 * 200 + 20).astype(np.uint8)
+    pts = corners_equal(gpu_ctx, chk, 400, 0.2, 5, 5)
+    assert len(pts) > 50
+    # single bright square: its 4 corners, symmetric responses
+    sq = np.zeros((120, 160), np.uint8); sq[40:80, 50:110] = 255
+    pts = corners_equal(gpu_ctx, sq, 10, 0.5, 10, 3)
+    assert len(pts) == 4
+    # constant image -> no corners
+    assert len(gpu_ctx.good_features(np.full((64, 64), 128, np.uint8), 10, 0.1, 5, 3)) == 0
+    # mask excludes the left half (also from the max)
+    img = rand_u8((240, 320), 11)
+    mask = np.ones((240, 320), np.uint8); mask[:, :160] = 0
+    pts = corners_equal(gpu_ctx, img, 100, 0.1, 8, 7, mask=mask)
+    assert len(pts) and np.all(pts[:, 0, 0] >= 160)
+
+
+def test_select_corners_from_map_batch(gpu_ctx):
+    eig = np.stack([io.mineig(rand_u8((200, 300), s), 5) for s in (12, 13, 14)])
+    pts, cnt = gpu_ctx.select_corners(eig, 64, 0.05, 9.0)
+    for b in range(3):
+        ref, _ = io.select_corners(eig[b], 64, 0.05, 9.0)
+        assert cnt[b] == len(ref) and np.array_equal(pts[b, :cnt[b]], ref.reshape(-1, 2))
+
+
+def lk_equal(gpu_ctx, prev, nxt, pts, **kw):
+    gn, gs, ge = gpu_ctx.lk_pyr(prev, nxt, pts, **kw)
+    rn, rs, re = io.lk_pyr(prev, nxt, pts, **kw)
+    assert np.array_equal(gs, rs), f"status differs at {np.nonzero(gs != rs)[0][:8]}"
+    assert np.array_equal(gn.view(np.uint32), rn.view(np.uint32)), f"max |d| {np.abs(gn - rn).max()}"
+    assert np.array_equal(ge.view(np.uint32), re.view(np.uint32))
+    return gn, gs, ge
+
+
+@pytest.fixture(scope="module")
+def pair480(pkg):
+    from of_amd import synth
+    p = synth.render_pair(480, 640, 21, v=(0.004, -0.003, 0.002), omega=(0.004, -0.002, 0.006), d=1.0)
+    return io.gray_bgr8(p["prev"]), io.gray_bgr8(p["next"]), p
+
+
+@pytest.mark.parametrize("kw", [dict(win=15, max_level=3, max_count=20, eps=0.03), dict(win=15, max_level=3, max_count=10, eps=0.5),
+                                dict(win=15, max_level=0, max_count=30, eps=0.01), dict(win=21, max_level=2, max_count=20, eps=0.03),
+                                dict(win=31, max_level=5, max_count=20, eps=0.03), dict(win=7, max_level=4, max_count=5, eps=0.0),
+                                dict(win=15, max_level=3, max_count=0, eps=0.03)])
+def test_lk_bit_exact(gpu_ctx, pair480, kw):
+    g0, g1, p = pair480
+    pts = io.good_features(g0, 300, 0.01, 7, 7)
+    gn, gs, ge = lk_equal(gpu_ctx, g0, g1, pts, **kw)
+    if kw["max_count"] >= 10 and kw["max_level"] >= 2:
+        from of_amd import synth
+        ok = gs.ravel() == 1
+        assert ok.mean() > 0.9
+        flow = (gn - pts).reshape(-1, 2)[ok]
+        truth = synth.true_flow_px(p["H"], pts.reshape(-1, 2)[ok])
+        assert np.median(np.abs(flow - truth)) < 0.1          # tracks the rendered motion
+
+
+def test_lk_edge_cases(gpu_ctx, pair480):
+    g0, g1, _ = pair480
+    h, w = g0.shape
+    # points on and outside the border, plus interior ones
+    pts = np.array([[0, 0], [w - 1, h - 1], [3.5, 2.25], [w - 2.5, 10.75], [-30, 50], [w + 40, 20], [100, -25], [w / 2, h / 2],
+                    [7, 7], [w - 8, h - 8], [6.99, 100.01], [-8, -8], [w + 7, h + 7]], np.float32).reshape(-1, 1, 2)
+    lk_equal(gpu_ctx, g0, g1, pts, win=15, max_level=3, max_count=20, eps=0.03)
+    # identical frames: zero flow, status 1, err 0 on textured points
+    tp = io.good_features(g0, 50, 0.05, 10, 7)
+    gn, gs, ge = lk_equal(gpu_ctx, g0, g0, tp, win=15, max_level=3, max_count=20, eps=0.03)
+    assert np.all(gs == 1) and np.array_equal(gn, tp) and np.all(ge == 0)
+    # flat image: rejected by the min-eigenvalue test
+    flat = np.full((h, w), 100, np.uint8)
+    gn, gs, ge = lk_equal(gpu_ctx, flat, flat, tp, win=15, max_level=3, max_count=20, eps=0.03)
+    assert np.all(gs == 0)
+
+
+def test_lk_batch_ragged_and_translation(gpu_ctx, pkg):
+    from of_amd import synth
+    imgs = [textured(300, 400, 30 + i, pkg) for i in range(3)]
+    prev = np.stack(imgs)
+    nxt = np.stack([np.roll(im, (2 + i, -3 - i), axis=(0, 1)) for i, im in enumerate(imgs)])
+    counts = np.array([40, 0, 17], np.int32)
+    pts = np.zeros((3, 40, 2), np.float32)
+    for b in range(3):
+        pts[b, :counts[b]] = io.good_features(prev[b], 40, 0.05, 12, 7).reshape(-1, 2)[:counts[b]]
+    gn, gs, ge = gpu_ctx.lk_pyr(prev, nxt, pts, counts, win=15, max_level=2, max_count=20, eps=0.03)
+    for b in range(3):
+        n = counts[b]
+        rn, rs, re = io.lk_pyr(prev[b], nxt[b], pts[b, :n], win=15, max_level=2, max_count=20, eps=0.03)
+        assert np.array_equal(gs[b, :n], rs.ravel()) and np.array_equal(gn[b, :n], rn.reshape(-1, 2)) and np.array_equal(ge[b, :n], re.ravel())
+        if n:
+            inner = (pts[b, :n, 0] > 30) & (pts[b, :n, 0] < 370) & (pts[b, :n, 1] > 30) & (pts[b, :n, 1] < 270) & (rs.ravel() == 1)
+            d = (rn.reshape(-1, 2) - pts[b, :n])[inner]
+            assert np.allclose(d, [-3 - b, 2 + b], atol=0.02)      # pure integer translation is recovered
+
+
+def test_lk_1080p_500_points(gpu_ctx, pkg):
+    from of_amd import synth
+    p = synth.render_pair(1080, 1920, 41, v=(0.002, -0.0015, 0.001), omega=(0.002, -0.001, 0.003), d=1.0)
+    g0, g1 = io.gray_bgr8(p["prev"]), io.gray_bgr8(p["next"])
+    pts = io.good_features(g0, 500, 0.01, 10, 7)
+    gn, gs, ge = lk_equal(gpu_ctx, g0, g1, pts, win=15, max_level=3, max_count=20, eps=0.03)
+    assert (gs == 1).mean() > 0.95

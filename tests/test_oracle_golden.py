@@ -1,0 +1,132 @@
+"""Pins oracle/estimation_oracle.py against golden vectors produced by the reference's own numpy
+functions (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import estimation_oracle as eo
+
+TOL = 1e-12
+
+
+def close(a, b, tol=TOL):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    np.testing.assert_allclose(a, b, rtol=tol, atol=tol)
+
+
+def test_g1_roundtrip_points_txt(golden):
+    g = golden
+    flow = eo.generate_test_data(g["g1_points"], g["g1_v"], g["g1_omega"], float(g["g1_d"]), g["g1_n"], g["g1_t"])
+    close(flow, g["g1_flow"])
+    assert abs(flow[0, 0] - 2.593068975207) < 1e-11 and abs(flow[0, 1] - 0.286187463185) < 1e-11
+    v, R, s = eo.solve_lgs_sim(g["g1_points"], flow, float(g["g1_d"]), g["g1_n"], g["g1_omega"], g["g1_t"])
+    close(v, g["g1_v_out"]); close(v, [1, 1, 1]); close(s, g["g1_s"])
+    assert R.shape == (1,) and R[0] < 1e-24
+    vn, Rn, rank, sn = eo.solve_lgs_node(g["g1_points"], flow, float(g["g1_d"]), g["g1_n"], g["g1_omega"])
+    close(vn, g["g1_node_v"]); close(vn, [1.205, 0.815, 0.98]); close(sn, g["g1_node_s"]); assert rank == 3
+
+
+def test_g2_node_kat(golden):
+    g = golden
+    tr = eo.pix_trans((320, 240))
+    x = g["g2_feat"].astype(float)
+    x[:, 0] = (x[:, 0] - tr[0]) * 0.01; x[:, 1] = (x[:, 1] - tr[1]) * 0.01
+    close(x, g["g2_x"])
+    u = eo.generate_test_data(x, [1, 1, 1], [0, 0, 0], 0.75, [0, 0, 1])
+    close(u, g["g2_u"])
+    v, R, rank, s = eo.solve_lgs_node(x, u, 0.75, [0, 0, 1], [0, 0, 0])
+    close(v, [1, 1, 1]); close(s, g["g2_s"]); assert rank == int(g["g2_rank"]) == 3
+
+
+def test_g3_feasibility(golden):
+    g = golden
+    r, d = eo.r_tilde(g["g2_x"], g["g2_u"], [0, 0, 1], [.1, .1, .1], .75)
+    close(r, g["g3_r"]); close(d, g["g3_d"]); close(r, -np.ones(4)); close(d, 0.1 * np.ones(4))
+    r, d = eo.r_tilde(g["g3r_x"], g["g3r_u"], g["g3r_n"], g["g3r_v"], float(g["g3r_dist"]))
+    close(r, g["g3r_r"]); close(d, g["g3r_d"])
+    assert r[5] == 1.0 and d[5] == 1.0          # zero-norm guard
+    r, d = eo.r_tilde(g["g3r_x"], g["g3r_u"], -g["g3r_n"], g["g3r_v"], float(g["g3r_dist"]))
+    close(r, g["g3n_r"]); close(d, g["g3n_d"])
+    fe = eo.feasibility_sim(g["g1_points"], g["g1_v"], g["g1_flow"], g["g1_omega"], g["g1_t"], g["g1_n"])
+    close(fe, g["g3b_out"])
+    close(fe[0, :3], [0.952212343398, 0.850736111959, 0.951098920789], 1e-11)
+    keep = g["g3c_keep"]
+    x3 = np.concatenate([g["g3r_x"], np.ones((64, 1))], 1)[keep]
+    u3 = np.concatenate([g["g3r_u"], np.zeros((64, 1))], 1)[keep]
+    r, d = eo.r_tilde_legacy(x3, u3, g["g3r_n"], g["g3r_v"])
+    close(r, g["g3c_r"]); close(d, g["g3c_d"])
+
+
+@pytest.mark.parametrize("N", [3, 4, 20, 200, 500, 2000])
+def test_g4_solve_variants(golden, N):
+    g = golden; p = f"g4_{N}_"
+    x, u, n, om, d, t = g[p + "x"], g[p + "u"], g[p + "n"], g[p + "omega"], float(g[p + "d"]), g[p + "t"]
+    v, R, rank, s = eo.solve_lgs_node(x, u, d, n, om)
+    close(v, g[p + "node_v"], 1e-10); close(R, g[p + "node_R"], 1e-9); close(s, g[p + "node_s"], 1e-11)
+    assert rank == int(g[p + "node_rank"])
+    v, R, s = eo.solve_lgs_sim(x, u, d, n, om, t)
+    close(v, g[p + "sim_v"], 1e-10); close(R, g[p + "sim_R"], 1e-9); close(s, g[p + "sim_s"], 1e-11)
+    v, R = eo.solve_lgs_eval(x, u, d, n, om, t)
+    close(v, g[p + "eval_v"], 1e-10); close(R, g[p + "eval_R"], 1e-9)
+
+
+def test_g4_rank_deficient(golden):
+    g = golden
+    v, R, rank, s = eo.solve_lgs_node(g["g4_def_x"], g["g4_def_u"], 1.3, [0, 0, 1.0], [0.1, 0.0, -0.2])
+    assert rank == 2 == int(g["g4_def_rank"]) and R.shape == (0,)
+    close(v, g["g4_def_v"], 1e-10); close(s[:2], g["g4_def_s"][:2])
+
+
+def test_g5_call_imu(golden):
+    g = golden
+    st = dict(vel=g["g5_vel0"].copy(), old_time=0.0, time_zero=0, first=True)
+    for m, want in zip(g["g5_msgs"], g["g5_states"]):
+        st = eo.imu_step(st, int(m[0]), int(m[1]), m[2:6], m[6:9], g["g5_cov_diag"], m[9:12])
+        got = np.concatenate([st["vel"], [st["old_time"], st["time_zero"]], st["rotation"].ravel(), st["normal"],
+                              st["ang"], st["ang_err"]])
+        close(got, want, 1e-13)
+    close(golden["g5_states"][1][:3], [0.09819262, 0.1123517, 0.0593944], 1e-7)
+
+
+@pytest.mark.parametrize("lvl", [0, 1, 2])
+def test_g6_of_simulation_injected(golden, lvl):
+    g = golden
+    v_obs, feas, Rb = eo.of_simulation(g["g1_v"], g["g1_omega"], 1, g["g1_n"], g["g1_t"], g["g1_points"], g["g1_flow"],
+                                       g[f"g6_{lvl}_sig"], g[f"g6_{lvl}_z"], 16)
+    close(v_obs, g[f"g6_{lvl}_v_obs"], 1e-10); close(Rb, g[f"g6_{lvl}_bound"], 1e-9)
+    close(feas, g[f"g6_{lvl}_feasible_last"], 1e-10)
+
+
+def test_g7_pix_trans_static(golden):
+    g = golden
+    for i, o in zip(g["g7_in"], g["g7_out"]):
+        close(eo.pix_trans(tuple(int(v) for v in i)), o)
+    assert np.array_equal(eo.static_immobile(g["g7_newpos"], g["g7_oldpos"], 3.0, 1.5, -1.0), g["g7_static"])
+
+
+def test_g9_of_module_system(golden):
+    g = golden
+    v, R, rank, s = eo.solve_of_module(g["g9_x"], g["g9_u"], g["g9_dist"], [0, 0, 1])
+    close(v, g["g9_v"], 1e-10); close(R, g["g9_R"], 1e-9); close(s, g["g9_s"], 1e-11); assert rank == int(g["g9_rank"])
+
+
+def test_g10_post_solve(golden):
+    g = golden
+    close(eo.post_solve(g["g10_v_obs"], g["g10_rotation"], g["g10_ang"], g["g10_offset"]), g["g10_v_uav"], 1e-13)
+
+
+def test_kf_scalar_recursion():
+    """of_module.py:63-76 matrices (F=B=H=I, Q=1e-5 I, R=10 I, P0=.1 I) reduce to a scalar recursion per axis
+    (SURVEY.md Appendix B5).  Parity unpinned (OpenCV absent): closed-form KAT only."""
+    I = np.eye(3)
+    x = np.zeros(3); P = 0.1 * I
+    xs, ps = 0.0, 0.1
+    rng = np.random.default_rng(0)
+    for _ in range(25):
+        u = rng.normal(0, 0.01, 3); z = rng.normal(0, 1, 3)
+        x, P = eo.kf_predict(x, P, I, 1e-5 * I, I, u)
+        x, P = eo.kf_correct(x, P, I, 10 * I, z)
+        xs = xs + u[0]; ps = ps + 1e-5
+        k = ps / (ps + 10); xs = xs + k * (z[0] - xs); ps = (1 - k) * ps
+        assert abs(x[0] - xs) < 1e-14 and abs(P[0, 0] - ps) < 1e-15
+        assert abs(P[0, 1]) < 1e-18
