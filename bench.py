@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py — frame-pairs/s of the optical-flow -> ego-velocity hot path at 1920x1080 (BASELINE.json configs[1]:
+500 Shi-Tomasi corners, 3-level LK pyramid) on N MI355X GPUs.
+
+  python bench.py [--gpus N --steps K --warmup W --batch B]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the whole hot path (BGR pair -> gray -> pyramids -> corners -> LK -> velocity) over a batch
+of B synthetic 1080p frame pairs per GPU that are already resident in HBM.  Frame pairs are independent, so ranks
+shard them with no data-path collective ("weak" scaling: B pairs per GPU); the only exchange is an RCCL all_gather
+of the [B,8] f32 velocity records after every step.  Timing: W warm-up steps, then exactly K steps between
+barrier + device synchronize on both sides, MAX over ranks.  Under torchrun the barrier/synchronize/all_gather are
+torch.distributed (nccl = RCCL) and torch.cuda.synchronize(); a plain single-process run (N=1) has nothing to
+exchange and uses hipDeviceSynchronize through the library, so torch is not imported at all.
+
+The JSON line also carries
+  roofline     : the stage with the largest share of the step, from HIP events recorded on the library's stream inside
+                 the timed region; achieved = SURVEY.md §8(d) algorithmic bytes per pair x B / mean stage time.
+  stages       : the same for every stage (ms per step, algorithmic GB/s).
+  cpu_baseline : the CPU oracle (oracle/, single thread, kind "port") timed on this host over a bounded sample of the
+                 same frame pairs (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package  # noqa: E402
+
+H, W = 1080, 1920
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def algorithmic_bytes(cfg, n_pts, n_cand):
+    """algorithmic bytes per frame pair, per stage (1080p, L levels, N points, w window)."""
+    P = [H * W]
+    h, w = H, W
+    for _ in range(cfg.max_level):
+        h, w = (h + 1) // 2, (w + 1) // 2
+        P.append(h * w)
+    L = cfg.max_level
+    wn = cfg.win
+    return {
+        "gray": 2 * (3 * P[0] + P[0]),
+        "pyr": 2 * sum(P[l - 1] + P[l] for l in range(1, L + 1)),
+        "eig": P[0] + 4 * P[0],
+        "nms": 4 * P[0] + 8 * n_cand,
+        "select": 8 * n_cand + 8 * n_pts,
+        "lk": n_pts * sum((wn + 2) ** 2 + (wn + 1 + 2 * 3) ** 2 for _ in range(L + 1)) + 21 * n_pts,
+        "solve": n_pts * 32 + 200,
+    }
+
+
+def cpu_baseline(prev, nxt, sensors, cfg, sample):
+    """Single-thread CPU oracle over `sample` pairs of the same workload (test infrastructure used as the checker's
+    timing leg only)."""
+    from oracle import image_oracle as io, estimation_oracle as eo
+    io.lib()
+    t0 = time.perf_counter()
+    v = None
+    for b in range(sample):
+        g0, g1 = io.gray_bgr8(prev[b]), io.gray_bgr8(nxt[b])
+        pts = io.good_features(g0, cfg.max_corners, cfg.quality, cfg.min_distance, cfg.block_size)
+        n, s, e = io.lk_pyr(g0, g1, pts, cfg.win, cfg.max_level, cfg.max_count, cfg.eps, cfg.min_eig_thr)
+        ok = s.ravel() == 1
+        sr = sensors[b]
+        new = n.reshape(-1, 2).astype(np.float64); old = pts.reshape(-1, 2).astype(np.float64)
+        x = (new[ok] - [sr[20], sr[21]]) * sr[19]; u = (new[ok] - old[ok]) * sr[19]
+        v = eo.solve_lgs_node(x, u, sr[0], sr[1:4], sr[4:7])[0]
+    dt = time.perf_counter() - t0
+    return sample / dt, v
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="frame pairs per GPU per step")
+    ap.add_argument("--cpu-sample", type=int, default=24, help="pairs timed on the CPU oracle (0 = skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = torch = None
+    if "WORLD_SIZE" in os.environ and "RANK" in os.environ:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; reporting n_gpus={world}", file=sys.stderr)
+
+    load_package()
+    import of_amd.ofk as ofk
+    from of_amd import synth
+    from of_amd.pipeline import FlowPipeline, PipelineConfig
+
+    cfg = PipelineConfig.baseline_1080p()
+    B = args.batch
+    truth = dict(v=(0.002, -0.0015, 0.001), omega=(0.002, -0.001, 0.003), d=1.0)
+    prev, nxt, base = synth.make_batch(B, H, W, seed=2000 + 131 * rank, distinct=4, **truth)
+    p0 = base[0]
+    sensors = ofk.make_sensors(B, d=p0["d"], normal=p0["n"], omega=p0["omega"], scaling=p0["scaling"], cx=p0["cx"], cy=p0["cy"])
+    pipe = FlowPipeline(W, H, B, cfg, device=local)
+    pipe.upload(prev, nxt, sensors)
+
+    gathered = rec_t = None
+    if dist is not None:
+        rec_t = torch.zeros((B, 8), dtype=torch.float32, device=f"cuda:{local}")
+        gathered = torch.zeros((world * B, 8), dtype=torch.float32, device=f"cuda:{local}")
+
+    def sync_all():
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+        else:
+            pipe.ctx._ck(pipe.ctx._L.ofk_device_sync())
+
+    def step():
+        pipe.run_async()
+        if dist is not None:
+            pipe.ctx.pairs_export_records_f32(rec_t.data_ptr(), B)
+            pipe.sync()                                  # records complete on the library's stream
+            dist.all_gather_into_tensor(gathered, rec_t)
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    pipe.ctx.profile_read()
+    pipe.ctx.profile_enable(0x7f)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    prof = pipe.ctx.profile_read()
+    pipe.ctx.profile_enable(0)
+
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local}")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    out = pipe.ctx.pairs_download(points=False)
+    rec = out["records"]
+    if rank == 0:
+        n_pts = float(np.mean(out["counts"]))
+        n_cand = float(np.mean(rec[:, 14]))
+        ab = algorithmic_bytes(cfg, n_pts, n_cand)
+        stages = {}
+        for s in ofk.STAGES:
+            ms, nl = prof[s]
+            per_step = ms / max(1, nl)
+            stages[s] = {"ms_per_step": round(per_step, 4), "algorithmic_GBps": round(ab[s] * B / (per_step * 1e-3) / 1e9, 2) if per_step > 0 else None}
+        dom = max(ofk.STAGES, key=lambda s: prof[s][0])
+        dom_ms = prof[dom][0] / max(1, prof[dom][1])
+        achieved = ab[dom] * B / (dom_ms * 1e-3) / 1e9
+        line = {
+            "metric": "frame-pairs/sec @1920x1080 (LK+velocity)",
+            "value": round(world * B * args.steps / dt, 2),
+            "unit": "frame-pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8/i32 image stages, f32 LK solve, f64 velocity solve",
+            "data": "synthetic",
+            "config": {"workload": "1920x1080 frame pairs, 500 Shi-Tomasi corners, 3-level LK pyramid (BASELINE configs[1])",
+                       "pairs_per_gpu_per_step": B, "corners_mean": round(n_pts, 1), "candidates_mean": round(n_cand, 1), "win": cfg.win, "max_level": cfg.max_level,
+                       "sharding": f"{world} x independent pair batches, all_gather of [B,8] f32 records"},
+            "roofline": {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": int(ab[dom] * B), "avg_ms": round(dom_ms, 4)},
+            "stages": stages,
+            "velocity_sample": [round(float(x), 6) for x in rec[0, :3]],
+            "velocity_truth": list(truth["v"]),
+        }
+        if world == 1 and args.cpu_sample > 0:
+            sample = min(args.cpu_sample, B)
+            cps, v_cpu = cpu_baseline(prev, nxt, sensors, cfg, sample)
+            line["cpu_baseline"] = {"value": round(cps, 3), "unit": "frame-pairs/s", "cores": 1, "kind": "port",
+                                    "sample": f"{sample} of the same 1080p pairs through oracle/ (C image stages + numpy lstsq), 1 thread, "
+                                              f"host has {os.cpu_count()} cores",
+                                    "velocity_max_rel_diff_vs_gpu": float(np.max(np.abs(v_cpu - rec[sample - 1, :3]) / np.abs(v_cpu)))}
+        print(json.dumps(line), flush=True)
+    pipe.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

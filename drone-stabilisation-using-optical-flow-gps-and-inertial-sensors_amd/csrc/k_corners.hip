@@ -40,6 +40,7 @@ __global__ __launch_bounds__(256) void k_mineig(const uint8_t *__restrict__ gray
     int *s_hxx = reinterpret_cast<int *>(s_d + PH * PW);
     int *s_hxy = s_hxx + PH * ME_TW;
     int *s_hyy = s_hxy + PH * ME_TW;
+    float *s_max = reinterpret_cast<float *>(s_hyy + PH * ME_TW);
 
     const int b = blockIdx.z;
     const uint8_t *img = gray + (size_t)b * gray_stride;
@@ -118,7 +119,6 @@ __global__ __launch_bounds__(256) void k_mineig(const uint8_t *__restrict__ gray
     if (maxbits) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
-        __shared__ float s_max[4];
         if ((tid & 63) == 0) s_max[tid >> 6] = lmax;
         __syncthreads();
         if (tid == 0) {
@@ -132,14 +132,17 @@ int ofk_launch_mineig(hipStream_t s, const uint8_t *gray, size_t gray_stride, in
                       size_t eig_stride, unsigned int *maxbits, const uint8_t *mask, size_t mask_stride, int batch)
 {
     const int PW = ME_TW + block - 1, PH = ME_TH + block - 1, GW = PW + 2, GH = PH + 2, GWp = (GW + 3) & ~3;
-    const size_t lds = ((size_t)(GH * GWp + 15) & ~(size_t)15) + (size_t)PH * PW * 4 + (size_t)3 * PH * ME_TW * 4;
+    const size_t lds = ((size_t)(GH * GWp + 15) & ~(size_t)15) + (size_t)PH * PW * 4 + (size_t)3 * PH * ME_TW * 4 + 16;
     if (lds > 160 * 1024) return -1;
     const double scale = 1.0 / (4.0 * block * 255.0);
     const float kd = (float)(0.5 * scale * scale), ko = (float)(scale * scale);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_mineig), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+    static size_t attr_lds = 64 * 1024;                       // dynamic LDS above 64 KiB has to be opted into
+    if (lds > attr_lds) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_mineig), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            (void)hipGetLastError();
+            return -1;
+        }
+        attr_lds = lds;
     }
     dim3 grid((w + ME_TW - 1) / ME_TW, (h + ME_TH - 1) / ME_TH, batch);
     hipLaunchKernelGGL(k_mineig, grid, dim3(256), lds, s, gray, gray_stride, h, w, block, kd, ko, eig, eig_stride, maxbits,

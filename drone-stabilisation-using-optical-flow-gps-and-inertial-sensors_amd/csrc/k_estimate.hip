@@ -218,7 +218,8 @@ __device__ __forceinline__ void rtilde_point(double x, double y, double ux, doub
 __global__ __launch_bounds__(256) void k_pairs_solve(const float *__restrict__ prev_pts, const float *__restrict__ next_pts,
                                                      const uint8_t *__restrict__ status, const int *__restrict__ counts,
                                                      int pts_stride, const double *__restrict__ sensors, int variant,
-                                                     int use_feas, double feas_T, double *__restrict__ records)
+                                                     int use_feas, double feas_T, const int *__restrict__ cand_count,
+                                                     double *__restrict__ records)
 {
     __shared__ double s_red[4];
     __shared__ double s_v[8];
@@ -278,16 +279,16 @@ __global__ __launch_bounds__(256) void k_pairs_solve(const float *__restrict__ p
         const double e2 = v[2] - (om[0] * off[1] - om[1] * off[0]);
         o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = r; o[4] = s_v[3]; o[5] = s_v[4]; o[6] = s_v[5]; o[7] = s_v[6];
         o[8] = R[0] * e0 + R[1] * e1 + R[2] * e2; o[9] = R[3] * e0 + R[4] * e1 + R[5] * e2; o[10] = R[6] * e0 + R[7] * e1 + R[8] * e2;
-        o[11] = a.cnt; o[12] = (double)n; o[13] = tracked; o[14] = 0.0; o[15] = 0.0;
+        o[11] = a.cnt; o[12] = (double)n; o[13] = tracked; o[14] = cand_count ? (double)cand_count[b] : 0.0; o[15] = 0.0;
     }
 }
 
 void ofk_launch_pairs_solve(hipStream_t s, const float *prev_pts, const float *next_pts, const uint8_t *status,
                             const int *counts, int pts_stride, const double *sensors, int variant, int use_feas,
-                            double feas_T, double *records, int batch)
+                            double feas_T, const int *cand_count, double *records, int batch)
 {
     hipLaunchKernelGGL(k_pairs_solve, dim3(batch), dim3(256), 0, s, prev_pts, next_pts, status, counts, pts_stride, sensors,
-                       variant, use_feas, feas_T, records);
+                       variant, use_feas, feas_T, cand_count, records);
 }
 
 __global__ void k_records_f32(const double *__restrict__ rec, float *__restrict__ dst, int batch)

@@ -583,7 +583,7 @@ extern "C" int ofk_pairs_run(ofk_ctx *c, const ofk_params *p)
     {
         StageTimer t(c, OFK_STAGE_SOLVE);
         ofk_launch_pairs_solve(c->stream, c->pts_prev, c->pts_next, c->status, c->counts, c->max_pts, c->sensors, p->solve_variant,
-                               p->use_feasibility, p->feas_T, c->records, B);
+                               p->use_feasibility, p->feas_T, c->cand_count, c->records, B);
     }
     return check_launch(c, "ofk_pairs_run");
 }

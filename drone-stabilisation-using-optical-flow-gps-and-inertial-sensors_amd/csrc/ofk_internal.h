@@ -80,7 +80,7 @@ void ofk_launch_lk(hipStream_t s, const uint8_t *prev, const uint8_t *next, size
                    double min_eig_thr, float *next_pts, uint8_t *status, float *err, int batch);
 void ofk_launch_pairs_solve(hipStream_t s, const float *prev_pts, const float *next_pts, const uint8_t *status,
                             const int *counts, int pts_stride, const double *sensors, int variant, int use_feas,
-                            double feas_T, double *records, int batch);
+                            double feas_T, const int *cand_count, double *records, int batch);
 void ofk_launch_records_f32(hipStream_t s, const double *records, float *dst, int batch);
 
 void ofk_launch_flow_model(hipStream_t s, const double *x, int batch, int n, const double *v, const double *omega,

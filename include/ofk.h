@@ -165,7 +165,7 @@ typedef struct ofk_params {
 #define OFK_SENSOR_DOUBLES 28
 /* Per-pair result record, [batch][OFK_RECORD_DOUBLES] doubles:
  * 0-2 v_obs  3 residual SS  4 rank  5-7 singular values  8-10 v_uav (node:258)  11 points used in the solve
- * 12 corners detected  13 points tracked (status==1)  14-15 reserved */
+ * 12 corners detected  13 points tracked (status==1)  14 corner candidates (after threshold + NMS)  15 reserved */
 #define OFK_RECORD_DOUBLES 16
 
 /* Copies a batch of BGR frame pairs into the context's device buffers (host -> HBM). */
