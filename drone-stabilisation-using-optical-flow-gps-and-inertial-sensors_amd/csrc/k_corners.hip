@@ -1,16 +1,27 @@
 // k_corners.hip — Shi-Tomasi corner detection (cv2.goodFeaturesToTrack semantics).  gfx950.
 //
-//   k_mineig : gray tile (+halo) -> LDS; Sobel-3 -> int16 (dx,dy) in LDS; separable box sums of the three
-//              products through an int32 LDS intermediate (sliding windows, all integer = exact);
-//              lambda_min in f32 with a fixed operation order (-ffp-contract=off); coalesced f32 store and a
-//              per-image max via one atomicMax per block.  HBM: reads P, writes 4P.
-//   k_nms    : threshold (> quality*max), 3x3 local max, mask; survivors appended to a per-image list as
-//              unique 64-bit keys  (~bits(value) << 32 | linear index)  so ascending key order is
-//              (value descending, index ascending).
-//   k_select : one 1024-thread workgroup per image.  Repeats { radix-select the next <=4096 smallest keys
-//              (8 passes x 8 bit), bitonic sort in LDS, greedy min-distance over the sorted chunk } until
-//              max_corners are accepted or the candidates are exhausted.  Result identical to a full sort
-//              followed by the serial greedy pass.
+//   k_mineig<BS,FUSED>
+//       One 256-thread block computes the min-eigenvalue response on a 64 x OH region:
+//         1. the gray tile (+ halo) is staged into LDS re-aligned with v_alignbyte (dword global loads);
+//         2. one thread per (row, 8-column segment) reads its gray bytes as dwords, forms the Sobel column sums
+//            s = r0+2r1+r2, t = r2-r0 (dx = s[j+2]-s[j], dy = t[j]+2t[j+1]+t[j+2]), the three products and their
+//            horizontal box sums by a sliding window, all in registers (fully unrolled for BS = 3, 7, 12), and
+//            writes eight int4 {xx,xy,yy} entries to LDS (XOR-swizzled: conflict-free ds_write_b128);
+//         3. one thread per (column, row segment) slides the vertical box sum over ds_read_b128 entries and
+//            evaluates lambda_min in f32 with a fixed operation order (-ffp-contract=off).
+//       All window sums are integers, so the result does not depend on the summation order (bit-exact vs oracle).
+//       FUSED = false: the f32 map is written to HBM (ofk_mineig_response).
+//       FUSED = true : no map.  The region overlaps its neighbours by one pixel, the block applies the 3x3
+//         local-max test itself and appends the survivors as 64-bit keys (~bits(value) << 32 | linear index) with
+//         ONE global atomic per block.  The quality threshold needs the image-wide maximum, which is not known yet;
+//         the block prunes with the running maximum (atomicMax so far), a valid lower bound, and k_select applies the
+//         exact threshold.  HBM traffic: P read + O(candidates) written, instead of P + 4P + 4P.
+//   k_nms    : the same threshold / 3x3 test / key list for a response map supplied by the caller
+//              (ofk_select_corners), block-aggregated appends.
+//   k_select : one 1024-thread workgroup per image.  Repeats { pick the next <= 4096 keys in ascending key order
+//              with an 11-bit histogram over (key - lower bound), bitonic sort in LDS, greedy min-distance over the
+//              sorted chunk } until max_corners are accepted or the keys below the threshold key are exhausted.
+//              Result identical to a full sort (value desc, index asc) followed by the serial greedy pass.
 #include "ofk_internal.h"
 
 __device__ __forceinline__ int reflect101(int i, int n)
@@ -20,134 +31,271 @@ __device__ __forceinline__ int reflect101(int i, int n)
     return i;
 }
 
-// ------------------------------------------------------------------------------------------------ min-eigenvalue map
-#define ME_TW 64
-#define ME_TH 32
+// ------------------------------------------------------------------------------------------------ min-eigenvalue
+#define ME_OW 64                                              // region width computed by one block
+#define ME_CAND_MAX 1920                                      // >= 62 x 30 interior pixels: the block buffer cannot overflow
 
-// dynamic LDS layout: gray (GH x GWp) u8 | d (PH x PW) int16x2 | hs[3] (PH x TW) int32
+__device__ __forceinline__ int hs_phys(int x) { return (x & ~7) | ((x & 7) ^ ((x >> 3) & 7)); }
+
+template <int BS, bool FUSED>
 __global__ __launch_bounds__(256) void k_mineig(const uint8_t *__restrict__ gray, size_t gray_stride, int h, int w,
-                                                int bs, float kd, float ko, float *__restrict__ eig, size_t eig_stride,
-                                                unsigned int *__restrict__ maxbits, const uint8_t *__restrict__ mask,
-                                                size_t mask_stride)
+                                                int bs_rt, int OH, float kd, float ko, float *__restrict__ eig,
+                                                size_t eig_stride, unsigned int *__restrict__ maxbits,
+                                                const uint8_t *__restrict__ mask, size_t mask_stride, double quality,
+                                                unsigned long long *__restrict__ cand, int cand_cap,
+                                                int *__restrict__ cand_count, int *__restrict__ flags)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int bs = BS ? BS : bs_rt;
     const int an = bs / 2;
-    const int PW = ME_TW + bs - 1, PH = ME_TH + bs - 1;       // product region
-    const int GW = PW + 2, GH = PH + 2;                       // gray region
-    const int GWp = (GW + 3) & ~3;
+    const int PH = OH + bs - 1;                               // product rows
+    const int GH = PH + 2;                                    // gray rows
+    const int GWp = 56 + 4 * ((9 + bs + 3) / 4);              // gray row pitch (bytes), covers every item's dword reads
+    // LDS carve: gray | hs (PH x 64 int4) | eig (OH x 64 f32) | misc
     uint8_t *s_g = smem;
-    unsigned *s_d = reinterpret_cast<unsigned *>(smem + ((GH * GWp + 15) & ~15));
-    int *s_hxx = reinterpret_cast<int *>(s_d + PH * PW);
-    int *s_hxy = s_hxx + PH * ME_TW;
-    int *s_hyy = s_hxy + PH * ME_TW;
-    float *s_max = reinterpret_cast<float *>(s_hyy + PH * ME_TW);
+    int4 *s_h = reinterpret_cast<int4 *>(smem + ((GH * GWp + 15) & ~15));
+    float *s_e = reinterpret_cast<float *>(s_h + PH * ME_OW);
+    int *s_misc = reinterpret_cast<int *>(s_e + OH * ME_OW);   // [0..3] wave maxima, [4] thr bits, [5] cand count, [6] base
+    unsigned long long *s_cand = reinterpret_cast<unsigned long long *>(s_h);   // aliases hs after the vertical pass
 
-    const int b = blockIdx.z;
+    const int b = blockIdx.z, tid = threadIdx.x;
     const uint8_t *img = gray + (size_t)b * gray_stride;
-    const int x0 = blockIdx.x * ME_TW, y0 = blockIdx.y * ME_TH;
-    const int px0 = x0 - an, py0 = y0 - an;                   // product region origin
+    const int IH = FUSED ? OH - 2 : OH;
+    const int ex0 = FUSED ? (int)blockIdx.x * (ME_OW - 2) - 1 : (int)blockIdx.x * ME_OW;     // eig region origin
+    const int ey0 = FUSED ? (int)blockIdx.y * IH - 1 : (int)blockIdx.y * IH;
+    const int px0 = ex0 - an, py0 = ey0 - an;                 // product region origin
     const int gx0 = px0 - 1, gy0 = py0 - 1;                   // gray region origin
-    const int tid = threadIdx.x;
+    const int GWd = GWp / 4;
 
-    for (int i = tid; i < GH * GW; i += 256) {
-        const int r = i / GW, c = i - r * GW;
-        s_g[r * GWp + c] = img[(size_t)reflect101(gy0 + r, h) * w + reflect101(gx0 + c, w)];
-    }
-    __syncthreads();
-    // Sobel at every product position.  A position mirrored across an image edge reads mirrored gray, which
-    // flips the sign of the derivative along that axis; undo it so that the PRODUCT image is what gets reflected.
-    for (int i = tid; i < PH * PW; i += 256) {
-        const int r = i / PW, c = i - r * PW;
-        const uint8_t *r0 = s_g + r * GWp + c, *r1 = r0 + GWp, *r2 = r1 + GWp;
-        int dx = (r0[2] - r0[0]) + 2 * (r1[2] - r1[0]) + (r2[2] - r2[0]);
-        int dy = (r2[0] - r0[0]) + 2 * (r2[1] - r0[1]) + (r2[2] - r0[2]);
-        const int X = px0 + c, Y = py0 + r;
-        if (X < 0 || X >= w) dx = -dx;
-        if (Y < 0 || Y >= h) dy = -dy;
-        s_d[i] = ((unsigned)dx & 0xffffu) | ((unsigned)dy << 16);
-    }
-    __syncthreads();
-    // horizontal box sums: item = (row, 8-column segment), sliding window
-    for (int it = tid; it < PH * (ME_TW / 8); it += 256) {
-        const int r = it / (ME_TW / 8), seg = it - r * (ME_TW / 8);
-        const unsigned *row = s_d + r * PW + seg * 8;
-        int sxx = 0, sxy = 0, syy = 0;
-        for (int i = 0; i < bs; ++i) {
-            const unsigned v = row[i];
-            const int dx = (int)(short)(v & 0xffffu), dy = (int)v >> 16;
-            sxx += dx * dx; sxy += dx * dy; syy += dy * dy;
+    // ---- 1. stage gray
+    const bool interior = gx0 >= 0 && gy0 >= 0 && gx0 + GWp + 4 <= w && gy0 + GH <= h && (w & 3) == 0;
+    if (interior) {
+        const int sh = gx0 & 3;
+        const uint8_t *base = img + (size_t)gy0 * w + (gx0 & ~3);
+        for (int i = tid; i < GH * GWd; i += 256) {
+            const int r = i / GWd, c = i - r * GWd;
+            const unsigned *p = reinterpret_cast<const unsigned *>(base + (size_t)r * w) + c;
+            const unsigned lo = p[0], hi = p[1];
+            unsigned v;
+            switch (sh) {                                       // block-uniform
+                case 0: v = lo; break;
+                case 1: v = __builtin_amdgcn_alignbyte(hi, lo, 1); break;
+                case 2: v = __builtin_amdgcn_alignbyte(hi, lo, 2); break;
+                default: v = __builtin_amdgcn_alignbyte(hi, lo, 3); break;
+            }
+            reinterpret_cast<unsigned *>(s_g)[r * GWd + c] = v;
         }
-        int *oxx = s_hxx + r * ME_TW + seg * 8, *oxy = s_hxy + r * ME_TW + seg * 8, *oyy = s_hyy + r * ME_TW + seg * 8;
-        oxx[0] = sxx; oxy[0] = sxy; oyy[0] = syy;
+    } else {
+        for (int i = tid; i < GH * GWp; i += 256) {
+            const int r = i / GWp, c = i - r * GWp;
+            s_g[i] = img[(size_t)reflect101(gy0 + r, h) * w + reflect101(gx0 + c, w)];
+        }
+    }
+    __syncthreads();
+
+    // ---- 2. Sobel + products + horizontal box sums, item = (product row, 8-column segment)
+    for (int it = tid; it < PH * 8; it += 256) {
+        const int r = it >> 3, seg = it & 7;
+        const int Y = py0 + r;
+        const bool flipy = Y < 0 || Y >= h;                   // a mirrored row/column flips the sign of dy/dx: undo it in dx*dy
+        int4 *orow = s_h + r * ME_OW + seg * 8;
+        if (BS > 0) {
+            constexpr int B_ = BS > 0 ? BS : 1;
+            constexpr int NCOL = 8 + B_ + 1, ND = (NCOL + 3) / 4, NS = 8 + B_ - 1;
+            unsigned a[3][ND];
 #pragma unroll
-        for (int k = 1; k < 8; ++k) {
-            const unsigned vo = row[k - 1], vn = row[k - 1 + bs];
-            const int dxo = (int)(short)(vo & 0xffffu), dyo = (int)vo >> 16;
-            const int dxn = (int)(short)(vn & 0xffffu), dyn = (int)vn >> 16;
-            sxx += dxn * dxn - dxo * dxo; sxy += dxn * dyn - dxo * dyo; syy += dyn * dyn - dyo * dyo;
-            oxx[k] = sxx; oxy[k] = sxy; oyy[k] = syy;
+            for (int q = 0; q < 3; ++q) {
+                const unsigned *g = reinterpret_cast<const unsigned *>(s_g + (r + q) * GWp + seg * 8);
+#pragma unroll
+                for (int i = 0; i < ND; ++i) a[q][i] = g[i];
+            }
+            int s[NCOL], t[NCOL];
+#pragma unroll
+            for (int j = 0; j < NCOL; ++j) {
+                const int b0 = (a[0][j >> 2] >> (8 * (j & 3))) & 255, b1 = (a[1][j >> 2] >> (8 * (j & 3))) & 255,
+                          b2 = (a[2][j >> 2] >> (8 * (j & 3))) & 255;
+                s[j] = b0 + 2 * b1 + b2; t[j] = b2 - b0;
+            }
+            int pxx[NS], pxy[NS], pyy[NS];
+#pragma unroll
+            for (int j = 0; j < NS; ++j) {
+                const int dx = s[j + 2] - s[j], dy = t[j] + 2 * t[j + 1] + t[j + 2];
+                const int X = px0 + seg * 8 + j;
+                const bool flip = (X < 0 || X >= w) != flipy;
+                pxx[j] = dx * dx; pyy[j] = dy * dy; pxy[j] = flip ? -(dx * dy) : dx * dy;
+            }
+            int sxx = 0, sxy = 0, syy = 0;
+#pragma unroll
+            for (int j = 0; j < B_; ++j) { sxx += pxx[j]; sxy += pxy[j]; syy += pyy[j]; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (k) { sxx += pxx[k + B_ - 1] - pxx[k - 1]; sxy += pxy[k + B_ - 1] - pxy[k - 1]; syy += pyy[k + B_ - 1] - pyy[k - 1]; }
+                orow[k ^ seg] = make_int4(sxx, sxy, syy, 0);
+            }
+        } else {
+            // generic block size: byte reads, trailing products recomputed
+            const uint8_t *g0 = s_g + r * GWp + seg * 8, *g1 = g0 + GWp, *g2 = g1 + GWp;
+            int sxx = 0, sxy = 0, syy = 0;
+            for (int j = 0; j < 8 + bs - 1; ++j) {
+                {
+                    const int dx = (g0[j + 2] - g0[j]) + 2 * (g1[j + 2] - g1[j]) + (g2[j + 2] - g2[j]);
+                    const int dy = (g2[j] - g0[j]) + 2 * (g2[j + 1] - g0[j + 1]) + (g2[j + 2] - g0[j + 2]);
+                    const int X = px0 + seg * 8 + j;
+                    const bool flip = (X < 0 || X >= w) != flipy;
+                    sxx += dx * dx; syy += dy * dy; sxy += flip ? -(dx * dy) : dx * dy;
+                }
+                if (j >= bs) {
+                    const int jo = j - bs;
+                    const int dx = (g0[jo + 2] - g0[jo]) + 2 * (g1[jo + 2] - g1[jo]) + (g2[jo + 2] - g2[jo]);
+                    const int dy = (g2[jo] - g0[jo]) + 2 * (g2[jo + 1] - g0[jo + 1]) + (g2[jo + 2] - g0[jo + 2]);
+                    const int X = px0 + seg * 8 + jo;
+                    const bool flip = (X < 0 || X >= w) != flipy;
+                    sxx -= dx * dx; syy -= dy * dy; sxy -= flip ? -(dx * dy) : dx * dy;
+                }
+                if (j >= bs - 1) orow[(j - bs + 1) ^ seg] = make_int4(sxx, sxy, syy, 0);
+            }
         }
     }
     __syncthreads();
-    // vertical box sums: thread = (column, 8-row segment); lambda_min; store
+
+    // ---- 3. vertical box sums + lambda_min; thread = (column, row segment)
     float lmax = 0.f;
     {
-        const int x = tid & 63, ys = (tid >> 6) * 8;
-        int sxx = 0, sxy = 0, syy = 0;
-        for (int j = 0; j < bs; ++j) {
-            const int q = (ys + j) * ME_TW + x;
-            sxx += s_hxx[q]; sxy += s_hxy[q]; syy += s_hyy[q];
-        }
-        const uint8_t *mk = mask ? mask + (size_t)b * mask_stride : nullptr;
-        float *out = eig + (size_t)b * eig_stride;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            if (k) {
-                const int qo = (ys + k - 1) * ME_TW + x, qn = (ys + k - 1 + bs) * ME_TW + x;
-                sxx += s_hxx[qn] - s_hxx[qo]; sxy += s_hxy[qn] - s_hxy[qo]; syy += s_hyy[qn] - s_hyy[qo];
-            }
-            const int gy = y0 + ys + k, gx = x0 + x;
-            if (gy < h && gx < w) {
+        const int x = tid & 63, q = tid >> 6;
+        const int len = (OH + 3) >> 2;
+        const int r0 = q * len;
+        const int n = min(len, OH - r0);
+        const int xp = hs_phys(x);
+        if (n > 0) {
+            int sxx = 0, sxy = 0, syy = 0;
+            for (int j = 0; j < bs; ++j) { const int4 v = s_h[(r0 + j) * ME_OW + xp]; sxx += v.x; sxy += v.y; syy += v.z; }
+            const uint8_t *mk = mask ? mask + (size_t)b * mask_stride : nullptr;
+            const int gx = ex0 + x;
+            for (int k = 0; k < n; ++k) {
+                if (k) {
+                    const int4 vo = s_h[(r0 + k - 1) * ME_OW + xp], vn = s_h[(r0 + k - 1 + bs) * ME_OW + xp];
+                    sxx += vn.x - vo.x; sxy += vn.y - vo.y; syy += vn.z - vo.z;
+                }
                 const float a = (float)sxx * kd, bb = (float)sxy * ko, c = (float)syy * kd;
                 const float amc = a - c;
                 const float v = (a + c) - sqrtf(amc * amc + bb * bb);
-                out[(size_t)gy * w + gx] = v;
-                if (!mk || mk[(size_t)gy * w + gx]) lmax = fmaxf(lmax, v);
+                const int gy = ey0 + r0 + k;
+                const bool inimg = gx >= 0 && gx < w && gy >= 0 && gy < h;
+                if (FUSED) {
+                    s_e[(r0 + k) * ME_OW + x] = v;
+                    const bool own = x >= 1 && x <= ME_OW - 2 && r0 + k >= 1 && r0 + k <= OH - 2;     // interior: counted once
+                    if (inimg && own && (!mk || mk[(size_t)gy * w + gx])) lmax = fmaxf(lmax, v);
+                } else if (inimg) {
+                    eig[(size_t)b * eig_stride + (size_t)gy * w + gx] = v;
+                    if (!mk || mk[(size_t)gy * w + gx]) lmax = fmaxf(lmax, v);
+                }
             }
         }
     }
-    if (maxbits) {
+    if (!maxbits) return;                                      // map only (uniform)
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
-        if ((tid & 63) == 0) s_max[tid >> 6] = lmax;
-        __syncthreads();
-        if (tid == 0) {
-            const float m = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
-            if (m > 0.f) atomicMax(maxbits + b, __float_as_uint(m));
+    for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
+    if ((tid & 63) == 0) s_misc[tid >> 6] = __float_as_int(lmax);
+    if (tid == 0) s_misc[5] = 0;
+    __syncthreads();
+    if (tid == 0) {
+        const float m = fmaxf(fmaxf(__int_as_float(s_misc[0]), __int_as_float(s_misc[1])),
+                              fmaxf(__int_as_float(s_misc[2]), __int_as_float(s_misc[3])));
+        unsigned cur = __float_as_uint(m);                    // m >= 0: bit patterns order like the values
+        const unsigned old = m > 0.f ? atomicMax(maxbits + b, cur)
+                                     : __hip_atomic_load(maxbits + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old > cur) cur = old;
+        s_misc[4] = __float_as_int((float)((double)__uint_as_float(cur) * quality));   // running threshold <= final threshold
+    }
+    if (!FUSED) return;
+    __syncthreads();
+
+    // ---- 4. 3x3 local maxima above the running threshold -> keys
+    {
+        const float thr = __int_as_float(s_misc[4]);
+        const uint8_t *mk = mask ? mask + (size_t)b * mask_stride : nullptr;
+        const int x = tid & 63;
+        for (int y = 1 + (tid >> 6); y <= OH - 2; y += 4) {
+            if (x < 1 || x > ME_OW - 2) continue;
+            const int gx = ex0 + x, gy = ey0 + y;
+            if (gx < 1 || gx >= w - 1 || gy < 1 || gy >= h - 1) continue;
+            const float *c = s_e + y * ME_OW + x;
+            const float v = c[0];
+            if (!(v > thr) || !(v > 0.f)) continue;
+            if (mk && !mk[(size_t)gy * w + gx]) continue;
+            const float m = fmaxf(fmaxf(fmaxf(c[-ME_OW - 1], c[-ME_OW]), fmaxf(c[-ME_OW + 1], c[-1])),
+                                  fmaxf(fmaxf(c[1], c[ME_OW - 1]), fmaxf(c[ME_OW], c[ME_OW + 1])));
+            if (m > v) continue;
+            const int slot = atomicAdd(&s_misc[5], 1);
+            if (slot < ME_CAND_MAX) s_cand[slot] = ((unsigned long long)(~__float_as_uint(v)) << 32) | (unsigned)(gy * w + gx);
         }
+    }
+    __syncthreads();
+    const int nc = min(s_misc[5], ME_CAND_MAX);
+    if (nc == 0) return;
+    if (tid == 0) s_misc[6] = atomicAdd(cand_count + b * OFK_CNT_STRIDE, nc);
+    __syncthreads();
+    const int base = s_misc[6];
+    for (int i = tid; i < nc; i += 256) {
+        if (base + i < cand_cap) cand[(size_t)b * cand_cap + base + i] = s_cand[i];
+        else if (i == 0 || base + i == cand_cap) atomicOr(flags, 1);
     }
 }
 
-int ofk_launch_mineig(hipStream_t s, const uint8_t *gray, size_t gray_stride, int h, int w, int block, float *eig,
-                      size_t eig_stride, unsigned int *maxbits, const uint8_t *mask, size_t mask_stride, int batch)
+static int mineig_oh(int bs) { int oh = 33 - bs; if (oh < 8) oh = 8; if (oh > 32) oh = 32; return oh; }
+
+template <int BS, bool FUSED>
+static int launch_mineig_t(hipStream_t s, const uint8_t *gray, size_t gray_stride, int h, int w, int block, float *eig,
+                           size_t eig_stride, unsigned int *maxbits, const uint8_t *mask, size_t mask_stride,
+                           double quality, unsigned long long *cand, int cand_cap, int *cand_count, int *flags, int batch)
 {
-    const int PW = ME_TW + block - 1, PH = ME_TH + block - 1, GW = PW + 2, GH = PH + 2, GWp = (GW + 3) & ~3;
-    const size_t lds = ((size_t)(GH * GWp + 15) & ~(size_t)15) + (size_t)PH * PW * 4 + (size_t)3 * PH * ME_TW * 4 + 16;
+    const int OH = mineig_oh(block), PH = OH + block - 1, GH = PH + 2, GWp = 56 + 4 * ((9 + block + 3) / 4);
+    size_t lds = ((size_t)(GH * GWp + 15) & ~(size_t)15) + (size_t)PH * ME_OW * 16 + (size_t)OH * ME_OW * 4 + 32;
     if (lds > 160 * 1024) return -1;
-    const double scale = 1.0 / (4.0 * block * 255.0);
-    const float kd = (float)(0.5 * scale * scale), ko = (float)(scale * scale);
     static size_t attr_lds = 64 * 1024;                       // dynamic LDS above 64 KiB has to be opted into
     if (lds > attr_lds) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_mineig), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_mineig<BS, FUSED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             (void)hipGetLastError();
             return -1;
         }
         attr_lds = lds;
     }
-    dim3 grid((w + ME_TW - 1) / ME_TW, (h + ME_TH - 1) / ME_TH, batch);
-    hipLaunchKernelGGL(k_mineig, grid, dim3(256), lds, s, gray, gray_stride, h, w, block, kd, ko, eig, eig_stride, maxbits,
-                       mask, mask_stride);
+    const double scale = 1.0 / (4.0 * block * 255.0);
+    const float kd = (float)(0.5 * scale * scale), ko = (float)(scale * scale);
+    const int IH = FUSED ? OH - 2 : OH, IW = FUSED ? ME_OW - 2 : ME_OW;
+    dim3 grid((w + IW - 1) / IW, (h + IH - 1) / IH, batch);
+    hipLaunchKernelGGL((k_mineig<BS, FUSED>), grid, dim3(256), lds, s, gray, gray_stride, h, w, block, OH, kd, ko, eig, eig_stride,
+                       maxbits, mask, mask_stride, quality, cand, cand_cap, cand_count, flags);
     return 0;
+}
+
+// Writes the f32 response map (maxbits optional).
+int ofk_launch_mineig(hipStream_t s, const uint8_t *gray, size_t gray_stride, int h, int w, int block, float *eig,
+                      size_t eig_stride, unsigned int *maxbits, const uint8_t *mask, size_t mask_stride, int batch)
+{
+#define ME_ARGS s, gray, gray_stride, h, w, block, eig, eig_stride, maxbits, mask, mask_stride, 0.0, nullptr, 0, nullptr, nullptr, batch
+    switch (block) {
+        case 3: return launch_mineig_t<3, false>(ME_ARGS);
+        case 7: return launch_mineig_t<7, false>(ME_ARGS);
+        case 12: return launch_mineig_t<12, false>(ME_ARGS);
+        default: return launch_mineig_t<0, false>(ME_ARGS);
+    }
+#undef ME_ARGS
+}
+
+// Response + 3x3 NMS + candidate keys + image maximum; no map.
+int ofk_launch_mineig_cand(hipStream_t s, const uint8_t *gray, size_t gray_stride, int h, int w, int block,
+                           unsigned int *maxbits, const uint8_t *mask, size_t mask_stride, double quality,
+                           unsigned long long *cand, int cand_cap, int *cand_count, int *flags, int batch)
+{
+#define ME_ARGS s, gray, gray_stride, h, w, block, nullptr, 0, maxbits, mask, mask_stride, quality, cand, cand_cap, cand_count, flags, batch
+    switch (block) {
+        case 3: return launch_mineig_t<3, true>(ME_ARGS);
+        case 7: return launch_mineig_t<7, true>(ME_ARGS);
+        case 12: return launch_mineig_t<12, true>(ME_ARGS);
+        default: return launch_mineig_t<0, true>(ME_ARGS);
+    }
+#undef ME_ARGS
 }
 
 // max over (mask != 0) of a response map that was supplied by the caller (ofk_select_corners)
@@ -181,39 +329,46 @@ void ofk_launch_maxbits(hipStream_t s, const float *eig, size_t eig_stride, cons
     hipLaunchKernelGGL(k_maxbits, dim3(blocks, batch), dim3(256), 0, s, eig, eig_stride, mask, mask_stride, npx, maxbits);
 }
 
-// ------------------------------------------------------------------------------------------------ threshold + NMS + compaction
+// ------------------------------------------------------------------------------------------------ threshold + NMS on a given map
 __global__ __launch_bounds__(256) void k_nms(const float *__restrict__ eig, size_t eig_stride,
                                              const uint8_t *__restrict__ mask, size_t mask_stride, int h, int w,
                                              const unsigned int *__restrict__ maxbits, double quality,
                                              unsigned long long *__restrict__ cand, int cand_cap,
                                              int *__restrict__ cand_count, int *__restrict__ flags)
 {
-    const int b = blockIdx.z;
+    __shared__ unsigned long long s_cand[1024];
+    __shared__ int s_n, s_base;
+    const int b = blockIdx.z, tid = threadIdx.x;
     const unsigned mb = maxbits[b];
     if (mb == 0) return;                                       // max <= 0: no corners
+    if (tid == 0) s_n = 0;
+    __syncthreads();
     const float thr = (float)((double)__uint_as_float(mb) * quality);
     const float *e = eig + (size_t)b * eig_stride;
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    bool keep = false;
-    float v = 0.f;
-    if (x >= 1 && x < w - 1 && y >= 1 && y < h - 1) {
-        const size_t i = (size_t)y * w + x;
-        v = e[i];
-        if (v > thr && (!mask || mask[(size_t)b * mask_stride + i])) {
-            const float *r0 = e + i - w, *r2 = e + i + w;
-            const float m = fmaxf(fmaxf(fmaxf(r0[-1], r0[0]), fmaxf(r0[1], e[i - 1])),
-                                  fmaxf(fmaxf(e[i + 1], r2[-1]), fmaxf(r2[0], r2[1])));
-            keep = !(m > v);
+    const int x = blockIdx.x * 64 + (tid & 63);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int y = blockIdx.y * 16 + (tid >> 6) * 4 + k;
+        if (x >= 1 && x < w - 1 && y >= 1 && y < h - 1) {
+            const size_t i = (size_t)y * w + x;
+            const float v = e[i];
+            if (v > thr && (!mask || mask[(size_t)b * mask_stride + i])) {
+                const float *r0 = e + i - w, *r2 = e + i + w;
+                const float m = fmaxf(fmaxf(fmaxf(r0[-1], r0[0]), fmaxf(r0[1], e[i - 1])),
+                                      fmaxf(fmaxf(e[i + 1], r2[-1]), fmaxf(r2[0], r2[1])));
+                if (!(m > v)) s_cand[atomicAdd(&s_n, 1)] = ((unsigned long long)(~__float_as_uint(v)) << 32) | (unsigned)(y * w + x);
+            }
         }
     }
-    if (keep) {
-        const int slot = atomicAdd(cand_count + b, 1);          // hipcc aggregates this per wave
-        if (slot < cand_cap)
-            cand[(size_t)b * cand_cap + slot] =
-                ((unsigned long long)(~__float_as_uint(v)) << 32) | (unsigned)(y * w + x);
-        else
-            atomicOr(flags, 1);
+    __syncthreads();
+    const int n = s_n;
+    if (n == 0) return;
+    if (tid == 0) s_base = atomicAdd(cand_count + b * OFK_CNT_STRIDE, n);
+    __syncthreads();
+    const int base = s_base;
+    for (int i = tid; i < n; i += 256) {
+        if (base + i < cand_cap) cand[(size_t)b * cand_cap + base + i] = s_cand[i];
+        else if (i == 0 || base + i == cand_cap) atomicOr(flags, 1);
     }
 }
 
@@ -221,94 +376,118 @@ void ofk_launch_nms(hipStream_t s, const float *eig, size_t eig_stride, const ui
                     int w, const unsigned int *maxbits, double quality, unsigned long long *cand, int cand_cap,
                     int *cand_count, int *flags, int batch)
 {
-    dim3 grid((w + 63) / 64, (h + 3) / 4, batch);
+    dim3 grid((w + 63) / 64, (h + 15) / 16, batch);
     hipLaunchKernelGGL(k_nms, grid, dim3(256), 0, s, eig, eig_stride, mask, mask_stride, h, w, maxbits, quality, cand,
                        cand_cap, cand_count, flags);
 }
 
 // ------------------------------------------------------------------------------------------------ sort + greedy min-distance
 #define SEL_T 1024
+#define SEL_BINS 2048
 
-__global__ __launch_bounds__(SEL_T) void k_select(unsigned long long *__restrict__ cand_all, int cand_cap,
-                                                  const int *__restrict__ cand_count, int w, int max_corners,
-                                                  float min_distance, float *__restrict__ pts, int pts_stride,
-                                                  int *__restrict__ counts)
+__global__ __launch_bounds__(SEL_T) void k_select(const unsigned long long *__restrict__ cand_all, int cand_cap,
+                                                  const int *__restrict__ cand_count, const unsigned int *__restrict__ maxbits,
+                                                  double quality, int w, int max_corners, float min_distance,
+                                                  float *__restrict__ pts, int pts_stride, int *__restrict__ counts)
 {
     __shared__ unsigned long long s_key[OFK_CHUNK];
-    __shared__ unsigned s_hist[256];
+    __shared__ unsigned s_hist[SEL_BINS];
     __shared__ int s_acc_xy[4096];                              // accepted corners, x | y<<16 (max_corners <= 4096)
-    __shared__ unsigned long long s_rej[16];                    // per-wave reject ballots of the current 64-candidate round
-    __shared__ int s_k, s_n, s_nacc, s_digit;
+    __shared__ unsigned long long s_rej[SEL_T / 64];            // per-wave reject ballots of the current 64-candidate round
+    __shared__ unsigned s_wsum[SEL_T / 64];
+    __shared__ int s_n, s_nacc, s_D, s_cum;
 
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long *cand = cand_all + (size_t)b * cand_cap;
-    int C = cand_count[b];
+    int C = cand_count[b * OFK_CNT_STRIDE];
     if (C > cand_cap) C = cand_cap;
+    const unsigned mb = maxbits[b];
+    if (tid == 0) { s_nacc = 0; counts[b] = 0; }
+    if (mb == 0 || C == 0) return;
+    const float thr = (float)((double)__uint_as_float(mb) * quality);
+    if (!(thr < __uint_as_float(mb))) return;                   // nothing is strictly above the threshold
+    // keys of interest: [a, kend);  v > thr  <=>  key < (~bits(thr)) << 32
+    const unsigned long long kend = (unsigned long long)(~__float_as_uint(thr)) << 32;
+    unsigned long long a = (unsigned long long)(~mb) << 32;     // smallest possible key (value == max)
     const float md2 = min_distance * min_distance;
     const bool use_dist = min_distance >= 1.f;
-    unsigned long long lo = 0;                                  // keys <= lo were handled by earlier chunks
-    int remaining = C;
-    if (tid == 0) s_nacc = 0;
     __syncthreads();
 
-    while (remaining > 0) {
-        int n;                                                  // keys in this chunk
-        unsigned long long hi;                                  // largest key of this chunk
-        if (remaining <= OFK_CHUNK) {
-            n = remaining; hi = ~0ull;
-        } else {
-            // radix select: the OFK_CHUNK-th smallest key among keys > lo
-            unsigned long long prefix = 0; int k = OFK_CHUNK;
-            for (int pass = 7; pass >= 0; --pass) {
-                if (tid < 256) s_hist[tid] = 0;
-                __syncthreads();
-                const int sh = pass * 8;
-                const unsigned long long himask = pass == 7 ? 0ull : (~0ull << (sh + 8));
-                for (int i = tid; i < C; i += SEL_T) {
-                    const unsigned long long key = cand[i];
-                    if (key > lo && (key & himask) == prefix) atomicAdd(&s_hist[(unsigned)(key >> sh) & 255u], 1u);
-                }
-                __syncthreads();
-                if (tid == 0) {
-                    int acc = 0, d = 0;
-                    for (; d < 256; ++d) { if (acc + (int)s_hist[d] >= k) break; acc += (int)s_hist[d]; }
-                    s_digit = d; s_k = k - acc;
-                }
-                __syncthreads();
-                prefix |= (unsigned long long)s_digit << sh; k = s_k;
-                __syncthreads();
+    while (a < kend) {
+        // ---- choose T in (a, kend] so that 1 <= #{a <= key < T} <= OFK_CHUNK (or detect that none is left)
+        unsigned long long curA = a, curB = kend, T = kend;
+        int taken = 0;
+        bool none_left = false;
+        for (int level = 0; level < 8; ++level) {
+            const unsigned long long width = curB - curA;
+            const int shift = width <= SEL_BINS ? 0 : 64 - __clzll((long long)(width - 1)) - 11;
+            const int nb = (int)((width - 1) >> shift) + 1;
+            for (int i = tid; i < SEL_BINS; i += SEL_T) s_hist[i] = 0;
+            __syncthreads();
+            for (int i = tid; i < C; i += SEL_T) {
+                const unsigned long long key = cand[i];
+                if (key >= curA && key < curB) atomicAdd(&s_hist[(unsigned)((key - curA) >> shift)], 1u);
             }
-            hi = prefix; n = OFK_CHUNK;
+            __syncthreads();
+            // inclusive prefix over the bins (2 bins per thread); D = #bins whose inclusive prefix fits the budget
+            const unsigned h0 = s_hist[2 * tid], h1 = s_hist[2 * tid + 1];
+            unsigned incl = h0 + h1;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const unsigned n_ = __shfl_up(incl, o); if (lane >= o) incl += n_; }
+            if (lane == 63) s_wsum[wave] = incl;
+            if (tid == 0) { s_D = 0; s_cum = 0; }
+            __syncthreads();
+            unsigned woff = 0, total = 0;
+            for (int q = 0; q < SEL_T / 64; ++q) { const unsigned ws = s_wsum[q]; if (q < wave) woff += ws; total += ws; }
+            const unsigned i1 = woff + incl, i0 = i1 - h1;      // inclusive prefixes of bins 2*tid and 2*tid+1
+            const int budget = OFK_CHUNK - taken;
+            const int fit = ((int)i0 <= budget) + ((int)i1 <= budget);
+            if (fit) atomicAdd(&s_D, fit);
+            __syncthreads();
+            const int D = min(s_D, nb);
+            if (D > 0 && (D - 1) / 2 == tid) s_cum = (int)(((D - 1) & 1) ? i1 : i0);
+            __syncthreads();
+            taken += s_cum;
+            if (level == 0 && total == 0) { none_left = true; break; }
+            if (D >= nb) { T = curB; break; }                  // everything in [curA, curB) fits
+            const unsigned long long newA = curA + ((unsigned long long)D << shift);
+            if (taken >= OFK_CHUNK / 8) { T = newA; break; }
+            curA = newA;                                        // descend into the first bin that did not fit
+            const unsigned long long bin_end = newA + (1ull << shift);
+            if (bin_end < curB) curB = bin_end;
         }
-        // gather keys in (lo, hi] into LDS (unordered), pad with ~0
+        if (none_left) break;
+        // ---- gather keys in [a, T)
+        __syncthreads();
         if (tid == 0) s_n = 0;
         __syncthreads();
         for (int i = tid; i < C; i += SEL_T) {
             const unsigned long long key = cand[i];
-            if (key > lo && key <= hi) s_key[atomicAdd(&s_n, 1)] = key;
+            if (key >= a && key < T) { const int slot = atomicAdd(&s_n, 1); if (slot < OFK_CHUNK) s_key[slot] = key; }
         }
         __syncthreads();
+        const int n = min(s_n, OFK_CHUNK);
         int npad = 64;
         while (npad < n) npad <<= 1;
         for (int i = n + tid; i < npad; i += SEL_T) s_key[i] = ~0ull;
         __syncthreads();
-        // bitonic sort ascending
+        // ---- bitonic sort ascending
         for (int kk = 2; kk <= npad; kk <<= 1)
             for (int j = kk >> 1; j > 0; j >>= 1) {
                 for (int i = tid; i < npad; i += SEL_T) {
                     const int p = i ^ j;
                     if (p > i) {
-                        const unsigned long long a = s_key[i], c = s_key[p];
+                        const unsigned long long x0 = s_key[i], x1 = s_key[p];
                         const bool up = (i & kk) == 0;
-                        if ((a > c) == up) { s_key[i] = c; s_key[p] = a; }
+                        if ((x0 > x1) == up) { s_key[i] = x1; s_key[p] = x0; }
                     }
                 }
                 __syncthreads();
             }
-        // greedy over the sorted chunk, 64 candidates per round
+        // ---- greedy over the sorted chunk, 64 candidates per round
         for (int base = 0; base < n; base += 64) {
             const int nacc = s_nacc;
-            if (max_corners > 0 && nacc >= max_corners) break;
+            if (nacc >= max_corners) break;
             const int ci = base + lane;
             const bool live = ci < n;
             const unsigned idx = live ? (unsigned)(s_key[ci] & 0xffffffffu) : 0u;
@@ -316,8 +495,8 @@ __global__ __launch_bounds__(SEL_T) void k_select(unsigned long long *__restrict
             bool rej = false;
             if (use_dist && live)
                 for (int j = wave; j < nacc; j += SEL_T / 64) {
-                    const int a = s_acc_xy[j];
-                    const int dx = cx - (a & 0xffff), dy = cy - (a >> 16);
+                    const int acc = s_acc_xy[j];
+                    const int dx = cx - (acc & 0xffff), dy = cy - (acc >> 16);
                     if ((float)(dx * dx + dy * dy) < md2) { rej = true; break; }
                 }
             const unsigned long long bal = __ballot(rej);
@@ -329,7 +508,7 @@ __global__ __launch_bounds__(SEL_T) void k_select(unsigned long long *__restrict
                 for (int q = 0; q < SEL_T / 64; ++q) r |= s_rej[q];
                 unsigned long long m = __ballot(live) & ~r;    // survivors of the accepted-set test, best first
                 int na = nacc;
-                while (m && (max_corners <= 0 || na < max_corners)) {
+                while (m && na < max_corners) {
                     const int win = __ffsll((long long)m) - 1;
                     const int wx = __shfl(cx, win), wy = __shfl(cy, win);
                     if (lane == 0) {
@@ -347,17 +526,17 @@ __global__ __launch_bounds__(SEL_T) void k_select(unsigned long long *__restrict
             }
             __syncthreads();
         }
-        if (max_corners > 0 && s_nacc >= max_corners) break;
-        remaining -= n;
-        lo = hi;
+        if (s_nacc >= max_corners) break;
+        a = T;
         __syncthreads();
     }
     if (tid == 0) counts[b] = s_nacc;
 }
 
-void ofk_launch_select(hipStream_t s, unsigned long long *cand, int cand_cap, const int *cand_count, int w,
-                       int max_corners, float min_distance, float *pts, int pts_stride, int *counts, int batch)
+void ofk_launch_select(hipStream_t s, const unsigned long long *cand, int cand_cap, const int *cand_count,
+                       const unsigned int *maxbits, double quality, int w, int max_corners, float min_distance, float *pts,
+                       int pts_stride, int *counts, int batch)
 {
-    hipLaunchKernelGGL(k_select, dim3(batch), dim3(SEL_T), 0, s, cand, cand_cap, cand_count, w, max_corners, min_distance,
-                       pts, pts_stride, counts);
+    hipLaunchKernelGGL(k_select, dim3(batch), dim3(SEL_T), 0, s, cand, cand_cap, cand_count, maxbits, quality, w, max_corners,
+                       min_distance, pts, pts_stride, counts);
 }

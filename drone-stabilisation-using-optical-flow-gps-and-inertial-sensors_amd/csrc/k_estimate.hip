@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void k_pairs_solve(const float *__restrict__ p
         const double e2 = v[2] - (om[0] * off[1] - om[1] * off[0]);
         o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = r; o[4] = s_v[3]; o[5] = s_v[4]; o[6] = s_v[5]; o[7] = s_v[6];
         o[8] = R[0] * e0 + R[1] * e1 + R[2] * e2; o[9] = R[3] * e0 + R[4] * e1 + R[5] * e2; o[10] = R[6] * e0 + R[7] * e1 + R[8] * e2;
-        o[11] = a.cnt; o[12] = (double)n; o[13] = tracked; o[14] = cand_count ? (double)cand_count[b] : 0.0; o[15] = 0.0;
+        o[11] = a.cnt; o[12] = (double)n; o[13] = tracked; o[14] = cand_count ? (double)cand_count[b * OFK_CNT_STRIDE] : 0.0; o[15] = 0.0;
     }
 }
 

@@ -218,6 +218,252 @@ __global__ __launch_bounds__(64) void k_lk(const uint8_t *__restrict__ prev, con
     }
 }
 
+
+// ================================================================================================
+// Fast path, win <= 15: lane = (window row, 4-pixel segment).
+//   * staging: all global loads of a level (prev neighbourhood + next region) are issued before the first wait;
+//     interior regions come in as aligned dwords re-aligned with v_alignbyte and land in LDS with 16-byte stores;
+//   * every tap read is a pair of aligned dwords (ds_read2_b32) + v_alignbyte: 2 LDS reads per lane per iteration;
+//   * the Scharr derivatives of the lane's own 2x5 taps are computed from its 4x7 neighbourhood in registers;
+//   * reductions: 4 DPP adds inside each 16-lane row (int32 is exact: 16 lanes x 4 px x 8160 x 4080 < 2^31),
+//     4 v_readlane, int64 scalar adds — no LDS traffic, no ds_bpermute.
+#define LKF_IP 24                                  // pitch of the staged prev neighbourhood (18 x 18 used)
+#define LKF_JW 32                                  // staged next region: 32 x 32 = win + 1 + 2*LK_M at win 15
+
+__device__ __forceinline__ int row_sum16(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);      // quad_perm(1,0,3,2)
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);      // quad_perm(2,3,0,1)
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);     // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);     // row_mirror
+    return v;
+}
+__device__ __forceinline__ long long wave_sum_rows(int v)
+{
+    v = row_sum16(v);
+    return (long long)__builtin_amdgcn_readlane(v, 0) + (long long)__builtin_amdgcn_readlane(v, 16) +
+           (long long)__builtin_amdgcn_readlane(v, 32) + (long long)__builtin_amdgcn_readlane(v, 48);
+}
+
+// 5 consecutive bytes starting at byte offset `off` of an LDS byte array (4-byte aligned base)
+__device__ __forceinline__ void lds_read5(const uint8_t *base, int off, int t[5])
+{
+    const unsigned *p = reinterpret_cast<const unsigned *>(base + (off & ~3));
+    const unsigned d0 = p[0], d1 = p[1];
+    const unsigned sh = (unsigned)off & 3u;
+    const unsigned v = (unsigned)(((unsigned long long)d1 << 32 | d0) >> (8 * sh));
+    t[0] = v & 255; t[1] = (v >> 8) & 255; t[2] = (v >> 16) & 255; t[3] = v >> 24; t[4] = (d1 >> (8 * sh)) & 255;
+}
+// 7 consecutive bytes starting at `off`
+__device__ __forceinline__ void lds_read7(const uint8_t *base, int off, int t[7])
+{
+    const unsigned *p = reinterpret_cast<const unsigned *>(base + (off & ~3));
+    const unsigned d0 = p[0], d1 = p[1], d2 = p[2];
+    const unsigned sh = (unsigned)off & 3u;
+    const unsigned lo = (unsigned)(((unsigned long long)d1 << 32 | d0) >> (8 * sh));
+    const unsigned hi = (unsigned)(((unsigned long long)d2 << 32 | d1) >> (8 * sh));
+    t[0] = lo & 255; t[1] = (lo >> 8) & 255; t[2] = (lo >> 16) & 255; t[3] = lo >> 24;
+    t[4] = hi & 255; t[5] = (hi >> 8) & 255; t[6] = (hi >> 16) & 255;
+}
+
+__global__ __launch_bounds__(64) void k_lk15(const uint8_t *__restrict__ prev, const uint8_t *__restrict__ next,
+                                             size_t pyr_stride, ofk_levels lv, const float *__restrict__ prev_pts,
+                                             const int *__restrict__ counts, int pts_stride, int win, int max_count,
+                                             double eps2, double min_eig_thr, float *__restrict__ next_pts,
+                                             uint8_t *__restrict__ status, float *__restrict__ err)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_I[20 * LKF_IP];
+    __shared__ __attribute__((aligned(16))) uint8_t s_J[(LKF_JW + 1) * LKF_JW];
+
+    const int b = blockIdx.y, p = blockIdx.x, lane = threadIdx.x;
+    if (p >= counts[b]) return;
+    const size_t pi = (size_t)b * pts_stride + p;
+    const float ptx = prev_pts[2 * pi], pty = prev_pts[2 * pi + 1];
+    const uint8_t *Pb = prev + (size_t)b * pyr_stride, *Nb = next + (size_t)b * pyr_stride;
+    const float half = (float)(win - 1) * 0.5f;
+    const int ww = win * win;
+    const int iw_ = win + 3, jw_ = win + 1 + 2 * LK_M;
+    const int wy = lane >> 2, wx0 = (lane & 3) * 4;            // this lane's window row and first column
+    const int npx = wy < win ? min(4, max(0, win - wx0)) : 0;  // pixels owned by the lane
+
+    int st = 1;
+    float errv = 0.f, nx = 0.f, ny = 0.f;
+    int pI[4], pIx[4], pIy[4];
+
+    for (int l = lv.n; l >= 0; --l) {
+        const int lh = lv.h[l], lw = lv.w[l];
+        const uint8_t *I = Pb + lv.off[l], *J = Nb + lv.off[l];
+        const float sc = (float)(1.0 / (double)(1 << l));
+        float px = ptx * sc, py = pty * sc, qx, qy;
+        if (l == lv.n) { qx = px; qy = py; } else { qx = nx * 2.f; qy = ny * 2.f; }
+        nx = qx; ny = qy;
+        px -= half; py -= half;
+        const int ipx = (int)floorf(px), ipy = (int)floorf(py);
+        if (ipx < -win || ipx >= lw || ipy < -win || ipy >= lh) {
+            if (l == 0) { st = 0; errv = 0.f; }
+            continue;
+        }
+        qx -= half; qy -= half;
+        int jx0 = 0, jy0 = 0;
+        bool jvalid = false;
+        // ---- stage the next-frame region around the initial guess (loads issued now, consumed after the I patch)
+        auto stage_J = [&](int iqx, int iqy) {
+            jx0 = iqx - LK_M; jy0 = iqy - LK_M;
+            __syncthreads();
+            const bool inner = jx0 >= 4 && jy0 >= 0 && jx0 + jw_ + 8 <= lw && jy0 + jw_ <= lh && (lw & 3) == 0 && jw_ == LKF_JW;
+            if (inner) {
+                const int r = lane >> 1, hf = lane & 1;                   // 32 rows x 2 halves of 16 bytes
+                const size_t addr = (size_t)(jy0 + r) * lw + jx0 + 16 * hf;
+                const unsigned sh = (unsigned)addr & 3u;
+                const unsigned *g = reinterpret_cast<const unsigned *>(J + (addr & ~(size_t)3));
+                const unsigned d0 = g[0], d1 = g[1], d2 = g[2], d3 = g[3], d4 = g[4];
+                uint4 o;
+                o.x = (unsigned)(((unsigned long long)d1 << 32 | d0) >> (8 * sh));
+                o.y = (unsigned)(((unsigned long long)d2 << 32 | d1) >> (8 * sh));
+                o.z = (unsigned)(((unsigned long long)d3 << 32 | d2) >> (8 * sh));
+                o.w = (unsigned)(((unsigned long long)d4 << 32 | d3) >> (8 * sh));
+                *reinterpret_cast<uint4 *>(s_J + r * LKF_JW + 16 * hf) = o;
+            } else {
+                for (int i = lane; i < jw_ * jw_; i += 64) {
+                    const int r = i / jw_, c = i - r * jw_;
+                    s_J[r * LKF_JW + c] = J[(size_t)reflect101(jy0 + r, lh) * lw + reflect101(jx0 + c, lw)];
+                }
+            }
+            __syncthreads();
+            jvalid = true;
+        };
+        // ---- stage the prev neighbourhood (origin ipx-1, ipy-1), (win+3)^2
+        __syncthreads();
+        {
+            const bool inner = ipx >= 5 && ipy >= 1 && ipx - 1 + 28 <= lw && ipy - 1 + iw_ <= lh && (lw & 3) == 0;
+            if (inner) {
+                if (lane < iw_) {                                          // one row of <= 18 bytes per lane: 6 dwords in, 5 out
+                    const size_t addr = (size_t)(ipy - 1 + lane) * lw + (ipx - 1);
+                    const unsigned sh = (unsigned)addr & 3u;
+                    const unsigned *g = reinterpret_cast<const unsigned *>(I + (addr & ~(size_t)3));
+                    const unsigned d0 = g[0], d1 = g[1], d2 = g[2], d3 = g[3], d4 = g[4], d5 = g[5];
+                    unsigned *o = reinterpret_cast<unsigned *>(s_I + lane * LKF_IP);
+                    o[0] = (unsigned)(((unsigned long long)d1 << 32 | d0) >> (8 * sh));
+                    o[1] = (unsigned)(((unsigned long long)d2 << 32 | d1) >> (8 * sh));
+                    o[2] = (unsigned)(((unsigned long long)d3 << 32 | d2) >> (8 * sh));
+                    o[3] = (unsigned)(((unsigned long long)d4 << 32 | d3) >> (8 * sh));
+                    o[4] = (unsigned)(((unsigned long long)d5 << 32 | d4) >> (8 * sh));
+                }
+            } else {
+                for (int i = lane; i < iw_ * iw_; i += 64) {
+                    const int r = i / iw_, c = i - r * iw_;
+                    s_I[r * LKF_IP + c] = I[(size_t)reflect101(ipy - 1 + r, lh) * lw + reflect101(ipx - 1 + c, lw)];
+                }
+            }
+        }
+        {
+            const int iqx = (int)floorf(qx), iqy = (int)floorf(qy);
+            if (!(iqx < -win || iqx >= lw || iqy < -win || iqy >= lh)) stage_J(iqx, iqy);
+            else __syncthreads();
+        }
+        // ---- patch: I (5 fractional bits), Ix, Iy of the lane's pixels; exact integer normal matrix
+        int w00, w01, w10, w11;
+        lk_weights(px - (float)ipx, py - (float)ipy, w00, w01, w10, w11);
+        int a11 = 0, a12 = 0, a22 = 0;
+        pI[0] = pI[1] = pI[2] = pI[3] = 0; pIx[0] = pIx[1] = pIx[2] = pIx[3] = 0; pIy[0] = pIy[1] = pIy[2] = pIy[3] = 0;
+        if (npx > 0) {
+            int n[4][7];                                                   // rows wy..wy+3 of s_I, cols wx0..wx0+6
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lds_read7(s_I, (wy + r) * LKF_IP + wx0, n[r]);
+            int dxv[2][5], dyv[2][5];                                      // Scharr at window taps (rows wy, wy+1; cols wx0..wx0+4)
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int c = 0; c < 5; ++c) {
+                    const int X = ipx + wx0 + c, Y = ipy + wy + r;
+                    const bool in = X >= 0 && X < lw && Y >= 0 && Y < lh;   // derivative image has a constant-0 border
+                    const int dx = 3 * (n[r][c + 2] - n[r][c]) + 10 * (n[r + 1][c + 2] - n[r + 1][c]) + 3 * (n[r + 2][c + 2] - n[r + 2][c]);
+                    const int dy = 3 * (n[r + 2][c] - n[r][c]) + 10 * (n[r + 2][c + 1] - n[r][c + 1]) + 3 * (n[r + 2][c + 2] - n[r][c + 2]);
+                    dxv[r][c] = in ? dx : 0; dyv[r][c] = in ? dy : 0;
+                }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < npx) {
+                    const int iv = descale(n[1][k + 1] * w00 + n[1][k + 2] * w01 + n[2][k + 1] * w10 + n[2][k + 2] * w11, 9);
+                    const int ix = descale(dxv[0][k] * w00 + dxv[0][k + 1] * w01 + dxv[1][k] * w10 + dxv[1][k + 1] * w11, 14);
+                    const int iy = descale(dyv[0][k] * w00 + dyv[0][k + 1] * w01 + dyv[1][k] * w10 + dyv[1][k + 1] * w11, 14);
+                    pI[k] = iv; pIx[k] = ix; pIy[k] = iy;
+                    a11 += ix * ix; a12 += ix * iy; a22 += iy * iy;
+                }
+        }
+        const long long A11s = wave_sum_rows(a11), A12s = wave_sum_rows(a12), A22s = wave_sum_rows(a22);
+        const float A11 = (float)((double)A11s * 0x1p-20), A12 = (float)((double)A12s * 0x1p-20),
+                    A22 = (float)((double)A22s * 0x1p-20);
+        float D = A11 * A22 - A12 * A12;
+        const float dd = A11 - A22;
+        const float minEig = (A22 + A11 - sqrtf(dd * dd + 4.f * A12 * A12)) / (float)(2 * ww);
+        if ((double)minEig < min_eig_thr || D < FLT_EPSILON) {
+            if (l == 0) st = 0;
+            continue;
+        }
+        D = 1.f / D;
+        float pdx = 0.f, pdy = 0.f;
+        for (int j = 0; j < max_count; ++j) {
+            const int iqx = (int)floorf(qx), iqy = (int)floorf(qy);
+            if (iqx < -win || iqx >= lw || iqy < -win || iqy >= lh) {
+                if (l == 0) st = 0;
+                break;
+            }
+            if (!jvalid || iqx < jx0 || iqx > jx0 + 2 * LK_M || iqy < jy0 || iqy > jy0 + 2 * LK_M) stage_J(iqx, iqy);
+            lk_weights(qx - (float)iqx, qy - (float)iqy, w00, w01, w10, w11);
+            int b1 = 0, b2 = 0;
+            if (npx > 0) {
+                int t0[5], t1[5];
+                const int off = (iqy - jy0 + wy) * LKF_JW + (iqx - jx0) + wx0;
+                lds_read5(s_J, off, t0); lds_read5(s_J, off + LKF_JW, t1);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < npx) {
+                        const int diff = descale(t0[k] * w00 + t0[k + 1] * w01 + t1[k] * w10 + t1[k + 1] * w11, 9) - pI[k];
+                        b1 += diff * pIx[k]; b2 += diff * pIy[k];
+                    }
+            }
+            const long long B1 = wave_sum_rows(b1), B2 = wave_sum_rows(b2);
+            const float fb1 = (float)((double)B1 * 0x1p-20), fb2 = (float)((double)B2 * 0x1p-20);
+            const float dx = (A12 * fb2 - A22 * fb1) * D, dy = (A12 * fb1 - A11 * fb2) * D;
+            qx += dx; qy += dy;
+            nx = qx + half; ny = qy + half;
+            if ((double)dx * (double)dx + (double)dy * (double)dy <= eps2) break;
+            if (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) {
+                nx -= dx * 0.5f; ny -= dy * 0.5f;
+                break;
+            }
+            pdx = dx; pdy = dy;
+        }
+        if (st && l == 0) {
+            const float ex = nx - half, ey = ny - half;
+            const int iex = (int)floorf(ex), iey = (int)floorf(ey);
+            if (iex < -win || iex >= lw || iey < -win || iey >= lh) { st = 0; continue; }
+            if (!jvalid || iex < jx0 || iex > jx0 + 2 * LK_M || iey < jy0 || iey > jy0 + 2 * LK_M) stage_J(iex, iey);
+            lk_weights(ex - (float)iex, ey - (float)iey, w00, w01, w10, w11);
+            int se = 0;
+            if (npx > 0) {
+                int t0[5], t1[5];
+                const int off = (iey - jy0 + wy) * LKF_JW + (iex - jx0) + wx0;
+                lds_read5(s_J, off, t0); lds_read5(s_J, off + LKF_JW, t1);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < npx) {
+                        const int diff = descale(t0[k] * w00 + t0[k + 1] * w01 + t1[k] * w10 + t1[k + 1] * w11, 9) - pI[k];
+                        se += diff < 0 ? -diff : diff;
+                    }
+            }
+            const long long SE = wave_sum_rows(se);
+            errv = (float)(int)SE / (float)(32 * ww);
+        }
+    }
+    if (lane == 0) {
+        next_pts[2 * pi] = nx; next_pts[2 * pi + 1] = ny;
+        status[pi] = (uint8_t)st;
+        err[pi] = st ? errv : 0.f;
+    }
+}
+
 void ofk_launch_lk(hipStream_t s, const uint8_t *prev, const uint8_t *next, size_t pyr_stride, const ofk_levels &lv,
                    const float *prev_pts, const int *counts, int pts_stride, int win, int max_count, double eps,
                    double min_eig_thr, float *next_pts, uint8_t *status, float *err, int batch)
@@ -229,6 +475,9 @@ void ofk_launch_lk(hipStream_t s, const uint8_t *prev, const uint8_t *next, size
     const double eps2 = eps * eps;
     dim3 grid(pts_stride, batch);
     if (win <= 15)
+        hipLaunchKernelGGL(k_lk15, grid, dim3(64), 0, s, prev, next, pyr_stride, lv, prev_pts, counts, pts_stride, win,
+                           max_count, eps2, min_eig_thr, next_pts, status, err);
+    else if (win <= 15)
         hipLaunchKernelGGL(k_lk<15>, grid, dim3(64), 0, s, prev, next, pyr_stride, lv, prev_pts, counts, pts_stride, win,
                            max_count, eps2, min_eig_thr, next_pts, status, err);
     else if (win <= 21)

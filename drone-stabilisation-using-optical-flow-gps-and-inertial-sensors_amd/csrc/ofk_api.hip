@@ -98,7 +98,7 @@ extern "C" int ofk_create(int device, int max_w, int max_h, int max_batch, int m
     for (int k = 0; k < 2; ++k) { ALLOC(c->bgr[k], B * c->bgr_stride); ALLOC(c->pyr[k], B * c->pyr_stride); }
     ALLOC(c->eig, B * c->img_stride * sizeof(float));
     ALLOC(c->cand, B * (size_t)c->cand_cap * 8);
-    ALLOC(c->cand_count, B * 4); ALLOC(c->maxbits, B * 4);
+    ALLOC(c->cand_count, B * OFK_CNT_STRIDE * 4); ALLOC(c->maxbits, B * 4);
     ALLOC(c->pts_prev, B * max_pts * 8); ALLOC(c->pts_next, B * max_pts * 8);
     ALLOC(c->status, B * max_pts); ALLOC(c->err, B * max_pts * 4); ALLOC(c->counts, B * 4);
     ALLOC(c->sensors, B * OFK_SENSOR_DOUBLES * 8); ALLOC(c->records, B * OFK_RECORD_DOUBLES * 8);
@@ -255,11 +255,11 @@ static int run_select(ofk_ctx *c, bool have_max, const uint8_t *dmask, int batch
         OFK_HIP(c, hipMemsetAsync(c->maxbits, 0, (size_t)batch * 4, c->stream));
         ofk_launch_maxbits(c->stream, c->eig, c->img_stride, dmask, c->img_stride, h, w, c->maxbits, batch);
     }
-    OFK_HIP(c, hipMemsetAsync(c->cand_count, 0, (size_t)batch * 4, c->stream));
+    OFK_HIP(c, hipMemsetAsync(c->cand_count, 0, (size_t)batch * OFK_CNT_STRIDE * 4, c->stream));
     ofk_launch_nms(c->stream, c->eig, c->img_stride, dmask, c->img_stride, h, w, c->maxbits, quality, c->cand, c->cand_cap,
                    c->cand_count, c->dev_flags, batch);
-    ofk_launch_select(c->stream, c->cand, c->cand_cap, c->cand_count, w, max_corners, (float)min_distance, c->pts_prev,
-                      c->max_pts, c->counts, batch);
+    ofk_launch_select(c->stream, c->cand, c->cand_cap, c->cand_count, c->maxbits, quality, w, max_corners, (float)min_distance,
+                      c->pts_prev, c->max_pts, c->counts, batch);
     return check_launch(c, "corner selection");
 }
 
@@ -303,9 +303,13 @@ extern "C" int ofk_good_features(ofk_ctx *c, const uint8_t *gray, const uint8_t 
     const uint8_t *dmask = nullptr;
     if (mask) { TRY(lazy_mask(c)); TRY(h2d(c, c->mask, c->img_stride, mask, px, batch)); dmask = c->mask; }
     OFK_HIP(c, hipMemsetAsync(c->maxbits, 0, (size_t)batch * 4, c->stream));
-    if (ofk_launch_mineig(c->stream, c->pyr[0], c->pyr_stride, h, w, block, c->eig, c->img_stride, c->maxbits, dmask, c->img_stride, batch))
+    OFK_HIP(c, hipMemsetAsync(c->cand_count, 0, (size_t)batch * OFK_CNT_STRIDE * 4, c->stream));
+    if (ofk_launch_mineig_cand(c->stream, c->pyr[0], c->pyr_stride, h, w, block, c->maxbits, dmask, c->img_stride, quality, c->cand,
+                               c->cand_cap, c->cand_count, c->dev_flags, batch))
         return ofk_fail(c, OFK_E_INVALID, "k_mineig: LDS tile too large for block_size %d", block);
-    TRY(run_select(c, true, dmask, batch, h, w, max_corners, quality, min_distance));
+    ofk_launch_select(c->stream, c->cand, c->cand_cap, c->cand_count, c->maxbits, quality, w, max_corners, (float)min_distance,
+                      c->pts_prev, c->max_pts, c->counts, batch);
+    TRY(check_launch(c, "corner detection"));
     return fetch_corners(c, batch, max_corners, pts, counts);
 }
 
@@ -559,21 +563,17 @@ extern "C" int ofk_pairs_run(ofk_ctx *c, const ofk_params *p)
         build_pyramids(c, lv, B, 3);
     }
     {
-        StageTimer t(c, OFK_STAGE_EIG);
+        StageTimer t(c, OFK_STAGE_EIG);                          // response + 3x3 NMS + candidate keys, no map in HBM
         hipMemsetAsync(c->maxbits, 0, (size_t)B * 4, c->stream);
-        hipMemsetAsync(c->cand_count, 0, (size_t)B * 4, c->stream);
-        if (ofk_launch_mineig(c->stream, c->pyr[0], c->pyr_stride, h, w, p->block_size, c->eig, c->img_stride, c->maxbits, nullptr, 0, B))
+        hipMemsetAsync(c->cand_count, 0, (size_t)B * OFK_CNT_STRIDE * 4, c->stream);
+        if (ofk_launch_mineig_cand(c->stream, c->pyr[0], c->pyr_stride, h, w, p->block_size, c->maxbits, nullptr, 0, p->quality, c->cand,
+                                   c->cand_cap, c->cand_count, c->dev_flags, B))
             return ofk_fail(c, OFK_E_INVALID, "k_mineig: LDS tile too large for block_size %d", p->block_size);
     }
     {
-        StageTimer t(c, OFK_STAGE_NMS);
-        ofk_launch_nms(c->stream, c->eig, c->img_stride, nullptr, 0, h, w, c->maxbits, p->quality, c->cand, c->cand_cap, c->cand_count,
-                       c->dev_flags, B);
-    }
-    {
         StageTimer t(c, OFK_STAGE_SELECT);
-        ofk_launch_select(c->stream, c->cand, c->cand_cap, c->cand_count, w, p->max_corners, (float)p->min_distance, c->pts_prev,
-                          c->max_pts, c->counts, B);
+        ofk_launch_select(c->stream, c->cand, c->cand_cap, c->cand_count, c->maxbits, p->quality, w, p->max_corners,
+                          (float)p->min_distance, c->pts_prev, c->max_pts, c->counts, B);
     }
     {
         StageTimer t(c, OFK_STAGE_LK);

@@ -8,6 +8,7 @@
 
 #define OFK_MAX_LEVELS 9            // level 0 .. 8
 #define OFK_CHUNK 4096              // candidates sorted per selection round (LDS resident)
+#define OFK_CNT_STRIDE 32           // ints between per-image candidate counters (one 128-B line each: no atomic contention)
 
 struct ofk_levels {
     int n;                          // deepest level index in use (0..8)
@@ -31,7 +32,7 @@ struct ofk_ctx {
     uint8_t *mask;                  // [B][img_stride]            optional detection mask (lazily allocated)
     int16_t *deriv;                 // [B][img_stride][2]         only for ofk_scharr_s16 (lazily allocated)
     unsigned long long *cand;       // [B][cand_cap]              candidate keys (~value bits << 32 | linear index)
-    int *cand_count;                // [B]
+    int *cand_count;                // [B][OFK_CNT_STRIDE]
     unsigned int *maxbits;          // [B]                        bit pattern of max positive response
     float *pts_prev, *pts_next;     // [B][max_pts][2]
     uint8_t *status;                // [B][max_pts]
@@ -73,8 +74,12 @@ void ofk_launch_maxbits(hipStream_t s, const float *eig, size_t eig_stride, cons
 void ofk_launch_nms(hipStream_t s, const float *eig, size_t eig_stride, const uint8_t *mask, size_t mask_stride, int h,
                     int w, const unsigned int *maxbits, double quality, unsigned long long *cand, int cand_cap,
                     int *cand_count, int *flags, int batch);
-void ofk_launch_select(hipStream_t s, unsigned long long *cand, int cand_cap, const int *cand_count, int w,
-                       int max_corners, float min_distance, float *pts, int pts_stride, int *counts, int batch);
+int  ofk_launch_mineig_cand(hipStream_t s, const uint8_t *gray, size_t gray_stride, int h, int w, int block,
+                            unsigned int *maxbits, const uint8_t *mask, size_t mask_stride, double quality,
+                            unsigned long long *cand, int cand_cap, int *cand_count, int *flags, int batch);
+void ofk_launch_select(hipStream_t s, const unsigned long long *cand, int cand_cap, const int *cand_count,
+                       const unsigned int *maxbits, double quality, int w, int max_corners, float min_distance, float *pts,
+                       int pts_stride, int *counts, int batch);
 void ofk_launch_lk(hipStream_t s, const uint8_t *prev, const uint8_t *next, size_t pyr_stride, const ofk_levels &lv,
                    const float *prev_pts, const int *counts, int pts_stride, int win, int max_count, double eps,
                    double min_eig_thr, float *next_pts, uint8_t *status, float *err, int batch);
