@@ -82,7 +82,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="frame pairs per GPU per step")
+    ap.add_argument("--batch", type=int, default=128, help="frame pairs per GPU per step")
     ap.add_argument("--cpu-sample", type=int, default=24, help="pairs timed on the CPU oracle (0 = skip)")
     args = ap.parse_args()
 
@@ -102,7 +102,7 @@ def main():
 
     load_package()
     import of_amd.ofk as ofk
-    from of_amd import synth
+    from of_amd import synth, sharding
     from of_amd.pipeline import FlowPipeline, PipelineConfig
 
     cfg = PipelineConfig.baseline_1080p()
@@ -131,7 +131,7 @@ def main():
         if dist is not None:
             pipe.ctx.pairs_export_records_f32(rec_t.data_ptr(), B)
             pipe.sync()                                  # records complete on the library's stream
-            dist.all_gather_into_tensor(gathered, rec_t)
+            sharding.gather_records(dist, rec_t, out=gathered)
 
     for _ in range(args.warmup):
         step()
@@ -148,9 +148,7 @@ def main():
     pipe.ctx.profile_enable(0)
 
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local}")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        dt = sharding.max_over_ranks(dist, dt, device=f"cuda:{local}")
 
     out = pipe.ctx.pairs_download(points=False)
     rec = out["records"]

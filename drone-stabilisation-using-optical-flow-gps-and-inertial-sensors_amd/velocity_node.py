@@ -91,14 +91,10 @@ class optical_fusion:
         with self._lock:
             state = np.zeros(ofk.IMU_STATE)
             state[0:3] = self.vel; state[3] = self.old_time; state[4] = self.time_zero; state[5] = 1.0 if self.first_imu_ else 0.0
-            if self.got_vel_ and not self.first_imu_:
-                keep_vel = np.array(self.vel, np.float64)
-            else:
-                keep_vel = None
             state = self._ctx().imu_propagate(state, msg)
-            self.vel = state[0:3].copy() if keep_vel is None else keep_vel
-            self.old_time = float(state[3]); self.time_zero = state[4] if self.first_imu_ is False else int(state[4])
-            self.first_imu_ = False
+            if not self.got_vel_:                       # node:80 (got_vel_ is never set on self, node:260-262 toggles a local)
+                self.vel = state[0:3].copy()
+            self.old_time = float(state[3]); self.time_zero = int(state[4]); self.first_imu_ = False
             self.rotation = state[6:15].reshape(3, 3).copy(); self.normal = state[15:18].copy()
             self.ang = state[18:21].copy(); self.ang_err = state[21:24].copy()
             self.got_ang_vel_ = True
