@@ -202,8 +202,8 @@ __global__ __launch_bounds__(256) void k_mineig(const uint8_t *__restrict__ gray
         const float m = fmaxf(fmaxf(__int_as_float(s_misc[0]), __int_as_float(s_misc[1])),
                               fmaxf(__int_as_float(s_misc[2]), __int_as_float(s_misc[3])));
         unsigned cur = __float_as_uint(m);                    // m >= 0: bit patterns order like the values
-        const unsigned old = m > 0.f ? atomicMax(maxbits + b, cur)
-                                     : __hip_atomic_load(maxbits + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned old = m > 0.f ? atomicMax(maxbits + b * OFK_MAX_STRIDE, cur)
+                                     : __hip_atomic_load(maxbits + b * OFK_MAX_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (old > cur) cur = old;
         s_misc[4] = __float_as_int((float)((double)__uint_as_float(cur) * quality));   // running threshold <= final threshold
     }
@@ -283,18 +283,277 @@ int ofk_launch_mineig(hipStream_t s, const uint8_t *gray, size_t gray_stride, in
 #undef ME_ARGS
 }
 
-// Response + 3x3 NMS + candidate keys + image maximum; no map.
+// ------------------------------------------------------------------------------------------------ streaming response + NMS
+// k_mineig_stream<BS>: one WAVE per column strip, marching down the rows — no LDS tile, no barriers.
+//   lane = gray/product column.  Per row: 1 byte load per lane (prefetched a block of BS rows ahead), Sobel column
+//   sums in registers, x-neighbours through DPP wave shifts, the horizontal box sum as a Horner chain of BS-1
+//   v_add_u32_dpp (acc = shr1(acc) + p), the vertical box sum as a register ring of BS rows, lambda_min in f32,
+//   3x3 NMS on the last three response rows, candidate keys buffered per wave in LDS and flushed 64 at a time with one
+//   global atomic.  A strip of 64 lanes yields 61-BS candidate columns (BS=7: 54, i.e. 84 % useful lanes; the LDS-tile
+//   kernel's halo redundancy is 2.4x).  Integer sums are identical to the oracle's, the f32 formula is the same.
+#define DPP_SHR1(v) __builtin_amdgcn_update_dpp(0, (v), 0x138, 0xF, 0xF, true)      /* lane l <- lane l-1 (column x-1) */
+#define DPP_SHL1(v) __builtin_amdgcn_update_dpp(0, (v), 0x130, 0xF, 0xF, true)      /* lane l <- lane l+1 (column x+1) */
+
+__device__ __forceinline__ float wave_max_f32(float v)
+{
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true)));
+    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16)),
+                c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return fmaxf(fmaxf(a, b), fmaxf(c, d));
+}
+
+template <int BS, bool MASK>
+__global__ __launch_bounds__(256) void k_mineig_stream(const uint8_t *__restrict__ gray, size_t gray_stride, int h, int w,
+                                                       int rows_per_strip, float kd, float ko,
+                                                       unsigned int *__restrict__ maxbits, const uint8_t *__restrict__ mask,
+                                                       size_t mask_stride, double quality,
+                                                       unsigned long long *__restrict__ seg, int seg_cap,
+                                                       int *__restrict__ seg_count, int *__restrict__ flags)
+{
+    constexpr int AN = BS / 2, SW = 61 - BS;
+    constexpr int NBUF = 64 + BS * SW;                          // keys a wave can hold between two flush points
+    __shared__ unsigned long long s_buf[4][NBUF];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sx = blockIdx.x * 4 + wave;
+    if (sx * SW >= w) return;                                   // whole wave
+    const int b = blockIdx.z;
+    const int ya = blockIdx.y * rows_per_strip, yb = min(h, ya + rows_per_strip);
+    const uint8_t *img = gray + (size_t)b * gray_stride;
+    const uint8_t *mk = MASK ? mask + (size_t)b * mask_stride : nullptr;
+    unsigned long long *buf = s_buf[wave];                      // private to this wave: LDS executes a wave's accesses in order
+
+    const int gx = sx * SW - 2 - AN + lane;                     // gray / product column of this lane
+    const int gxr = reflect101(gx, w);
+    const bool flipx = gx < 0 || gx >= w;
+    const int xo = gx - (BS - 1) + AN;                          // column of this lane's box sums / response
+    const bool lane_ok = lane >= BS + 1 && lane <= 61;
+    const bool own_col = lane_ok && xo >= 0 && xo < w;          // counted for the maximum (every pixel exactly once)
+    const bool nms_col = lane_ok && xo >= 1 && xo < w - 1;      // may be a corner
+    const int xoc = min(max(xo, 0), w - 1);                     // clamped: safe address for predicated mask reads
+
+    const int Yp0 = ya - 1 - AN;                                // first product row
+    const int nsteps = (yb - ya) + BS + 3;                      // gray rows consumed (padded up to a multiple of BS below)
+    // Every strip owns a fixed segment of the key buffer: keys are appended with plain stores, the count is written
+    // once at the end.  (A returning global atomic per flush stalled the whole CU's memory pipeline: 0.26 -> 1.1 ms.)
+    const int nstrips = (w + SW - 1) / SW;
+    const int nseg = nstrips * (int)gridDim.y, segid = (int)blockIdx.y * nstrips + sx;
+    unsigned long long *myseg = seg + ((size_t)b * nseg + segid) * seg_cap;
+    int written = 0;                                            // keys already in the segment (uniform)
+    int cnt = 0;                                                // keys buffered in LDS by this wave (uniform)
+    float lmax = 0.f, published = 0.f;
+    unsigned mb_seen = __hip_atomic_load(maxbits + b * OFK_MAX_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // running maximum, refreshed per block
+    float thr = (float)((double)__uint_as_float(mb_seen) * quality);
+
+    // Row r of the march reads gray row reflect101(Yp0 - 1 + r).  The overhang is at most BS + 3 < h (checked by the
+    // host), so one branch-free reflection suffices; rows past the strip are clamped (their results are never used).
+    // Interior strips fetch DWORDS: one wave-instruction brings 3 rows x 17 dwords (68 B cover the strip's 64 columns at
+    // any alignment) and ds_bpermute hands every lane its byte — byte-wide global loads cost a TA cycle per lane quad
+    // and were the bottleneck (measured: 66 % of the wave time parked on vmcnt).  Edge strips (mirrored columns) keep
+    // the per-lane byte loads.
+    const unsigned ugx = (unsigned)gxr;
+    const int gx0 = sx * SW - 2 - AN;                           // column of lane 0
+    const bool fast = gx0 >= 0 && (gx0 & ~3) + 68 <= w && (w & 3) == 0;       // wave-uniform
+    constexpr int NL = (BS + 2) / 3;                            // dword loads per block of BS rows
+    const int sh = gx0 & 3;
+    const int lrow = min(lane / 17, 2), lk = lane - 17 * (lane / 17);          // loader role of this lane (lanes >= 51: dummy)
+    const unsigned ldoff = (unsigned)((gx0 & ~3) + 4 * min(lk, 16));
+    const int srcsel = ((lane + sh) >> 2) * 4, bytesh = ((lane + sh) & 3) * 8;  // consumer role: source dword lane, byte
+    auto row_of = [&](int r) -> int {
+        int gy = Yp0 - 1 + min(r, nsteps - 1);
+        gy = gy < 0 ? -gy : gy;
+        return gy >= h ? 2 * (h - 1) - gy : gy;
+    };
+#define OFK_LOAD_BLOCK(R0, OUT)                                                                                        \
+    do {                                                                                                               \
+        if (fast) {                                                                                                    \
+            _Pragma("unroll") for (int q_ = 0; q_ < NL; ++q_) {                                                        \
+                const int a_ = row_of((R0) + 3 * q_), b_ = row_of((R0) + 3 * q_ + 1), c_ = row_of((R0) + 3 * q_ + 2); \
+                const int gy_ = lrow == 0 ? a_ : (lrow == 1 ? b_ : c_);                                                \
+                OUT[q_] = (int)*reinterpret_cast<const unsigned *>(img + (size_t)gy_ * w + ldoff);                     \
+            }                                                                                                          \
+        } else {                                                                                                       \
+            _Pragma("unroll") for (int i_ = 0; i_ < BS; ++i_) OUT[i_] = (img + (size_t)row_of((R0) + i_) * w)[ugx];    \
+        }                                                                                                              \
+    } while (0)
+
+    // Warm-up needs no special case: the first two (incomplete) Sobel rows enter the vertical ring as garbage and
+    // leave it again (exact integer subtraction) before the first response row that is used.
+    int g0 = 0, g1 = 0;
+    int ringxx[BS], ringxy[BS], ringyy[BS];
+#pragma unroll
+    for (int i = 0; i < BS; ++i) { ringxx[i] = 0; ringxy[i] = 0; ringyy[i] = 0; }
+    int vxx = 0, vxy = 0, vyy = 0;
+    float e0 = 0.f, e1 = 0.f, hm0 = 0.f, hm1 = 0.f;
+    int nextg[BS];
+#pragma unroll
+    for (int i = 0; i < BS; ++i) nextg[i] = 0;
+    OFK_LOAD_BLOCK(0, nextg);
+
+    for (int base = 0; base < nsteps; base += BS) {
+        int curg[BS];
+        if (fast) {
+#pragma unroll
+            for (int i = 0; i < BS; ++i) {
+                const int v = __builtin_amdgcn_ds_bpermute(srcsel + 68 * (i % 3), nextg[i / 3]);
+                curg[i] = (int)(((unsigned)v >> bytesh) & 255u);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < BS; ++i) curg[i] = nextg[i];
+        }
+        // ---- the only branchy part of the loop sits here: move full 64-key chunks from LDS to this strip's segment
+        //      (plain stores) and publish the strip maximum (non-returning atomic)
+        {
+            unsigned cur_seen = (unsigned)__builtin_amdgcn_readfirstlane((int)mb_seen);
+            if (__float_as_uint(published) > cur_seen) cur_seen = __float_as_uint(published);
+            thr = (float)((double)__uint_as_float(cur_seen) * quality);
+        }
+        if (cnt >= 64) {
+            const int nchunk = cnt >> 6;
+            for (int q = 0; q < nchunk; ++q) {
+                const unsigned long long key = buf[q * 64 + lane];
+                if (written + q * 64 + lane < seg_cap) myseg[written + q * 64 + lane] = key;
+            }
+            written += nchunk * 64;
+            const unsigned long long rest = buf[nchunk * 64 + lane];   // < 64 keys remain
+            __builtin_amdgcn_wave_barrier();
+            buf[lane] = rest;
+            cnt -= nchunk * 64;
+            const float mw = wave_max_f32(lmax);
+            if (mw > published) {                               // publish only when this strip raised its maximum
+                if (lane == 0) (void)atomicMax(maxbits + b * OFK_MAX_STRIDE, __float_as_uint(mw));
+                published = mw;
+            }
+            mb_seen = __hip_atomic_load(maxbits + b * OFK_MAX_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // consumed at the next block
+        }
+        OFK_LOAD_BLOCK(base + BS, nextg);                                      // prefetch the next block of rows
+        // ---- BS rows of straight-line code
+#pragma unroll
+        for (int i = 0; i < BS; ++i) {
+            const int r = base + i;
+#ifdef ABLATE_LOAD
+            const int g2 = (lane * 7 + r * 13) & 255;
+#else
+            const int g2 = curg[i];
+#endif
+            const int Y = Yp0 + r - 2;                          // product row
+            const bool flip = (Y < 0 || Y >= h) != flipx;
+            const int s = g0 + 2 * g1 + g2, t = g2 - g0;
+            // written as an ADD of the negated source: ROCm 7.2 folds `a - dpp(b)` into v_subrev_u32_dpp, which on gfx950
+            // returned shr(shl(s)) - s here (measured); v_add_u32_dpp is exact
+            const int ns = -s;
+            const int dx = DPP_SHL1(s) + DPP_SHR1(ns);
+            const int dy = DPP_SHR1(t) + 2 * t + DPP_SHL1(t);
+            const int pxx = dx * dx, pyy = dy * dy, pxy = flip ? -(dx * dy) : dx * dy;
+            int hxx = pxx, hxy = pxy, hyy = pyy;
+#ifndef ABLATE_HORNER
+#pragma unroll
+            for (int k = 1; k < BS; ++k) { hxx = DPP_SHR1(hxx) + pxx; hxy = DPP_SHR1(hxy) + pxy; hyy = DPP_SHR1(hyy) + pyy; }
+#endif
+            vxx += hxx - ringxx[i]; vxy += hxy - ringxy[i]; vyy += hyy - ringyy[i];
+            ringxx[i] = hxx; ringxy[i] = hxy; ringyy[i] = hyy;
+            const int yo = ya - 2 + r - BS;                     // response row completed by this step (garbage while r <= BS)
+            const float a = (float)vxx * kd, bb = (float)vxy * ko, c = (float)vyy * kd;
+            const float amc = a - c;
+#ifdef ABLATE_EIG
+            const float e2 = a + bb + c + amc;
+#else
+            const float e2 = (a + c) - sqrtf(amc * amc + bb * bb);
+#endif
+            const bool row_own = yo >= ya && yo < yb;           // uniform
+            bool cnt_max = own_col && row_own;
+            if (MASK) cnt_max = cnt_max && mk[(size_t)min(max(yo, 0), h - 1) * w + xoc] != 0;
+            lmax = cnt_max ? fmaxf(lmax, e2) : lmax;
+#ifdef OFK_DEBUG_EIG
+            if (own_col && row_own) g_dbg_eig[(size_t)yo * w + xo] = e2;
+#endif
+            const float hm2 = fmaxf(fmaxf(__int_as_float(DPP_SHR1(__float_as_int(e2))), e2), __int_as_float(DPP_SHL1(__float_as_int(e2))));
+            const int yn = yo - 1;                              // row whose 3x3 neighbourhood is now complete
+            const bool row_nms = yn >= ya && yn < yb && yn >= 1 && yn < h - 1;     // uniform
+            const float m = fmaxf(fmaxf(hm0, hm2), fmaxf(__int_as_float(DPP_SHR1(__float_as_int(e1))), __int_as_float(DPP_SHL1(__float_as_int(e1)))));
+#ifdef ABLATE_NMS
+            bool is = nms_col && row_nms && e1 > 1e30f && !(m > e1);
+#else
+            bool is = nms_col && row_nms && e1 > thr && e1 > 0.f && !(m > e1);
+#endif
+            if (MASK) is = is && mk[(size_t)min(max(yn, 0), h - 1) * w + xoc] != 0;
+            const unsigned long long bal = __ballot(is);
+            if (is) buf[cnt + __popcll(bal & ((1ull << lane) - 1))] = ((unsigned long long)(~__float_as_uint(e1)) << 32) | (unsigned)(yn * w + xo);
+            cnt += __popcll(bal);
+            e0 = e1; e1 = e2; hm0 = hm1; hm1 = hm2;
+            g0 = g1; g1 = g2;
+        }
+    }
+    (void)e0;
+    // ---- tail: remaining keys, the segment's count and the strip maximum
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < cnt; i += 64)
+        if (written + i < seg_cap) myseg[written + i] = buf[i];
+    if (lane == 0) {
+        seg_count[(size_t)b * nseg + segid] = min(written + cnt, seg_cap);
+        if (written + cnt > seg_cap) (void)atomicOr(flags, 1);
+    }
+    const float mw = wave_max_f32(lmax);
+    if (lane == 0 && mw > published) (void)atomicMax(maxbits + b * OFK_MAX_STRIDE, __float_as_uint(mw));
+}
+
+// Geometry of the streaming kernel's segments for an image of h x w (shared by launcher and host-side sizing).
+void ofk_stream_geometry(int h, int w, int block, int batch, int *rows, int *nseg, int *seg_cap)
+{
+    const int SW = 61 - block;
+    const int strips = (w + SW - 1) / SW;
+    int r = batch >= 16 ? 128 : 32;                             // fewer, longer strips when the batch already fills the chip
+    while (strips * ((h + r - 1) / r) > 2048) r *= 2;           // k_select walks at most 2048 segments per image
+    *rows = r; *nseg = strips * ((h + r - 1) / r);
+    *seg_cap = ((SW * r / 4 + 64 + 63) / 64) * 64;              // strict local maxima fill at most a quarter of the strip
+}
+
+template <int BS>
+static int launch_mineig_stream(hipStream_t s, const uint8_t *gray, size_t gray_stride, int h, int w, unsigned int *maxbits,
+                                const uint8_t *mask, size_t mask_stride, double quality, unsigned long long *seg,
+                                size_t seg_keys_per_image, int *seg_count, int seg_count_cap, int *flags, int batch, int *nseg_out,
+                                int *segcap_out)
+{
+    constexpr int SW = 61 - BS;
+    int rows, nseg, seg_cap;
+    ofk_stream_geometry(h, w, BS, batch, &rows, &nseg, &seg_cap);
+    if ((size_t)nseg * seg_cap > seg_keys_per_image || nseg > seg_count_cap) return -1;
+    const int strips = (w + SW - 1) / SW;
+    const double scale = 1.0 / (4.0 * BS * 255.0);
+    const float kd = (float)(0.5 * scale * scale), ko = (float)(scale * scale);
+    dim3 grid((strips + 3) / 4, (h + rows - 1) / rows, batch);
+    if (mask)
+        hipLaunchKernelGGL((k_mineig_stream<BS, true>), grid, dim3(256), 0, s, gray, gray_stride, h, w, rows, kd, ko, maxbits, mask,
+                           mask_stride, quality, seg, seg_cap, seg_count, flags);
+    else
+        hipLaunchKernelGGL((k_mineig_stream<BS, false>), grid, dim3(256), 0, s, gray, gray_stride, h, w, rows, kd, ko, maxbits, mask,
+                           mask_stride, quality, seg, seg_cap, seg_count, flags);
+    *nseg_out = nseg; *segcap_out = seg_cap;
+    return 0;
+}
+
+// Response + 3x3 NMS + candidate keys + image maximum; no map.  Block sizes 3/5/7/12 run the streaming kernel, which
+// writes per-strip SEGMENTS (*nseg_out > 0); the others run the LDS-tile kernel, which appends to the flat list.
 int ofk_launch_mineig_cand(hipStream_t s, const uint8_t *gray, size_t gray_stride, int h, int w, int block,
                            unsigned int *maxbits, const uint8_t *mask, size_t mask_stride, double quality,
-                           unsigned long long *cand, int cand_cap, int *cand_count, int *flags, int batch)
+                           unsigned long long *cand, int cand_cap, int *cand_count, unsigned long long *seg,
+                           size_t seg_keys_per_image, int *seg_count, int seg_count_cap, int *flags, int batch, int *nseg_out,
+                           int *segcap_out)
 {
+    *nseg_out = 0; *segcap_out = 0;
 #define ME_ARGS s, gray, gray_stride, h, w, block, nullptr, 0, maxbits, mask, mask_stride, quality, cand, cand_cap, cand_count, flags, batch
+#define ST_ARGS s, gray, gray_stride, h, w, maxbits, mask, mask_stride, quality, seg, seg_keys_per_image, seg_count, seg_count_cap, flags, batch, nseg_out, segcap_out
     switch (block) {
-        case 3: return launch_mineig_t<3, true>(ME_ARGS);
-        case 7: return launch_mineig_t<7, true>(ME_ARGS);
-        case 12: return launch_mineig_t<12, true>(ME_ARGS);
-        default: return launch_mineig_t<0, true>(ME_ARGS);
+        case 3: return launch_mineig_stream<3>(ST_ARGS);
+        case 5: return launch_mineig_stream<5>(ST_ARGS);
+        case 7: return launch_mineig_stream<7>(ST_ARGS);
+        case 12: return launch_mineig_stream<12>(ST_ARGS);
+        default: return launch_mineig_t<0, true>(ME_ARGS);       // LDS-tile kernel for the remaining block sizes
     }
+#undef ST_ARGS
 #undef ME_ARGS
 }
 
@@ -316,7 +575,7 @@ __global__ __launch_bounds__(256) void k_maxbits(const float *__restrict__ eig, 
     __syncthreads();
     if (threadIdx.x == 0) {
         m = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
-        if (m > 0.f) atomicMax(maxbits + b, __float_as_uint(m));
+        if (m > 0.f) atomicMax(maxbits + b * OFK_MAX_STRIDE, __float_as_uint(m));
     }
 }
 
@@ -339,7 +598,7 @@ __global__ __launch_bounds__(256) void k_nms(const float *__restrict__ eig, size
     __shared__ unsigned long long s_cand[1024];
     __shared__ int s_n, s_base;
     const int b = blockIdx.z, tid = threadIdx.x;
-    const unsigned mb = maxbits[b];
+    const unsigned mb = maxbits[b * OFK_MAX_STRIDE];
     if (mb == 0) return;                                       // max <= 0: no corners
     if (tid == 0) s_n = 0;
     __syncthreads();
@@ -385,10 +644,12 @@ void ofk_launch_nms(hipStream_t s, const float *eig, size_t eig_stride, const ui
 #define SEL_T 1024
 #define SEL_BINS 2048
 
-__global__ __launch_bounds__(SEL_T) void k_select(const unsigned long long *__restrict__ cand_all, int cand_cap,
-                                                  const int *__restrict__ cand_count, const unsigned int *__restrict__ maxbits,
-                                                  double quality, int w, int max_corners, float min_distance,
-                                                  float *__restrict__ pts, int pts_stride, int *__restrict__ counts)
+__global__ __launch_bounds__(SEL_T) void k_select(unsigned long long *__restrict__ cand_all, int cand_cap,
+                                                  int *__restrict__ cand_count, const unsigned long long *__restrict__ seg,
+                                                  int seg_cap, const int *__restrict__ seg_count, int nseg,
+                                                  const unsigned int *__restrict__ maxbits, double quality, int w,
+                                                  int max_corners, float min_distance, float *__restrict__ pts, int pts_stride,
+                                                  int *__restrict__ counts)
 {
     __shared__ unsigned long long s_key[OFK_CHUNK];
     __shared__ unsigned s_hist[SEL_BINS];
@@ -398,20 +659,47 @@ __global__ __launch_bounds__(SEL_T) void k_select(const unsigned long long *__re
     __shared__ int s_n, s_nacc, s_D, s_cum;
 
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const unsigned long long *cand = cand_all + (size_t)b * cand_cap;
-    int C = cand_count[b * OFK_CNT_STRIDE];
-    if (C > cand_cap) C = cand_cap;
-    const unsigned mb = maxbits[b];
-    if (tid == 0) { s_nacc = 0; counts[b] = 0; }
-    if (mb == 0 || C == 0) return;
+    unsigned long long *cand = cand_all + (size_t)b * cand_cap;
+    const unsigned mb = maxbits[b * OFK_MAX_STRIDE];
+    if (tid == 0) { s_nacc = 0; s_n = 0; counts[b] = 0; }
+    if (mb == 0) { if (tid == 0 && nseg > 0) cand_count[b * OFK_CNT_STRIDE] = 0; return; }
     const float thr = (float)((double)__uint_as_float(mb) * quality);
-    if (!(thr < __uint_as_float(mb))) return;                   // nothing is strictly above the threshold
     // keys of interest: [a, kend);  v > thr  <=>  key < (~bits(thr)) << 32
     const unsigned long long kend = (unsigned long long)(~__float_as_uint(thr)) << 32;
     unsigned long long a = (unsigned long long)(~mb) << 32;     // smallest possible key (value == max)
     const float md2 = min_distance * min_distance;
     const bool use_dist = min_distance >= 1.f;
     __syncthreads();
+    int C;
+    if (nseg > 0) {
+        // the streaming response kernel left one segment of keys per strip, pruned with a running threshold only:
+        // compact the keys that pass the exact threshold into the flat list (one LDS atomic per wave-iteration)
+        const unsigned long long *sbase = seg + (size_t)b * nseg * seg_cap;
+        for (int sg = wave; sg < nseg; sg += SEL_T / 64) {
+            const int n = min(seg_count[(size_t)b * nseg + sg], seg_cap);
+            for (int i0 = 0; i0 < n; i0 += 64) {
+                const int i = i0 + lane;
+                const unsigned long long key = i < n ? sbase[(size_t)sg * seg_cap + i] : ~0ull;
+                const bool keep = key < kend;
+                const unsigned long long bal = __ballot(keep);
+                if (bal) {
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&s_n, __popcll(bal));
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    const int pos = base + __popcll(bal & ((1ull << lane) - 1));
+                    if (keep && pos < cand_cap) cand[pos] = key;
+                }
+            }
+        }
+        __syncthreads();
+        C = min(s_n, cand_cap);
+        if (tid == 0) cand_count[b * OFK_CNT_STRIDE] = s_n;
+        __threadfence_block();
+        __syncthreads();
+    } else {
+        C = min(cand_count[b * OFK_CNT_STRIDE], cand_cap);
+    }
+    if (C == 0 || !(thr < __uint_as_float(mb))) return;         // nothing is strictly above the threshold
 
     while (a < kend) {
         // ---- choose T in (a, kend] so that 1 <= #{a <= key < T} <= OFK_CHUNK (or detect that none is left)
@@ -533,10 +821,10 @@ __global__ __launch_bounds__(SEL_T) void k_select(const unsigned long long *__re
     if (tid == 0) counts[b] = s_nacc;
 }
 
-void ofk_launch_select(hipStream_t s, const unsigned long long *cand, int cand_cap, const int *cand_count,
-                       const unsigned int *maxbits, double quality, int w, int max_corners, float min_distance, float *pts,
-                       int pts_stride, int *counts, int batch)
+void ofk_launch_select(hipStream_t s, unsigned long long *cand, int cand_cap, int *cand_count, const unsigned long long *seg,
+                       int seg_cap, const int *seg_count, int nseg, const unsigned int *maxbits, double quality, int w,
+                       int max_corners, float min_distance, float *pts, int pts_stride, int *counts, int batch)
 {
-    hipLaunchKernelGGL(k_select, dim3(batch), dim3(SEL_T), 0, s, cand, cand_cap, cand_count, maxbits, quality, w, max_corners,
-                       min_distance, pts, pts_stride, counts);
+    hipLaunchKernelGGL(k_select, dim3(batch), dim3(SEL_T), 0, s, cand, cand_cap, cand_count, seg, seg_cap, seg_count, nseg, maxbits,
+                       quality, w, max_corners, min_distance, pts, pts_stride, counts);
 }

@@ -98,7 +98,10 @@ extern "C" int ofk_create(int device, int max_w, int max_h, int max_batch, int m
     for (int k = 0; k < 2; ++k) { ALLOC(c->bgr[k], B * c->bgr_stride); ALLOC(c->pyr[k], B * c->pyr_stride); }
     ALLOC(c->eig, B * c->img_stride * sizeof(float));
     ALLOC(c->cand, B * (size_t)c->cand_cap * 8);
-    ALLOC(c->cand_count, B * OFK_CNT_STRIDE * 4); ALLOC(c->maxbits, B * 4);
+    c->seg_keys = (size_t)(c->P / 4) + (size_t)(c->P / 4) / 2 + 64 * OFK_SEG_MAX;   // segment rounding slack
+    ALLOC(c->cand_seg, B * c->seg_keys * 8);
+    ALLOC(c->seg_count, B * OFK_SEG_MAX * 4);
+    ALLOC(c->cand_count, B * OFK_CNT_STRIDE * 4); ALLOC(c->maxbits, B * OFK_MAX_STRIDE * 4);
     ALLOC(c->pts_prev, B * max_pts * 8); ALLOC(c->pts_next, B * max_pts * 8);
     ALLOC(c->status, B * max_pts); ALLOC(c->err, B * max_pts * 4); ALLOC(c->counts, B * 4);
     ALLOC(c->sensors, B * OFK_SENSOR_DOUBLES * 8); ALLOC(c->records, B * OFK_RECORD_DOUBLES * 8);
@@ -120,7 +123,7 @@ extern "C" int ofk_destroy(ofk_ctx *c)
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (int k = 0; k < 2; ++k) { if (c->bgr[k]) hipFree(c->bgr[k]); if (c->pyr[k]) hipFree(c->pyr[k]); }
-    void *ptrs[] = {c->eig, c->mask, c->deriv, c->cand, c->cand_count, c->maxbits, c->pts_prev, c->pts_next, c->status, c->err,
+    void *ptrs[] = {c->eig, c->mask, c->deriv, c->cand, c->cand_seg, c->seg_count, c->cand_count, c->maxbits, c->pts_prev, c->pts_next, c->status, c->err,
                     c->counts, c->sensors, c->records, c->dev_flags, c->scratch};
     for (void *p : ptrs) if (p) hipFree(p);
     if (c->hstage) hipHostFree(c->hstage);
@@ -223,7 +226,7 @@ extern "C" int ofk_scharr_s16(ofk_ctx *c, const uint8_t *gray, int batch, int h,
 static int check_block(ofk_ctx *c, int h, int w, int block)
 {
     if (block < 1 || block > 45) return ofk_fail(c, OFK_E_INVALID, "block_size %d outside 1..45", block);
-    if (h <= block + 1 || w <= block + 1) return ofk_fail(c, OFK_E_INVALID, "image %dx%d too small for block_size %d", w, h, block);
+    if (h < block + 4 || w < block + 4) return ofk_fail(c, OFK_E_INVALID, "image %dx%d too small for block_size %d", w, h, block);
     return OFK_OK;
 }
 
@@ -252,14 +255,14 @@ static int run_select(ofk_ctx *c, bool have_max, const uint8_t *dmask, int batch
                       double min_distance)
 {
     if (!have_max) {
-        OFK_HIP(c, hipMemsetAsync(c->maxbits, 0, (size_t)batch * 4, c->stream));
+        OFK_HIP(c, hipMemsetAsync(c->maxbits, 0, (size_t)batch * OFK_MAX_STRIDE * 4, c->stream));
         ofk_launch_maxbits(c->stream, c->eig, c->img_stride, dmask, c->img_stride, h, w, c->maxbits, batch);
     }
     OFK_HIP(c, hipMemsetAsync(c->cand_count, 0, (size_t)batch * OFK_CNT_STRIDE * 4, c->stream));
     ofk_launch_nms(c->stream, c->eig, c->img_stride, dmask, c->img_stride, h, w, c->maxbits, quality, c->cand, c->cand_cap,
                    c->cand_count, c->dev_flags, batch);
-    ofk_launch_select(c->stream, c->cand, c->cand_cap, c->cand_count, c->maxbits, quality, w, max_corners, (float)min_distance,
-                      c->pts_prev, c->max_pts, c->counts, batch);
+    ofk_launch_select(c->stream, c->cand, c->cand_cap, c->cand_count, nullptr, 0, nullptr, 0, c->maxbits, quality, w, max_corners,
+                      (float)min_distance, c->pts_prev, c->max_pts, c->counts, batch);
     return check_launch(c, "corner selection");
 }
 
@@ -302,14 +305,24 @@ extern "C" int ofk_good_features(ofk_ctx *c, const uint8_t *gray, const uint8_t 
     TRY(h2d(c, c->pyr[0], c->pyr_stride, gray, px, batch));
     const uint8_t *dmask = nullptr;
     if (mask) { TRY(lazy_mask(c)); TRY(h2d(c, c->mask, c->img_stride, mask, px, batch)); dmask = c->mask; }
-    OFK_HIP(c, hipMemsetAsync(c->maxbits, 0, (size_t)batch * 4, c->stream));
+    OFK_HIP(c, hipMemsetAsync(c->maxbits, 0, (size_t)batch * OFK_MAX_STRIDE * 4, c->stream));
     OFK_HIP(c, hipMemsetAsync(c->cand_count, 0, (size_t)batch * OFK_CNT_STRIDE * 4, c->stream));
+    int nseg = 0, segcap = 0;
     if (ofk_launch_mineig_cand(c->stream, c->pyr[0], c->pyr_stride, h, w, block, c->maxbits, dmask, c->img_stride, quality, c->cand,
-                               c->cand_cap, c->cand_count, c->dev_flags, batch))
-        return ofk_fail(c, OFK_E_INVALID, "k_mineig: LDS tile too large for block_size %d", block);
-    ofk_launch_select(c->stream, c->cand, c->cand_cap, c->cand_count, c->maxbits, quality, w, max_corners, (float)min_distance,
-                      c->pts_prev, c->max_pts, c->counts, batch);
+                               c->cand_cap, c->cand_count, c->cand_seg, c->seg_keys, c->seg_count, OFK_SEG_MAX, c->dev_flags, batch,
+                               &nseg, &segcap))
+        return ofk_fail(c, OFK_E_INVALID, "corner response: block_size %d does not fit (LDS tile / key segments)", block);
+    ofk_launch_select(c->stream, c->cand, c->cand_cap, c->cand_count, c->cand_seg, segcap, c->seg_count, nseg, c->maxbits, quality, w,
+                      max_corners, (float)min_distance, c->pts_prev, c->max_pts, c->counts, batch);
     TRY(check_launch(c, "corner detection"));
+    if (getenv("OFK_DEBUG")) {
+        unsigned mb[4 * OFK_MAX_STRIDE] = {0}; int cc[4 * OFK_CNT_STRIDE] = {0}; int cn[4] = {0};
+        hipStreamSynchronize(c->stream);
+        hipMemcpy(mb, c->maxbits, 4 * OFK_MAX_STRIDE * (batch < 4 ? batch : 4), hipMemcpyDeviceToHost);
+        hipMemcpy(cc, c->cand_count, 4 * OFK_CNT_STRIDE * (batch < 4 ? batch : 4), hipMemcpyDeviceToHost);
+        hipMemcpy(cn, c->counts, 4 * (batch < 4 ? batch : 4), hipMemcpyDeviceToHost);
+        for (int b = 0; b < batch && b < 4; ++b) fprintf(stderr, "[ofk debug] image %d: maxbits 0x%08x candidates %d corners %d\n", b, mb[b * OFK_MAX_STRIDE], cc[b * OFK_CNT_STRIDE], cn[b]);
+    }
     return fetch_corners(c, batch, max_corners, pts, counts);
 }
 
@@ -553,6 +566,7 @@ extern "C" int ofk_pairs_run(ofk_ctx *c, const ofk_params *p)
     TRY(check_lk(c, h, w, p->win, p->max_level));
     if (p->solve_variant != OFK_SOLVE_NODE && p->solve_variant != OFK_SOLVE_SIM) return ofk_fail(c, OFK_E_INVALID, "solve_variant must be NODE or SIM");
     const ofk_levels lv = ofk_make_levels(h, w, p->win, p->max_level);
+    int nseg = 0, segcap = 0;
     {
         StageTimer t(c, OFK_STAGE_GRAY);
         ofk_launch_gray(c->stream, c->bgr[0], c->bgr_stride, c->pyr[0], c->pyr_stride, B, h, w);
@@ -564,16 +578,17 @@ extern "C" int ofk_pairs_run(ofk_ctx *c, const ofk_params *p)
     }
     {
         StageTimer t(c, OFK_STAGE_EIG);                          // response + 3x3 NMS + candidate keys, no map in HBM
-        hipMemsetAsync(c->maxbits, 0, (size_t)B * 4, c->stream);
+        hipMemsetAsync(c->maxbits, 0, (size_t)B * OFK_MAX_STRIDE * 4, c->stream);
         hipMemsetAsync(c->cand_count, 0, (size_t)B * OFK_CNT_STRIDE * 4, c->stream);
         if (ofk_launch_mineig_cand(c->stream, c->pyr[0], c->pyr_stride, h, w, p->block_size, c->maxbits, nullptr, 0, p->quality, c->cand,
-                                   c->cand_cap, c->cand_count, c->dev_flags, B))
-            return ofk_fail(c, OFK_E_INVALID, "k_mineig: LDS tile too large for block_size %d", p->block_size);
+                                   c->cand_cap, c->cand_count, c->cand_seg, c->seg_keys, c->seg_count, OFK_SEG_MAX, c->dev_flags, B,
+                                   &nseg, &segcap))
+            return ofk_fail(c, OFK_E_INVALID, "corner response: block_size %d does not fit (LDS tile / key segments)", p->block_size);
     }
     {
         StageTimer t(c, OFK_STAGE_SELECT);
-        ofk_launch_select(c->stream, c->cand, c->cand_cap, c->cand_count, c->maxbits, p->quality, w, p->max_corners,
-                          (float)p->min_distance, c->pts_prev, c->max_pts, c->counts, B);
+        ofk_launch_select(c->stream, c->cand, c->cand_cap, c->cand_count, c->cand_seg, segcap, c->seg_count, nseg, c->maxbits, p->quality,
+                          w, p->max_corners, (float)p->min_distance, c->pts_prev, c->max_pts, c->counts, B);
     }
     {
         StageTimer t(c, OFK_STAGE_LK);

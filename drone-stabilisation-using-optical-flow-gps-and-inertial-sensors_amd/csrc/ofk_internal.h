@@ -8,6 +8,8 @@
 
 #define OFK_MAX_LEVELS 9            // level 0 .. 8
 #define OFK_CHUNK 4096              // candidates sorted per selection round (LDS resident)
+#define OFK_SEG_MAX 2048            // segments (strips) per image the selection kernel walks
+#define OFK_MAX_STRIDE 128          // ints between per-image response maxima: one L2 channel each (a packed array was a hot spot)
 #define OFK_CNT_STRIDE 32           // ints between per-image candidate counters (one 128-B line each: no atomic contention)
 
 struct ofk_levels {
@@ -31,9 +33,12 @@ struct ofk_ctx {
     float *eig;                     // [B][img_stride]            Shi-Tomasi response
     uint8_t *mask;                  // [B][img_stride]            optional detection mask (lazily allocated)
     int16_t *deriv;                 // [B][img_stride][2]         only for ofk_scharr_s16 (lazily allocated)
-    unsigned long long *cand;       // [B][cand_cap]              candidate keys (~value bits << 32 | linear index)
+    unsigned long long *cand;       // [B][cand_cap]              candidate keys (~value bits << 32 | linear index), flat list
+    unsigned long long *cand_seg;   // [B][seg_keys]              per-strip key segments written by the streaming response kernel
+    int *seg_count;                 // [B][OFK_SEG_MAX]           keys per segment
+    size_t seg_keys;                // keys per image in cand_seg
     int *cand_count;                // [B][OFK_CNT_STRIDE]
-    unsigned int *maxbits;          // [B]                        bit pattern of max positive response
+    unsigned int *maxbits;          // [B][OFK_MAX_STRIDE]                       bit pattern of max positive response
     float *pts_prev, *pts_next;     // [B][max_pts][2]
     uint8_t *status;                // [B][max_pts]
     float *err;                     // [B][max_pts]
@@ -76,10 +81,13 @@ void ofk_launch_nms(hipStream_t s, const float *eig, size_t eig_stride, const ui
                     int *cand_count, int *flags, int batch);
 int  ofk_launch_mineig_cand(hipStream_t s, const uint8_t *gray, size_t gray_stride, int h, int w, int block,
                             unsigned int *maxbits, const uint8_t *mask, size_t mask_stride, double quality,
-                            unsigned long long *cand, int cand_cap, int *cand_count, int *flags, int batch);
-void ofk_launch_select(hipStream_t s, const unsigned long long *cand, int cand_cap, const int *cand_count,
-                       const unsigned int *maxbits, double quality, int w, int max_corners, float min_distance, float *pts,
-                       int pts_stride, int *counts, int batch);
+                            unsigned long long *cand, int cand_cap, int *cand_count, unsigned long long *seg,
+                            size_t seg_keys_per_image, int *seg_count, int seg_count_cap, int *flags, int batch, int *nseg_out,
+                            int *segcap_out);
+void ofk_stream_geometry(int h, int w, int block, int batch, int *rows, int *nseg, int *seg_cap);
+void ofk_launch_select(hipStream_t s, unsigned long long *cand, int cand_cap, int *cand_count, const unsigned long long *seg,
+                       int seg_cap, const int *seg_count, int nseg, const unsigned int *maxbits, double quality, int w,
+                       int max_corners, float min_distance, float *pts, int pts_stride, int *counts, int batch);
 void ofk_launch_lk(hipStream_t s, const uint8_t *prev, const uint8_t *next, size_t pyr_stride, const ofk_levels &lv,
                    const float *prev_pts, const int *counts, int pts_stride, int win, int max_count, double eps,
                    double min_eig_thr, float *next_pts, uint8_t *status, float *err, int batch);
