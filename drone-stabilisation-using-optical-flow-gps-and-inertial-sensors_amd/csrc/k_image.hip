@@ -69,23 +69,45 @@ void ofk_launch_gray(hipStream_t s, const uint8_t *bgr, size_t bgr_stride, uint8
 #define PD_SW 136                       // staged source columns: [2*ox0-4, 2*ox0+132)
 #define PD_SH (2 * PD_TH + 3)           // staged source rows:    [2*oy0-2, 2*oy0+2*TH+1)
 
-__global__ __launch_bounds__(256) void k_pyr_down(const uint8_t *__restrict__ src, size_t src_stride, int h, int w,
-                                                  uint8_t *__restrict__ dst, size_t dst_stride, int dh, int dw)
+// z < batch: image z of (src0 -> dst0); z >= batch: image z - batch of (src1 -> dst1) — both frames of a pair in one launch.
+__global__ __launch_bounds__(256) void k_pyr_down(const uint8_t *__restrict__ src0, const uint8_t *__restrict__ src1,
+                                                  size_t src_stride, int h, int w, uint8_t *__restrict__ dst0,
+                                                  uint8_t *__restrict__ dst1, size_t dst_stride, int dh, int dw, int batch)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_src[PD_SH][PD_SW];
-    __shared__ uint16_t s_h[PD_SH][PD_TW];
-    const int b = blockIdx.z;
-    const uint8_t *img = src + (size_t)b * src_stride;
-    uint8_t *out = dst + (size_t)b * dst_stride;
+    __shared__ __attribute__((aligned(16))) uint16_t s_h[PD_SH][PD_TW];
+    const int z = blockIdx.z;
+    const uint8_t *img = z < batch ? src0 + (size_t)z * src_stride : src1 + (size_t)(z - batch) * src_stride;
+    uint8_t *out = z < batch ? dst0 + (size_t)z * dst_stride : dst1 + (size_t)(z - batch) * dst_stride;
     const int ox0 = blockIdx.x * PD_TW, oy0 = blockIdx.y * PD_TH;
     const int sx0 = 2 * ox0 - 4, sy0 = 2 * oy0 - 2;
     const int tid = threadIdx.x;
-    const bool interior = sx0 >= 0 && sy0 >= 0 && sx0 + PD_SW <= w && sy0 + PD_SH <= h && (w & 3) == 0;
-    if (interior) {
-        for (int i = tid; i < PD_SH * (PD_SW / 4); i += 256) {
+    if ((w & 3) == 0 && w >= 8) {
+        // Dword staging for every tile: rows are mirrored per row, out-of-range dwords are clamped (never faulting) and
+        // the two mirrored columns a border tile really needs (-2,-1 / w,w+1) are patched from LDS afterwards.
+        // All of this thread's loads are issued before the first LDS store (one memory latency per block, not five).
+        constexpr int ND = PD_SH * (PD_SW / 4), NIT = (ND + 255) / 256;
+        unsigned v[NIT];
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int i = min(tid + 256 * k, ND - 1);
             const int r = i / (PD_SW / 4), c4 = i % (PD_SW / 4);
-            const unsigned v = *reinterpret_cast<const unsigned *>(img + (size_t)(sy0 + r) * w + sx0 + c4 * 4);
-            *reinterpret_cast<unsigned *>(&s_src[r][c4 * 4]) = v;
+            const int sc = min(max(sx0 + 4 * c4, 0), w - 4);
+            v[k] = *reinterpret_cast<const unsigned *>(img + (size_t)reflect101(sy0 + r, h) * w + sc);
+        }
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int i = tid + 256 * k;
+            if (i < ND) reinterpret_cast<unsigned *>(&s_src[0][0])[i] = v[k];
+        }
+        if (sx0 < 0 || sx0 + PD_SW > w) {                       // block-uniform
+            __syncthreads();
+            if (tid < PD_SH) {
+                if (sx0 < 0) { s_src[tid][2] = s_src[tid][6]; s_src[tid][3] = s_src[tid][5]; }          // cols -2,-1 <- 2,1
+                const int c = w - sx0;                          // staged index of source column w
+                if (c >= 3 && c < PD_SW) s_src[tid][c] = s_src[tid][c - 2];                              // w   <- w-2
+                if (c >= 3 && c + 1 < PD_SW) s_src[tid][c + 1] = s_src[tid][c - 3];                      // w+1 <- w-3
+            }
         }
     } else {
         for (int i = tid; i < PD_SH * PD_SW; i += 256) {
@@ -94,18 +116,46 @@ __global__ __launch_bounds__(256) void k_pyr_down(const uint8_t *__restrict__ sr
         }
     }
     __syncthreads();
-    for (int i = tid; i < PD_SH * PD_TW; i += 256) {
-        const int r = i / PD_TW, x = i % PD_TW;
-        const uint8_t *p = &s_src[r][2 * x + 2];          // source column 2*(ox0+x)-2 sits at staged column 2x+2
-        s_h[r][x] = (uint16_t)(p[0] + 4 * p[1] + 6 * p[2] + 4 * p[3] + p[4]);
+    // horizontal [1 4 6 4 1]: item = (staged row, 4 outputs); 16 source bytes come in as two ds_read_b64, 4 u16 go out as one
+    for (int i = tid; i < PD_SH * (PD_TW / 4); i += 256) {
+        const int r = i >> 4, q = i & 15;
+        const uint2 lo = *reinterpret_cast<const uint2 *>(&s_src[r][8 * q]);
+        const uint2 hi = *reinterpret_cast<const uint2 *>(&s_src[r][8 * q + 8]);
+        const unsigned d[4] = {lo.x, lo.y, hi.x, hi.y};
+        unsigned o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                       // output 4q+j reads staged bytes 8q + 2j + 2 .. + 6
+            unsigned acc = 0;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const int byte = 2 * j + 2 + k;
+                const unsigned v = (d[byte >> 2] >> (8 * (byte & 3))) & 255u;
+                acc += (k == 0 || k == 4) ? v : (k == 2 ? 6u * v : 4u * v);
+            }
+            o[j] = acc;
+        }
+        *reinterpret_cast<uint2 *>(&s_h[r][4 * q]) = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
     }
     __syncthreads();
-    for (int i = tid; i < PD_TH * PD_TW; i += 256) {
-        const int y = i / PD_TW, x = i % PD_TW;
-        const int oy = oy0 + y, ox = ox0 + x;
+    // vertical: item = (output row, 4 outputs): five ds_read_b64, one dword store
+    {
+        const int y = tid >> 4, q = tid & 15;
+        const int oy = oy0 + y, ox = ox0 + 4 * q;
         if (oy < dh && ox < dw) {
-            const int s = s_h[2 * y][x] + 4 * s_h[2 * y + 1][x] + 6 * s_h[2 * y + 2][x] + 4 * s_h[2 * y + 3][x] + s_h[2 * y + 4][x];
-            out[(size_t)oy * dw + ox] = (uint8_t)((s + 128) >> 8);
+            unsigned acc[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const uint2 v = *reinterpret_cast<const uint2 *>(&s_h[2 * y + k][4 * q]);
+                const unsigned wgt = (k == 0 || k == 4) ? 1u : (k == 2 ? 6u : 4u);
+                acc[0] += wgt * (v.x & 0xffffu); acc[1] += wgt * (v.x >> 16);
+                acc[2] += wgt * (v.y & 0xffffu); acc[3] += wgt * (v.y >> 16);
+            }
+            const unsigned pk = ((acc[0] + 128) >> 8) | (((acc[1] + 128) >> 8) << 8) | (((acc[2] + 128) >> 8) << 16) |
+                                (((acc[3] + 128) >> 8) << 24);
+            uint8_t *dp = out + (size_t)oy * dw + ox;
+            if (ox + 3 < dw && (dw & 3) == 0) *reinterpret_cast<unsigned *>(dp) = pk;
+            else
+                for (int j = 0; j < 4 && ox + j < dw; ++j) dp[j] = (uint8_t)(pk >> (8 * j));
         }
     }
 }
@@ -115,7 +165,17 @@ void ofk_launch_pyr_down(hipStream_t s, const uint8_t *src, size_t src_stride, i
 {
     const int dh = (h + 1) / 2, dw = (w + 1) / 2;
     dim3 grid((dw + PD_TW - 1) / PD_TW, (dh + PD_TH - 1) / PD_TH, batch);
-    hipLaunchKernelGGL(k_pyr_down, grid, dim3(256), 0, s, src, src_stride, h, w, dst, dst_stride, dh, dw);
+    hipLaunchKernelGGL(k_pyr_down, grid, dim3(256), 0, s, src, (const uint8_t *)nullptr, src_stride, h, w, dst, (uint8_t *)nullptr,
+                       dst_stride, dh, dw, batch);
+}
+
+// the same level of both frames of every pair in one launch
+void ofk_launch_pyr_down2(hipStream_t s, const uint8_t *src0, const uint8_t *src1, size_t src_stride, int h, int w,
+                          uint8_t *dst0, uint8_t *dst1, size_t dst_stride, int batch)
+{
+    const int dh = (h + 1) / 2, dw = (w + 1) / 2;
+    dim3 grid((dw + PD_TW - 1) / PD_TW, (dh + PD_TH - 1) / PD_TH, 2 * batch);
+    hipLaunchKernelGGL(k_pyr_down, grid, dim3(256), 0, s, src0, src1, src_stride, h, w, dst0, dst1, dst_stride, dh, dw, batch);
 }
 
 // ------------------------------------------------------------------------------------------------ Scharr

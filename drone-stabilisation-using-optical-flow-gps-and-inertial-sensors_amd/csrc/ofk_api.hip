@@ -337,11 +337,15 @@ static int check_lk(ofk_ctx *c, int h, int w, int win, int max_level)
 // builds levels 1..L of both resident pyramids
 static void build_pyramids(ofk_ctx *c, const ofk_levels &lv, int batch, int which_mask)
 {
-    for (int k = 0; k < 2; ++k) {
-        if (!(which_mask & (1 << k))) continue;
-        for (int l = 1; l <= lv.n; ++l)
-            ofk_launch_pyr_down(c->stream, c->pyr[k] + lv.off[l - 1], c->pyr_stride, lv.h[l - 1], lv.w[l - 1],
-                                c->pyr[k] + lv.off[l], c->pyr_stride, batch);
+    for (int l = 1; l <= lv.n; ++l) {
+        if (which_mask == 3)
+            ofk_launch_pyr_down2(c->stream, c->pyr[0] + lv.off[l - 1], c->pyr[1] + lv.off[l - 1], c->pyr_stride, lv.h[l - 1], lv.w[l - 1],
+                                 c->pyr[0] + lv.off[l], c->pyr[1] + lv.off[l], c->pyr_stride, batch);
+        else {
+            const int k = which_mask == 1 ? 0 : 1;
+            ofk_launch_pyr_down(c->stream, c->pyr[k] + lv.off[l - 1], c->pyr_stride, lv.h[l - 1], lv.w[l - 1], c->pyr[k] + lv.off[l],
+                                c->pyr_stride, batch);
+        }
     }
 }
 

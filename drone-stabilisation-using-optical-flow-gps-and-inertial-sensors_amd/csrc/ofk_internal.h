@@ -70,6 +70,8 @@ void ofk_launch_gray(hipStream_t s, const uint8_t *bgr, size_t bgr_stride, uint8
                      int h, int w);
 void ofk_launch_pyr_down(hipStream_t s, const uint8_t *src, size_t src_stride, int h, int w, uint8_t *dst,
                          size_t dst_stride, int batch);
+void ofk_launch_pyr_down2(hipStream_t s, const uint8_t *src0, const uint8_t *src1, size_t src_stride, int h, int w,
+                          uint8_t *dst0, uint8_t *dst1, size_t dst_stride, int batch);
 void ofk_launch_scharr(hipStream_t s, const uint8_t *src, size_t src_stride, int h, int w, int16_t *dxdy,
                        size_t dst_stride_elems, int batch);
 int  ofk_launch_mineig(hipStream_t s, const uint8_t *gray, size_t gray_stride, int h, int w, int block, float *eig,
