@@ -49,12 +49,29 @@ def algorithmic_bytes(cfg, n_pts, n_cand):
     return {
         "gray": 2 * (3 * P[0] + P[0]),
         "pyr": 2 * sum(P[l - 1] + P[l] for l in range(1, L + 1)),
-        "eig": P[0] + 4 * P[0],
-        "nms": 4 * P[0] + 8 * n_cand,
+        # SURVEY's G_eig (P + 4P) and G_nms (4P + 8 N_cand) assume a materialised f32 response map.  The fused streaming
+        # kernel never writes it: its compulsory traffic is the gray frame in and the candidate keys out.
+        "eig": P[0] + 8 * n_cand,
+        "nms": 0,
         "select": 8 * n_cand + 8 * n_pts,
         "lk": n_pts * sum((wn + 2) ** 2 + (wn + 1 + 2 * 3) ** 2 for _ in range(L + 1)) + 21 * n_pts,
         "solve": n_pts * 32 + 200,
     }
+
+
+STAGE_KERNEL = {"gray": "k_gray_bgr8", "pyr": "k_pyr_down", "eig": "k_mineig_stream<7, false>", "select": "k_select", "lk": "k_lk15",
+                "solve": "k_pairs_solve"}
+
+
+def pmc_traffic(stage, pairs_per_launch):
+    """HBM bytes per launch of the stage's kernel from the committed rocprofv3 PMC passes (profiles/r01_traffic_pmc.json,
+    collected by tools/profile_round.sh on this same command), scaled to the pairs one launch processes; None if absent."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic_pmc.json")))
+        k = t["kernels"][STAGE_KERNEL[stage]]
+        return int(k["hbm_bytes_per_launch"] * pairs_per_launch / t["batch"])
+    except Exception:
+        return None
 
 
 def cpu_baseline(prev, nxt, sensors, cfg, sample):
@@ -83,6 +100,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=128, help="frame pairs per GPU per step")
+    ap.add_argument("--streams", type=int, default=1, help="concurrent slices of the batch (HIP streams) per GPU")
     ap.add_argument("--cpu-sample", type=int, default=24, help="pairs timed on the CPU oracle (0 = skip)")
     args = ap.parse_args()
 
@@ -111,7 +129,7 @@ def main():
     prev, nxt, base = synth.make_batch(B, H, W, seed=2000 + 131 * rank, distinct=4, **truth)
     p0 = base[0]
     sensors = ofk.make_sensors(B, d=p0["d"], normal=p0["n"], omega=p0["omega"], scaling=p0["scaling"], cx=p0["cx"], cy=p0["cy"])
-    pipe = FlowPipeline(W, H, B, cfg, device=local)
+    pipe = FlowPipeline(W, H, B, cfg, device=local, streams=args.streams)
     pipe.upload(prev, nxt, sensors)
 
     gathered = rec_t = None
@@ -159,11 +177,13 @@ def main():
         stages = {}
         for s in ofk.STAGES:
             ms, nl = prof[s]
-            per_step = ms / max(1, nl)
-            stages[s] = {"ms_per_step": round(per_step, 4), "algorithmic_GBps": round(ab[s] * B / (per_step * 1e-3) / 1e9, 2) if per_step > 0 else None}
+            per_step = ms / args.steps                   # summed over the slices (streams) of a step
+            stages[s] = {"ms_per_step": round(per_step, 4), "launches_per_step": nl // max(1, args.steps),
+                         "algorithmic_GBps": round(ab[s] * B / (per_step * 1e-3) / 1e9, 2) if per_step > 0 else None}
         dom = max(ofk.STAGES, key=lambda s: prof[s][0])
-        dom_ms = prof[dom][0] / max(1, prof[dom][1])
-        achieved = ab[dom] * B / (dom_ms * 1e-3) / 1e9
+        slices = max(1, prof[dom][1] // max(1, args.steps))       # event pairs (= stage launches) per step
+        dom_ms = prof[dom][0] / max(1, prof[dom][1])             # mean duration of one bracketed launch group
+        achieved = ab[dom] * (B / slices) / (dom_ms * 1e-3) / 1e9
         line = {
             "metric": "frame-pairs/sec @1920x1080 (LK+velocity)",
             "value": round(world * B * args.steps / dt, 2),
@@ -178,11 +198,12 @@ def main():
             "dtype": "u8/i32 image stages, f32 LK solve, f64 velocity solve",
             "data": "synthetic",
             "config": {"workload": "1920x1080 frame pairs, 500 Shi-Tomasi corners, 3-level LK pyramid (BASELINE configs[1])",
-                       "pairs_per_gpu_per_step": B, "corners_mean": round(n_pts, 1), "candidates_mean": round(n_cand, 1), "win": cfg.win, "max_level": cfg.max_level,
+                       "pairs_per_gpu_per_step": B, "streams_per_gpu": args.streams, "corners_mean": round(n_pts, 1), "candidates_mean": round(n_cand, 1), "win": cfg.win, "max_level": cfg.max_level,
                        "sharding": f"{world} x independent pair batches, all_gather of [B,8] f32 records"},
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "algorithmic_bytes_per_launch": int(ab[dom] * B), "avg_ms": round(dom_ms, 4)},
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom, B / slices),
+                         "algorithmic_bytes_per_launch": int(ab[dom] * B / slices), "avg_ms": round(dom_ms, 4)},
+            "pipeline_algorithmic_GBps": round(sum(ab.values()) * world * B * args.steps / dt / 1e9, 1),
             "stages": stages,
             "velocity_sample": [round(float(x), 6) for x in rec[0, :3]],
             "velocity_truth": list(truth["v"]),

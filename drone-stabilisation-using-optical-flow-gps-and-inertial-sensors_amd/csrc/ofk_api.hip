@@ -94,6 +94,16 @@ extern "C" int ofk_create(int device, int max_w, int max_h, int max_batch, int m
     c->img_stride = up(c->P, 64);
     c->cand_cap = (int)(c->P / 4 < 4096 ? 4096 : c->P / 4);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { free(c); return ofk_fail(nullptr, OFK_E_HIP, "hipStreamCreate failed"); }
+    c->nstreams = 1;
+    c->streams[0] = c->stream;
+    for (int k = 1; k < OFK_MAX_STREAMS; ++k) {
+        if (hipStreamCreateWithFlags(&c->streams[k], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming) != hipSuccess) {
+            ofk_fail(nullptr, OFK_E_HIP, "hipStreamCreate (slice stream %d) failed", k);
+            ofk_destroy(c);
+            return OFK_E_HIP;
+        }
+    }
+    hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     const size_t B = (size_t)max_batch;
     for (int k = 0; k < 2; ++k) { ALLOC(c->bgr[k], B * c->bgr_stride); ALLOC(c->pyr[k], B * c->pyr_stride); }
     ALLOC(c->eig, B * c->img_stride * sizeof(float));
@@ -121,7 +131,7 @@ extern "C" int ofk_destroy(ofk_ctx *c)
 {
     if (!c) return OFK_OK;
     hipSetDevice(c->device);
-    if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->stream) hipDeviceSynchronize();
     for (int k = 0; k < 2; ++k) { if (c->bgr[k]) hipFree(c->bgr[k]); if (c->pyr[k]) hipFree(c->pyr[k]); }
     void *ptrs[] = {c->eig, c->mask, c->deriv, c->cand, c->cand_seg, c->seg_count, c->cand_count, c->maxbits, c->pts_prev, c->pts_next, c->status, c->err,
                     c->counts, c->sensors, c->records, c->dev_flags, c->scratch};
@@ -129,6 +139,8 @@ extern "C" int ofk_destroy(ofk_ctx *c)
     if (c->hstage) hipHostFree(c->hstage);
     if (c->ev) { for (int i = 0; i < c->ev_cap; ++i) if (c->ev[i]) hipEventDestroy(c->ev[i]); free(c->ev); }
     free(c->ev_stage);
+    for (int k = 1; k < OFK_MAX_STREAMS; ++k) { if (c->streams[k]) hipStreamDestroy(c->streams[k]); if (c->ev_join[k]) hipEventDestroy(c->ev_join[k]); }
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->stream) hipStreamDestroy(c->stream);
     free(c);
     return OFK_OK;
@@ -542,20 +554,20 @@ extern "C" int ofk_pairs_set_sensors(ofk_ctx *c, const double *sensors, int batc
 }
 
 struct StageTimer {
-    ofk_ctx *c; int stage; bool on;
-    StageTimer(ofk_ctx *c_, int st) : c(c_), stage(st), on(((c_->prof_mask >> st) & 1) && c_->ev_n + 2 <= c_->ev_cap)
+    ofk_ctx *c; int stage; bool on; hipStream_t st; int slot;
+    StageTimer(ofk_ctx *c_, int stg, hipStream_t s) : c(c_), stage(stg), on(((c_->prof_mask >> stg) & 1) && c_->ev_n + 2 <= c_->ev_cap), st(s), slot(c_->ev_n)
     {
         if (!on) return;
-        if (!c->ev[c->ev_n]) hipEventCreate(&c->ev[c->ev_n]);
-        if (!c->ev[c->ev_n + 1]) hipEventCreate(&c->ev[c->ev_n + 1]);
-        hipEventRecord(c->ev[c->ev_n], c->stream);
+        c->ev_n += 2;
+        if (!c->ev[slot]) hipEventCreate(&c->ev[slot]);
+        if (!c->ev[slot + 1]) hipEventCreate(&c->ev[slot + 1]);
+        hipEventRecord(c->ev[slot], st);
     }
     ~StageTimer()
     {
         if (!on) return;
-        hipEventRecord(c->ev[c->ev_n + 1], c->stream);
-        c->ev_stage[c->ev_n / 2] = stage;
-        c->ev_n += 2;
+        hipEventRecord(c->ev[slot + 1], st);
+        c->ev_stage[slot / 2] = stage;
     }
 };
 
@@ -570,39 +582,67 @@ extern "C" int ofk_pairs_run(ofk_ctx *c, const ofk_params *p)
     TRY(check_lk(c, h, w, p->win, p->max_level));
     if (p->solve_variant != OFK_SOLVE_NODE && p->solve_variant != OFK_SOLVE_SIM) return ofk_fail(c, OFK_E_INVALID, "solve_variant must be NODE or SIM");
     const ofk_levels lv = ofk_make_levels(h, w, p->win, p->max_level);
-    int nseg = 0, segcap = 0;
-    {
-        StageTimer t(c, OFK_STAGE_GRAY);
-        ofk_launch_gray(c->stream, c->bgr[0], c->bgr_stride, c->pyr[0], c->pyr_stride, B, h, w);
-        ofk_launch_gray(c->stream, c->bgr[1], c->bgr_stride, c->pyr[1], c->pyr_stride, B, h, w);
+    // The batch is cut into `nstreams` contiguous slices, each running the whole stage chain on its own stream: the
+    // latency-bound stages of one slice (corner selection: one workgroup per image; the per-pair solve) overlap with the
+    // streaming stages of the others.  Pairs are independent, so slices share nothing.
+    const int S = c->nstreams < 1 ? 1 : (c->nstreams > B ? B : c->nstreams);
+    if (S > 1) {
+        hipEventRecord(c->ev_fork, c->stream);
+        for (int k = 1; k < S; ++k) hipStreamWaitEvent(c->streams[k], c->ev_fork, 0);
     }
-    {
-        StageTimer t(c, OFK_STAGE_PYR);
-        build_pyramids(c, lv, B, 3);
-    }
-    {
-        StageTimer t(c, OFK_STAGE_EIG);                          // response + 3x3 NMS + candidate keys, no map in HBM
-        hipMemsetAsync(c->maxbits, 0, (size_t)B * OFK_MAX_STRIDE * 4, c->stream);
-        hipMemsetAsync(c->cand_count, 0, (size_t)B * OFK_CNT_STRIDE * 4, c->stream);
-        if (ofk_launch_mineig_cand(c->stream, c->pyr[0], c->pyr_stride, h, w, p->block_size, c->maxbits, nullptr, 0, p->quality, c->cand,
-                                   c->cand_cap, c->cand_count, c->cand_seg, c->seg_keys, c->seg_count, OFK_SEG_MAX, c->dev_flags, B,
-                                   &nseg, &segcap))
-            return ofk_fail(c, OFK_E_INVALID, "corner response: block_size %d does not fit (LDS tile / key segments)", p->block_size);
-    }
-    {
-        StageTimer t(c, OFK_STAGE_SELECT);
-        ofk_launch_select(c->stream, c->cand, c->cand_cap, c->cand_count, c->cand_seg, segcap, c->seg_count, nseg, c->maxbits, p->quality,
-                          w, p->max_corners, (float)p->min_distance, c->pts_prev, c->max_pts, c->counts, B);
-    }
-    {
-        StageTimer t(c, OFK_STAGE_LK);
-        ofk_launch_lk(c->stream, c->pyr[0], c->pyr[1], c->pyr_stride, lv, c->pts_prev, c->counts, c->max_pts, p->win, p->max_count,
-                      p->eps, p->min_eig_thr, c->pts_next, c->status, c->err, B);
-    }
-    {
-        StageTimer t(c, OFK_STAGE_SOLVE);
-        ofk_launch_pairs_solve(c->stream, c->pts_prev, c->pts_next, c->status, c->counts, c->max_pts, c->sensors, p->solve_variant,
-                               p->use_feasibility, p->feas_T, c->cand_count, c->records, B);
+    for (int k = 0; k < S; ++k) {
+        const int b0 = (int)((long long)B * k / S), nb = (int)((long long)B * (k + 1) / S) - b0;
+        if (nb <= 0) continue;
+        hipStream_t st = k == 0 ? c->stream : c->streams[k];
+        uint8_t *bgr0 = c->bgr[0] + (size_t)b0 * c->bgr_stride, *bgr1 = c->bgr[1] + (size_t)b0 * c->bgr_stride;
+        uint8_t *pyr0 = c->pyr[0] + (size_t)b0 * c->pyr_stride, *pyr1 = c->pyr[1] + (size_t)b0 * c->pyr_stride;
+        unsigned int *maxbits = c->maxbits + (size_t)b0 * OFK_MAX_STRIDE;
+        int *cand_count = c->cand_count + (size_t)b0 * OFK_CNT_STRIDE;
+        unsigned long long *cand = c->cand + (size_t)b0 * c->cand_cap, *cand_seg = c->cand_seg + (size_t)b0 * c->seg_keys;
+        int *seg_count = c->seg_count + (size_t)b0 * OFK_SEG_MAX;
+        float *pts_prev = c->pts_prev + (size_t)b0 * c->max_pts * 2, *pts_next = c->pts_next + (size_t)b0 * c->max_pts * 2;
+        uint8_t *status = c->status + (size_t)b0 * c->max_pts;
+        float *err = c->err + (size_t)b0 * c->max_pts;
+        int *counts = c->counts + b0;
+        int nseg = 0, segcap = 0;
+        {
+            StageTimer t(c, OFK_STAGE_GRAY, st);
+            ofk_launch_gray(st, bgr0, c->bgr_stride, pyr0, c->pyr_stride, nb, h, w);
+            ofk_launch_gray(st, bgr1, c->bgr_stride, pyr1, c->pyr_stride, nb, h, w);
+        }
+        {
+            StageTimer t(c, OFK_STAGE_PYR, st);
+            for (int l = 1; l <= lv.n; ++l)
+                ofk_launch_pyr_down2(st, pyr0 + lv.off[l - 1], pyr1 + lv.off[l - 1], c->pyr_stride, lv.h[l - 1], lv.w[l - 1], pyr0 + lv.off[l],
+                                     pyr1 + lv.off[l], c->pyr_stride, nb);
+        }
+        {
+            StageTimer t(c, OFK_STAGE_EIG, st);                  // response + 3x3 NMS + candidate keys, no map in HBM
+            hipMemsetAsync(maxbits, 0, (size_t)nb * OFK_MAX_STRIDE * 4, st);
+            hipMemsetAsync(cand_count, 0, (size_t)nb * OFK_CNT_STRIDE * 4, st);
+            if (ofk_launch_mineig_cand(st, pyr0, c->pyr_stride, h, w, p->block_size, maxbits, nullptr, 0, p->quality, cand, c->cand_cap,
+                                       cand_count, cand_seg, c->seg_keys, seg_count, OFK_SEG_MAX, c->dev_flags, nb, &nseg, &segcap))
+                return ofk_fail(c, OFK_E_INVALID, "corner response: block_size %d does not fit (LDS tile / key segments)", p->block_size);
+        }
+        {
+            StageTimer t(c, OFK_STAGE_SELECT, st);
+            ofk_launch_select(st, cand, c->cand_cap, cand_count, cand_seg, segcap, seg_count, nseg, maxbits, p->quality, w, p->max_corners,
+                              (float)p->min_distance, pts_prev, c->max_pts, counts, nb);
+        }
+        {
+            StageTimer t(c, OFK_STAGE_LK, st);
+            ofk_launch_lk(st, pyr0, pyr1, c->pyr_stride, lv, pts_prev, counts, c->max_pts, p->win, p->max_count, p->eps, p->min_eig_thr,
+                          pts_next, status, err, nb);
+        }
+        {
+            StageTimer t(c, OFK_STAGE_SOLVE, st);
+            ofk_launch_pairs_solve(st, pts_prev, pts_next, status, counts, c->max_pts, c->sensors + (size_t)b0 * OFK_SENSOR_DOUBLES,
+                                   p->solve_variant, p->use_feasibility, p->feas_T, cand_count, c->records + (size_t)b0 * OFK_RECORD_DOUBLES, nb);
+        }
+        if (k > 0) {                                             // join: the context's stream waits for the slice
+            hipEventRecord(c->ev_join[k], st);
+            hipStreamWaitEvent(c->stream, c->ev_join[k], 0);
+        }
     }
     return check_launch(c, "ofk_pairs_run");
 }
@@ -635,6 +675,13 @@ extern "C" int ofk_pairs_export_records_f32(ofk_ctx *c, void *device_dst, int ba
     if (!c || !device_dst || batch < 1 || batch > c->cur_batch) return ofk_fail(c, OFK_E_INVALID, "ofk_pairs_export_records_f32: bad argument");
     ofk_launch_records_f32(c->stream, c->records, (float *)device_dst, batch);
     return check_launch(c, "k_records_f32");
+}
+
+extern "C" int ofk_set_streams(ofk_ctx *c, int nstreams)
+{
+    if (!c || nstreams < 1 || nstreams > OFK_MAX_STREAMS) return ofk_fail(c, OFK_E_INVALID, "ofk_set_streams: 1..%d", OFK_MAX_STREAMS);
+    c->nstreams = nstreams;
+    return OFK_OK;
 }
 
 extern "C" int ofk_profile_enable(ofk_ctx *c, int stage_mask)

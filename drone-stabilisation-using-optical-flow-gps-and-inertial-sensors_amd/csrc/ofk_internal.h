@@ -7,6 +7,7 @@
 #include "ofk.h"
 
 #define OFK_MAX_LEVELS 9            // level 0 .. 8
+#define OFK_MAX_STREAMS 8           // slices of a batch that run their stage chains concurrently
 #define OFK_CHUNK 4096              // candidates sorted per selection round (LDS resident)
 #define OFK_SEG_MAX 2048            // segments (strips) per image the selection kernel walks
 #define OFK_MAX_STRIDE 128          // ints between per-image response maxima: one L2 channel each (a packed array was a hot spot)
@@ -20,7 +21,9 @@ struct ofk_levels {
 
 struct ofk_ctx {
     int device;
-    hipStream_t stream;
+    hipStream_t stream;                           // the context's stream (slice 0); entry points synchronise on it
+    hipStream_t streams[OFK_MAX_STREAMS]; int nstreams;   // extra slice streams, joined back into `stream` by events
+    hipEvent_t ev_fork, ev_join[OFK_MAX_STREAMS];
     int max_w, max_h, max_batch, max_pts, max_level;
     size_t P;                       // max_w * max_h
     size_t bgr_stride;              // bytes between images in bgr[], 256-B aligned

@@ -26,7 +26,8 @@ SYMBOLS = (
     "ofk_gray_bgr8", "ofk_pyr_down_u8", "ofk_scharr_s16", "ofk_mineig_response", "ofk_select_corners",
     "ofk_good_features", "ofk_lk_pyr", "ofk_flow_model", "ofk_feasibility", "ofk_velocity_solve", "ofk_imu_propagate",
     "ofk_post_solve", "ofk_kf_predict_update", "ofk_of_simulation", "ofk_pairs_upload", "ofk_pairs_set_sensors",
-    "ofk_pairs_run", "ofk_pairs_download", "ofk_pairs_export_records_f32", "ofk_profile_enable", "ofk_profile_read",
+    "ofk_pairs_run", "ofk_pairs_download", "ofk_pairs_export_records_f32", "ofk_set_streams", "ofk_profile_enable",
+    "ofk_profile_read",
 )
 
 
@@ -81,6 +82,7 @@ def load_library():
         L.ofk_pairs_run.argtypes = [vp, C.POINTER(Params)]
         L.ofk_pairs_download.argtypes = [vp, vp, vp, vp, vp, vp, vp]
         L.ofk_pairs_export_records_f32.argtypes = [vp, vp, i]
+        L.ofk_set_streams.argtypes = [vp, i]
         L.ofk_profile_enable.argtypes = [vp, i]
         L.ofk_profile_read.argtypes = [vp, vp, vp]
         for s in SYMBOLS:
@@ -373,6 +375,9 @@ class Context:
     def pairs_export_records_f32(self, device_ptr, batch):
         with self._lock:
             self._ck(self._L.ofk_pairs_export_records_f32(self._h, C.c_void_p(int(device_ptr)), int(batch)))
+
+    def set_streams(self, n):
+        self._ck(self._L.ofk_set_streams(self._h, int(n)))
 
     def profile_enable(self, mask):
         self._ck(self._L.ofk_profile_enable(self._h, int(mask)))

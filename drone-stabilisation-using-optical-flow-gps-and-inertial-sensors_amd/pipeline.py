@@ -54,11 +54,13 @@ class PipelineConfig:
 
 
 class FlowPipeline:
-    def __init__(self, width, height, batch=1, cfg=None, device=0):
+    def __init__(self, width, height, batch=1, cfg=None, device=0, streams=1):
         self.cfg = cfg or PipelineConfig.baseline_1080p()
         self.batch = batch
         self.ctx = ofk.Context(device, width, height, batch, max(1, self.cfg.max_corners), max(0, self.cfg.max_level))
         self._params = self.cfg.to_params()
+        if streams > 1:
+            self.ctx.set_streams(streams)
 
     def upload(self, prev_bgr, next_bgr, sensors):
         self.ctx.pairs_upload(prev_bgr, next_bgr)

@@ -182,6 +182,10 @@ int ofk_pairs_download(ofk_ctx *ctx, double *records, float *prev_pts, float *ne
  * DEVICE pointer owned by the caller (the buffer an RCCL all_gather sends), asynchronously on the context's stream. */
 int ofk_pairs_export_records_f32(ofk_ctx *ctx, void *device_dst, int batch);
 
+/* Number of concurrent slices ofk_pairs_run cuts the batch into (1..8, default 1): each slice runs the whole stage chain on
+ * its own HIP stream so that latency-bound stages overlap with streaming ones; results do not depend on it. */
+int ofk_set_streams(ofk_ctx *ctx, int nstreams);
+
 /* Per-stage HIP-event timing on the context's stream. */
 #define OFK_STAGE_GRAY    0
 #define OFK_STAGE_PYR     1

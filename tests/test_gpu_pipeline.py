@@ -78,6 +78,28 @@ def test_pairs_feasibility_filter_and_rerun_idempotent(pkg, ofk):
     pipe.close()
 
 
+def test_streams_do_not_change_results(pkg, ofk):
+    """Cutting the batch into concurrent slices (HIP streams) is a scheduling choice only: bit-identical outputs."""
+    from of_amd import synth
+    from of_amd.pipeline import FlowPipeline, PipelineConfig
+    prev, nxt, base = synth.make_batch(5, 240, 320, seed=90, distinct=5)
+    sensors = ofk.make_sensors(5, scaling=base[0]["scaling"], cx=base[0]["cx"], cy=base[0]["cy"])
+    cfg = PipelineConfig(max_corners=80, quality=0.03, min_distance=6)
+    outs = []
+    for streams in (1, 2, 4, 8):
+        pipe = FlowPipeline(320, 240, 5, cfg, streams=streams)
+        pipe.upload(prev, nxt, sensors)
+        outs.append(pipe.run())
+        pipe.close()
+    for o in outs[1:]:
+        assert np.array_equal(o["counts"], outs[0]["counts"])
+        for b in range(5):
+            n = int(o["counts"][b])
+            for k in ("prev_pts", "next_pts", "status", "err"):
+                assert np.array_equal(o[k][b, :n], outs[0][k][b, :n]), k
+        assert np.array_equal(o["records"], outs[0]["records"])
+
+
 def test_profile_and_export(pkg, ofk):
     from of_amd import synth
     from of_amd.pipeline import FlowPipeline, PipelineConfig
