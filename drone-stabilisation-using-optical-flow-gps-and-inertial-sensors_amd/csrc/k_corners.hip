@@ -644,6 +644,12 @@ void ofk_launch_nms(hipStream_t s, const float *eig, size_t eig_stride, const ui
 #define SEL_T 1024
 #define SEL_BINS 2048
 
+#ifdef OFK_SEL_STAMPS
+__device__ long long *g_stamps;
+#define OFK_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_stamps[k] = clock64(); } while (0)
+#else
+#define OFK_STAMP(k) do { } while (0)
+#endif
 __global__ __launch_bounds__(SEL_T) void k_select(unsigned long long *__restrict__ cand_all, int cand_cap,
                                                   int *__restrict__ cand_count, const unsigned long long *__restrict__ seg,
                                                   int seg_cap, const int *__restrict__ seg_count, int nseg,
@@ -656,9 +662,11 @@ __global__ __launch_bounds__(SEL_T) void k_select(unsigned long long *__restrict
     __shared__ int s_acc_xy[4096];                              // accepted corners, x | y<<16 (max_corners <= 4096)
     __shared__ unsigned long long s_rej[SEL_T / 64];            // per-wave reject ballots of the current 64-candidate round
     __shared__ unsigned s_wsum[SEL_T / 64];
+    __shared__ unsigned long long s_conf[64];                   // conflict matrix of the current greedy round
     __shared__ int s_n, s_nacc, s_D, s_cum;
 
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    OFK_STAMP(0);
     unsigned long long *cand = cand_all + (size_t)b * cand_cap;
     const unsigned mb = maxbits[b * OFK_MAX_STRIDE];
     if (tid == 0) { s_nacc = 0; s_n = 0; counts[b] = 0; }
@@ -675,19 +683,58 @@ __global__ __launch_bounds__(SEL_T) void k_select(unsigned long long *__restrict
         // the streaming response kernel left one segment of keys per strip, pruned with a running threshold only:
         // compact the keys that pass the exact threshold into the flat list (one LDS atomic per wave-iteration)
         const unsigned long long *sbase = seg + (size_t)b * nseg * seg_cap;
-        for (int sg = wave; sg < nseg; sg += SEL_T / 64) {
-            const int n = min(seg_count[(size_t)b * nseg + sg], seg_cap);
-            for (int i0 = 0; i0 < n; i0 += 64) {
-                const int i = i0 + lane;
-                const unsigned long long key = i < n ? sbase[(size_t)sg * seg_cap + i] : ~0ull;
-                const bool keep = key < kend;
+        // flat index over all segments: counts -> LDS, inclusive prefix (2 entries per thread), then every thread fetches
+        // independent keys (binary search for its segment), so the loads of a whole pass are in flight together
+        int *s_cnt = reinterpret_cast<int *>(s_hist);           // [SEL_BINS >= nseg]
+        int *s_pre = reinterpret_cast<int *>(s_key);            // aliases the sort buffer (unused until the first gather)
+        for (int i = tid; i < SEL_BINS; i += SEL_T) s_cnt[i] = i < nseg ? min(seg_count[(size_t)b * nseg + i], seg_cap) : 0;
+        __syncthreads();
+        int N;
+        {
+            const int h0 = s_cnt[2 * tid], h1 = s_cnt[2 * tid + 1];
+            int incl = h0 + h1;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int n_ = __shfl_up(incl, o); if (lane >= o) incl += n_; }
+            if (lane == 63) s_wsum[wave] = (unsigned)incl;
+            __syncthreads();
+            int woff = 0, total = 0;
+            for (int q = 0; q < SEL_T / 64; ++q) { const int ws = (int)s_wsum[q]; if (q < wave) woff += ws; total += ws; }
+            s_pre[2 * tid + 1] = woff + incl; s_pre[2 * tid] = woff + incl - h1;
+            N = total;
+        }
+        __syncthreads();
+        // each wave owns a contiguous range of the flat index and walks it 4 x 64 keys at a time: one binary search per
+        // wave, a short forward scan per lane, four independent global loads in flight before the first is consumed
+        const int per_wave = (((N + SEL_T / 64 - 1) / (SEL_T / 64)) + 63) & ~63;
+        const int jbeg = min(N, wave * per_wave), jend = min(N, jbeg + per_wave);
+        int sg_w = 0;
+        {
+            int lo = 0, hi = nseg - 1;                          // smallest sg with s_pre[sg] > jbeg
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_pre[mid] > jbeg) hi = mid; else lo = mid + 1; }
+            sg_w = __builtin_amdgcn_readfirstlane(lo);
+        }
+        for (int j0 = jbeg; j0 < jend; j0 += 256) {
+            unsigned long long key[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int j = j0 + 64 * q + lane;
+                const bool valid = j < jend;
+                int sg = sg_w;
+                while (valid && s_pre[sg] <= j) ++sg;
+                if (q == 0) sg_w = __builtin_amdgcn_readfirstlane(sg);     // lane 0 of the first chunk: lower bound for what follows
+                const int off = j - (sg ? s_pre[sg - 1] : 0);
+                key[q] = valid ? sbase[(size_t)sg * seg_cap + off] : ~0ull;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool keep = key[q] < kend;
                 const unsigned long long bal = __ballot(keep);
                 if (bal) {
                     int base = 0;
                     if (lane == 0) base = atomicAdd(&s_n, __popcll(bal));
                     base = __builtin_amdgcn_readfirstlane(base);
                     const int pos = base + __popcll(bal & ((1ull << lane) - 1));
-                    if (keep && pos < cand_cap) cand[pos] = key;
+                    if (keep && pos < cand_cap) cand[pos] = key[q];
                 }
             }
         }
@@ -700,9 +747,13 @@ __global__ __launch_bounds__(SEL_T) void k_select(unsigned long long *__restrict
         C = min(cand_count[b * OFK_CNT_STRIDE], cand_cap);
     }
     if (C == 0 || !(thr < __uint_as_float(mb))) return;         // nothing is strictly above the threshold
+    OFK_STAMP(1);
 
+    // keys handled per round: about twice the corners still wanted (sorting 4096 keys to accept 500 wasted 2/3 of the sort)
+    int tgt = 512;
+    while (tgt < 2 * max_corners && tgt < OFK_CHUNK) tgt <<= 1;
     while (a < kend) {
-        // ---- choose T in (a, kend] so that 1 <= #{a <= key < T} <= OFK_CHUNK (or detect that none is left)
+        // ---- choose T in (a, kend] so that 1 <= #{a <= key < T} <= tgt (or detect that none is left)
         unsigned long long curA = a, curB = kend, T = kend;
         int taken = 0;
         bool none_left = false;
@@ -728,7 +779,7 @@ __global__ __launch_bounds__(SEL_T) void k_select(unsigned long long *__restrict
             unsigned woff = 0, total = 0;
             for (int q = 0; q < SEL_T / 64; ++q) { const unsigned ws = s_wsum[q]; if (q < wave) woff += ws; total += ws; }
             const unsigned i1 = woff + incl, i0 = i1 - h1;      // inclusive prefixes of bins 2*tid and 2*tid+1
-            const int budget = OFK_CHUNK - taken;
+            const int budget = tgt - taken;
             const int fit = ((int)i0 <= budget) + ((int)i1 <= budget);
             if (fit) atomicAdd(&s_D, fit);
             __syncthreads();
@@ -739,12 +790,13 @@ __global__ __launch_bounds__(SEL_T) void k_select(unsigned long long *__restrict
             if (level == 0 && total == 0) { none_left = true; break; }
             if (D >= nb) { T = curB; break; }                  // everything in [curA, curB) fits
             const unsigned long long newA = curA + ((unsigned long long)D << shift);
-            if (taken >= OFK_CHUNK / 8) { T = newA; break; }
+            if (taken >= tgt / 4) { T = newA; break; }
             curA = newA;                                        // descend into the first bin that did not fit
             const unsigned long long bin_end = newA + (1ull << shift);
             if (bin_end < curB) curB = bin_end;
         }
         if (none_left) break;
+        OFK_STAMP(2);
         // ---- gather keys in [a, T)
         __syncthreads();
         if (tid == 0) s_n = 0;
@@ -759,7 +811,10 @@ __global__ __launch_bounds__(SEL_T) void k_select(unsigned long long *__restrict
         while (npad < n) npad <<= 1;
         for (int i = n + tid; i < npad; i += SEL_T) s_key[i] = ~0ull;
         __syncthreads();
+        OFK_STAMP(3);
         // ---- bitonic sort ascending
+        // (element i belongs to thread i % 1024, so for j < 64 both partners of a compare-exchange sit in the same wave:
+        //  those steps need no workgroup barrier — LDS executes a wave's accesses in order)
         for (int kk = 2; kk <= npad; kk <<= 1)
             for (int j = kk >> 1; j > 0; j >>= 1) {
                 for (int i = tid; i < npad; i += SEL_T) {
@@ -770,8 +825,10 @@ __global__ __launch_bounds__(SEL_T) void k_select(unsigned long long *__restrict
                         if ((x0 > x1) == up) { s_key[i] = x1; s_key[p] = x0; }
                     }
                 }
-                __syncthreads();
+                if (j >= 64 || j == 1) __syncthreads();         // j == 1 ends a kk stage: the next stage starts with j = kk/2
+                else __builtin_amdgcn_wave_barrier();
             }
+        OFK_STAMP(4);
         // ---- greedy over the sorted chunk, 64 candidates per round
         for (int base = 0; base < n; base += 64) {
             const int nacc = s_nacc;
@@ -780,37 +837,54 @@ __global__ __launch_bounds__(SEL_T) void k_select(unsigned long long *__restrict
             const bool live = ci < n;
             const unsigned idx = live ? (unsigned)(s_key[ci] & 0xffffffffu) : 0u;
             const int cx = (int)(idx % (unsigned)w), cy = (int)(idx / (unsigned)w);
+            // every wave tests the round's 64 candidates against its share of the accepted set (4 independent LDS reads
+            // in flight, no early exit) and builds 4 rows of the round's conflict matrix
             bool rej = false;
-            if (use_dist && live)
-                for (int j = wave; j < nacc; j += SEL_T / 64) {
-                    const int acc = s_acc_xy[j];
-                    const int dx = cx - (acc & 0xffff), dy = cy - (acc >> 16);
-                    if ((float)(dx * dx + dy * dy) < md2) { rej = true; break; }
+            if (use_dist) {
+                for (int j = wave * 4; j < nacc; j += 4 * (SEL_T / 64)) {
+                    const int a0 = s_acc_xy[j], a1 = s_acc_xy[min(j + 1, nacc - 1)], a2 = s_acc_xy[min(j + 2, nacc - 1)],
+                              a3 = s_acc_xy[min(j + 3, nacc - 1)];
+                    const int dx0 = cx - (a0 & 0xffff), dy0 = cy - (a0 >> 16), dx1 = cx - (a1 & 0xffff), dy1 = cy - (a1 >> 16);
+                    const int dx2 = cx - (a2 & 0xffff), dy2 = cy - (a2 >> 16), dx3 = cx - (a3 & 0xffff), dy3 = cy - (a3 >> 16);
+                    rej = rej || (float)(dx0 * dx0 + dy0 * dy0) < md2 || (float)(dx1 * dx1 + dy1 * dy1) < md2 ||
+                          (float)(dx2 * dx2 + dy2 * dy2) < md2 || (float)(dx3 * dx3 + dy3 * dy3) < md2;
                 }
-            const unsigned long long bal = __ballot(rej);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int j = __builtin_amdgcn_readfirstlane(wave) * 4 + q;   // candidate (lane) j of this round
+                    const int jx = __builtin_amdgcn_readlane(cx, j), jy = __builtin_amdgcn_readlane(cy, j);
+                    const int dx = cx - jx, dy = cy - jy;
+                    const unsigned long long bj = __ballot((float)(dx * dx + dy * dy) < md2);
+                    if (lane == 0) s_conf[j] = bj;
+                }
+            }
+            const unsigned long long bal = __ballot(rej && live);
             if (lane == 0) s_rej[wave] = bal;
             __syncthreads();
             if (wave == 0) {
                 unsigned long long r = 0;
 #pragma unroll
                 for (int q = 0; q < SEL_T / 64; ++q) r |= s_rej[q];
-                unsigned long long m = __ballot(live) & ~r;    // survivors of the accepted-set test, best first
-                int na = nacc;
-                while (m && na < max_corners) {
-                    const int win = __ffsll((long long)m) - 1;
-                    const int wx = __shfl(cx, win), wy = __shfl(cy, win);
-                    if (lane == 0) {
-                        s_acc_xy[na] = wx | (wy << 16);
-                        pts[((size_t)b * pts_stride + na) * 2] = (float)wx;
-                        pts[((size_t)b * pts_stride + na) * 2 + 1] = (float)wy;
-                    }
-                    ++na;
-                    const int dx = cx - wx, dy = cy - wy;
-                    const bool clash = use_dist && (float)(dx * dx + dy * dy) < md2;
-                    m &= ~__ballot(clash);
-                    m &= ~(1ull << win);
+                const unsigned long long alive = __ballot(live) & ~r;   // survivors of the accepted-set test, best first
+                const unsigned long long myconf = use_dist ? s_conf[lane] : 0ull;   // lanes clashing with candidate `lane`
+                // the serial greedy pass over <= 64 candidates runs on the scalar unit
+                unsigned long long acc = 0, al = alive;
+                int room = max_corners - nacc;
+                const unsigned clo = (unsigned)myconf, chi = (unsigned)(myconf >> 32);
+                while (al && room > 0) {
+                    const int i = __ffsll((long long)al) - 1;
+                    acc |= 1ull << i; --room;
+                    const unsigned long long ci_ = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)chi, i) << 32) |
+                                                   (unsigned)__builtin_amdgcn_readlane((int)clo, i);
+                    al &= ~(ci_ | (1ull << i));
                 }
-                if (lane == 0) s_nacc = na;
+                if ((acc >> lane) & 1ull) {                      // accepted candidates store in parallel, in rank order
+                    const int pos = nacc + __popcll(acc & ((1ull << lane) - 1));
+                    s_acc_xy[pos] = cx | (cy << 16);
+                    pts[((size_t)b * pts_stride + pos) * 2] = (float)cx;
+                    pts[((size_t)b * pts_stride + pos) * 2 + 1] = (float)cy;
+                }
+                if (lane == 0) s_nacc = nacc + __popcll(acc);
             }
             __syncthreads();
         }
@@ -818,6 +892,7 @@ __global__ __launch_bounds__(SEL_T) void k_select(unsigned long long *__restrict
         a = T;
         __syncthreads();
     }
+    OFK_STAMP(5);
     if (tid == 0) counts[b] = s_nacc;
 }
 

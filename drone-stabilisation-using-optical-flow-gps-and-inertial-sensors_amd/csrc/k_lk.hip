@@ -244,6 +244,14 @@ __device__ __forceinline__ long long wave_sum_rows(int v)
     return (long long)__builtin_amdgcn_readlane(v, 0) + (long long)__builtin_amdgcn_readlane(v, 16) +
            (long long)__builtin_amdgcn_readlane(v, 32) + (long long)__builtin_amdgcn_readlane(v, 48);
 }
+// f32((exact wave sum) * 2^-20): the sum of four int32 row sums is exact in f64, so this equals f32(f64(int64 sum) * 2^-20)
+__device__ __forceinline__ float wave_sum_rows_scaled(int v)
+{
+    v = row_sum16(v);
+    const double d = ((double)__builtin_amdgcn_readlane(v, 0) + (double)__builtin_amdgcn_readlane(v, 16)) +
+                     ((double)__builtin_amdgcn_readlane(v, 32) + (double)__builtin_amdgcn_readlane(v, 48));
+    return (float)(d * 0x1p-20);
+}
 
 // 5 consecutive bytes starting at byte offset `off` of an LDS byte array (4-byte aligned base)
 __device__ __forceinline__ void lds_read5(const uint8_t *base, int off, int t[5])
@@ -251,7 +259,7 @@ __device__ __forceinline__ void lds_read5(const uint8_t *base, int off, int t[5]
     const unsigned *p = reinterpret_cast<const unsigned *>(base + (off & ~3));
     const unsigned d0 = p[0], d1 = p[1];
     const unsigned sh = (unsigned)off & 3u;
-    const unsigned v = (unsigned)(((unsigned long long)d1 << 32 | d0) >> (8 * sh));
+    const unsigned v = __builtin_amdgcn_alignbyte(d1, d0, sh);                 // bytes off .. off+3
     t[0] = v & 255; t[1] = (v >> 8) & 255; t[2] = (v >> 16) & 255; t[3] = v >> 24; t[4] = (d1 >> (8 * sh)) & 255;
 }
 // 7 consecutive bytes starting at `off`
@@ -260,8 +268,7 @@ __device__ __forceinline__ void lds_read7(const uint8_t *base, int off, int t[7]
     const unsigned *p = reinterpret_cast<const unsigned *>(base + (off & ~3));
     const unsigned d0 = p[0], d1 = p[1], d2 = p[2];
     const unsigned sh = (unsigned)off & 3u;
-    const unsigned lo = (unsigned)(((unsigned long long)d1 << 32 | d0) >> (8 * sh));
-    const unsigned hi = (unsigned)(((unsigned long long)d2 << 32 | d1) >> (8 * sh));
+    const unsigned lo = __builtin_amdgcn_alignbyte(d1, d0, sh), hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
     t[0] = lo & 255; t[1] = (lo >> 8) & 255; t[2] = (lo >> 16) & 255; t[3] = lo >> 24;
     t[4] = hi & 255; t[5] = (hi >> 8) & 255; t[6] = (hi >> 16) & 255;
 }
@@ -318,10 +325,10 @@ __global__ __launch_bounds__(64) void k_lk15(const uint8_t *__restrict__ prev, c
                 const unsigned *g = reinterpret_cast<const unsigned *>(J + (addr & ~(size_t)3));
                 const unsigned d0 = g[0], d1 = g[1], d2 = g[2], d3 = g[3], d4 = g[4];
                 uint4 o;
-                o.x = (unsigned)(((unsigned long long)d1 << 32 | d0) >> (8 * sh));
-                o.y = (unsigned)(((unsigned long long)d2 << 32 | d1) >> (8 * sh));
-                o.z = (unsigned)(((unsigned long long)d3 << 32 | d2) >> (8 * sh));
-                o.w = (unsigned)(((unsigned long long)d4 << 32 | d3) >> (8 * sh));
+                o.x = __builtin_amdgcn_alignbyte(d1, d0, sh);
+                o.y = __builtin_amdgcn_alignbyte(d2, d1, sh);
+                o.z = __builtin_amdgcn_alignbyte(d3, d2, sh);
+                o.w = __builtin_amdgcn_alignbyte(d4, d3, sh);
                 *reinterpret_cast<uint4 *>(s_J + r * LKF_JW + 16 * hf) = o;
             } else {
                 for (int i = lane; i < jw_ * jw_; i += 64) {
@@ -343,11 +350,11 @@ __global__ __launch_bounds__(64) void k_lk15(const uint8_t *__restrict__ prev, c
                     const unsigned *g = reinterpret_cast<const unsigned *>(I + (addr & ~(size_t)3));
                     const unsigned d0 = g[0], d1 = g[1], d2 = g[2], d3 = g[3], d4 = g[4], d5 = g[5];
                     unsigned *o = reinterpret_cast<unsigned *>(s_I + lane * LKF_IP);
-                    o[0] = (unsigned)(((unsigned long long)d1 << 32 | d0) >> (8 * sh));
-                    o[1] = (unsigned)(((unsigned long long)d2 << 32 | d1) >> (8 * sh));
-                    o[2] = (unsigned)(((unsigned long long)d3 << 32 | d2) >> (8 * sh));
-                    o[3] = (unsigned)(((unsigned long long)d4 << 32 | d3) >> (8 * sh));
-                    o[4] = (unsigned)(((unsigned long long)d5 << 32 | d4) >> (8 * sh));
+                    o[0] = __builtin_amdgcn_alignbyte(d1, d0, sh);
+                    o[1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
+                    o[2] = __builtin_amdgcn_alignbyte(d3, d2, sh);
+                    o[3] = __builtin_amdgcn_alignbyte(d4, d3, sh);
+                    o[4] = __builtin_amdgcn_alignbyte(d5, d4, sh);
                 }
             } else {
                 for (int i = lane; i < iw_ * iw_; i += 64) {
@@ -384,16 +391,14 @@ __global__ __launch_bounds__(64) void k_lk15(const uint8_t *__restrict__ prev, c
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (k < npx) {
-                    const int iv = descale(n[1][k + 1] * w00 + n[1][k + 2] * w01 + n[2][k + 1] * w10 + n[2][k + 2] * w11, 9);
-                    const int ix = descale(dxv[0][k] * w00 + dxv[0][k + 1] * w01 + dxv[1][k] * w10 + dxv[1][k + 1] * w11, 14);
-                    const int iy = descale(dyv[0][k] * w00 + dyv[0][k + 1] * w01 + dyv[1][k] * w10 + dyv[1][k + 1] * w11, 14);
+                    const int iv = descale(__mul24(n[1][k + 1], w00) + __mul24(n[1][k + 2], w01) + __mul24(n[2][k + 1], w10) + __mul24(n[2][k + 2], w11), 9);
+                    const int ix = descale(__mul24(dxv[0][k], w00) + __mul24(dxv[0][k + 1], w01) + __mul24(dxv[1][k], w10) + __mul24(dxv[1][k + 1], w11), 14);
+                    const int iy = descale(__mul24(dyv[0][k], w00) + __mul24(dyv[0][k + 1], w01) + __mul24(dyv[1][k], w10) + __mul24(dyv[1][k + 1], w11), 14);
                     pI[k] = iv; pIx[k] = ix; pIy[k] = iy;
-                    a11 += ix * ix; a12 += ix * iy; a22 += iy * iy;
+                    a11 += __mul24(ix, ix); a12 += __mul24(ix, iy); a22 += __mul24(iy, iy);
                 }
         }
-        const long long A11s = wave_sum_rows(a11), A12s = wave_sum_rows(a12), A22s = wave_sum_rows(a22);
-        const float A11 = (float)((double)A11s * 0x1p-20), A12 = (float)((double)A12s * 0x1p-20),
-                    A22 = (float)((double)A22s * 0x1p-20);
+        const float A11 = wave_sum_rows_scaled(a11), A12 = wave_sum_rows_scaled(a12), A22 = wave_sum_rows_scaled(a22);
         float D = A11 * A22 - A12 * A12;
         const float dd = A11 - A22;
         const float minEig = (A22 + A11 - sqrtf(dd * dd + 4.f * A12 * A12)) / (float)(2 * ww);
@@ -419,12 +424,11 @@ __global__ __launch_bounds__(64) void k_lk15(const uint8_t *__restrict__ prev, c
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     if (k < npx) {
-                        const int diff = descale(t0[k] * w00 + t0[k + 1] * w01 + t1[k] * w10 + t1[k + 1] * w11, 9) - pI[k];
-                        b1 += diff * pIx[k]; b2 += diff * pIy[k];
+                        const int diff = descale(__mul24(t0[k], w00) + __mul24(t0[k + 1], w01) + __mul24(t1[k], w10) + __mul24(t1[k + 1], w11), 9) - pI[k];
+                        b1 += __mul24(diff, pIx[k]); b2 += __mul24(diff, pIy[k]);
                     }
             }
-            const long long B1 = wave_sum_rows(b1), B2 = wave_sum_rows(b2);
-            const float fb1 = (float)((double)B1 * 0x1p-20), fb2 = (float)((double)B2 * 0x1p-20);
+            const float fb1 = wave_sum_rows_scaled(b1), fb2 = wave_sum_rows_scaled(b2);
             const float dx = (A12 * fb2 - A22 * fb1) * D, dy = (A12 * fb1 - A11 * fb2) * D;
             qx += dx; qy += dy;
             nx = qx + half; ny = qy + half;
@@ -449,7 +453,7 @@ __global__ __launch_bounds__(64) void k_lk15(const uint8_t *__restrict__ prev, c
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     if (k < npx) {
-                        const int diff = descale(t0[k] * w00 + t0[k + 1] * w01 + t1[k] * w10 + t1[k + 1] * w11, 9) - pI[k];
+                        const int diff = descale(__mul24(t0[k], w00) + __mul24(t0[k + 1], w01) + __mul24(t1[k], w10) + __mul24(t1[k + 1], w11), 9) - pI[k];
                         se += diff < 0 ? -diff : diff;
                     }
             }
