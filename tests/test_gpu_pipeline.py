@@ -78,6 +78,30 @@ def test_pairs_feasibility_filter_and_rerun_idempotent(pkg, ofk):
     pipe.close()
 
 
+@pytest.mark.parametrize("h,w,bs", [(257, 333, 7), (479, 641, 3), (250, 322, 5), (300, 404, 12), (240, 320, 9)])
+def test_pairs_pipeline_odd_sizes_and_block_sizes(pkg, ofk, h, w, bs):
+    """Widths that are not multiples of 4 take the byte-granular staging paths; block sizes 3/5/7/12 run the streaming
+    response kernel, 9 the LDS-tile kernel.  All must agree with the oracle bit for bit."""
+    from of_amd import synth
+    from of_amd.pipeline import FlowPipeline, PipelineConfig
+    cfg = PipelineConfig(max_corners=120, quality=0.03, min_distance=7, block_size=bs, win=15, max_level=3)
+    pairs = [synth.render_pair(h, w, 300 + b, v=(0.005, -0.004, 0.002), omega=(0.004, 0.002, -0.005), d=1.0) for b in range(2)]
+    prev = np.stack([p["prev"] for p in pairs]); nxt = np.stack([p["next"] for p in pairs])
+    sensors = np.concatenate([ofk.make_sensors(1, d=1.0, normal=p["n"], omega=p["omega"], scaling=p["scaling"], cx=p["cx"], cy=p["cy"]) for p in pairs])
+    pipe = FlowPipeline(w, h, 2, cfg)
+    pipe.upload(prev, nxt, sensors)
+    out = pipe.run()
+    for b in range(2):
+        ref = oracle_chain(prev[b], nxt[b], cfg, sensors[b])
+        n = int(out["counts"][b])
+        assert n == len(ref["pts"]) and n > 8
+        assert np.array_equal(out["prev_pts"][b, :n], ref["pts"].reshape(-1, 2))
+        assert np.array_equal(out["status"][b, :n], ref["status"].ravel())
+        assert np.array_equal(out["next_pts"][b, :n].view(np.uint32), ref["nxt"].reshape(-1, 2).view(np.uint32))
+        np.testing.assert_allclose(out["records"][b, 0:3], ref["v"], rtol=1e-9, atol=1e-13)
+    pipe.close()
+
+
 def test_streams_do_not_change_results(pkg, ofk):
     """Cutting the batch into concurrent slices (HIP streams) is a scheduling choice only: bit-identical outputs."""
     from of_amd import synth
