@@ -506,6 +506,7 @@ void ofk_stream_geometry(int h, int w, int block, int batch, int *rows, int *nse
     const int SW = 61 - block;
     const int strips = (w + SW - 1) / SW;
     int r = batch >= 16 ? 128 : 32;                             // fewer, longer strips when the batch already fills the chip
+    if (const char *e = getenv("OFK_EIG_ROWS")) { const int v = atoi(e); if (v >= 8 && v <= 4096) r = v; }   // tuning knob
     while (strips * ((h + r - 1) / r) > 2048) r *= 2;           // k_select walks at most 2048 segments per image
     *rows = r; *nseg = strips * ((h + r - 1) / r);
     *seg_cap = ((SW * r / 4 + 64 + 63) / 64) * 64;              // strict local maxima fill at most a quarter of the strip
@@ -654,9 +655,12 @@ __global__ __launch_bounds__(SEL_T) void k_select(unsigned long long *__restrict
                                                   int *__restrict__ cand_count, const unsigned long long *__restrict__ seg,
                                                   int seg_cap, const int *__restrict__ seg_count, int nseg,
                                                   const unsigned int *__restrict__ maxbits, double quality, int w,
-                                                  int max_corners, float min_distance, float *__restrict__ pts, int pts_stride,
-                                                  int *__restrict__ counts)
+                                                  int max_corners_all, float min_distance, float *__restrict__ pts, int pts_stride,
+                                                  int *__restrict__ counts, const int *__restrict__ limit)
 {
+    // per-image corner budget (re-detection appends only what a stream is missing); <= 0: nothing to do for this image
+    const int max_corners = limit ? min(max_corners_all, limit[blockIdx.x]) : max_corners_all;
+    if (max_corners <= 0) { if (threadIdx.x == 0) { counts[blockIdx.x] = 0; if (nseg > 0) cand_count[blockIdx.x * OFK_CNT_STRIDE] = 0; } return; }
     __shared__ unsigned long long s_key[OFK_CHUNK];
     __shared__ unsigned s_hist[SEL_BINS];
     __shared__ int s_acc_xy[4096];                              // accepted corners, x | y<<16 (max_corners <= 4096)
@@ -741,6 +745,10 @@ __global__ __launch_bounds__(SEL_T) void k_select(unsigned long long *__restrict
         __syncthreads();
         C = min(s_n, cand_cap);
         if (tid == 0) cand_count[b * OFK_CNT_STRIDE] = s_n;
+        if (s_n > cand_cap) {                                   // flat list overflow (uniform): the host reports OFK_E_CAPACITY
+            if (tid == 0) counts[b] = -1;
+            return;
+        }
         __threadfence_block();
         __syncthreads();
     } else {
@@ -898,8 +906,8 @@ __global__ __launch_bounds__(SEL_T) void k_select(unsigned long long *__restrict
 
 void ofk_launch_select(hipStream_t s, unsigned long long *cand, int cand_cap, int *cand_count, const unsigned long long *seg,
                        int seg_cap, const int *seg_count, int nseg, const unsigned int *maxbits, double quality, int w,
-                       int max_corners, float min_distance, float *pts, int pts_stride, int *counts, int batch)
+                       int max_corners, float min_distance, float *pts, int pts_stride, int *counts, const int *limit, int batch)
 {
     hipLaunchKernelGGL(k_select, dim3(batch), dim3(SEL_T), 0, s, cand, cand_cap, cand_count, seg, seg_cap, seg_count, nseg, maxbits,
-                       quality, w, max_corners, min_distance, pts, pts_stride, counts);
+                       quality, w, max_corners, min_distance, pts, pts_stride, counts, limit);
 }

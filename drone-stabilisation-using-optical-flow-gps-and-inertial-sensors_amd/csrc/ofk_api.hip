@@ -134,11 +134,12 @@ extern "C" int ofk_destroy(ofk_ctx *c)
     if (c->stream) hipDeviceSynchronize();
     for (int k = 0; k < 2; ++k) { if (c->bgr[k]) hipFree(c->bgr[k]); if (c->pyr[k]) hipFree(c->pyr[k]); }
     void *ptrs[] = {c->eig, c->mask, c->deriv, c->cand, c->cand_seg, c->seg_count, c->cand_count, c->maxbits, c->pts_prev, c->pts_next, c->status, c->err,
-                    c->counts, c->sensors, c->records, c->dev_flags, c->scratch};
+                    c->counts, c->sensors, c->records, c->dev_flags, c->scratch, c->pts_new, c->new_counts, c->limit};
     for (void *p : ptrs) if (p) hipFree(p);
     if (c->hstage) hipHostFree(c->hstage);
     if (c->ev) { for (int i = 0; i < c->ev_cap; ++i) if (c->ev[i]) hipEventDestroy(c->ev[i]); free(c->ev); }
     free(c->ev_stage);
+    free(c->h_counts);
     for (int k = 1; k < OFK_MAX_STREAMS; ++k) { if (c->streams[k]) hipStreamDestroy(c->streams[k]); if (c->ev_join[k]) hipEventDestroy(c->ev_join[k]); }
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -274,7 +275,7 @@ static int run_select(ofk_ctx *c, bool have_max, const uint8_t *dmask, int batch
     ofk_launch_nms(c->stream, c->eig, c->img_stride, dmask, c->img_stride, h, w, c->maxbits, quality, c->cand, c->cand_cap,
                    c->cand_count, c->dev_flags, batch);
     ofk_launch_select(c->stream, c->cand, c->cand_cap, c->cand_count, nullptr, 0, nullptr, 0, c->maxbits, quality, w, max_corners,
-                      (float)min_distance, c->pts_prev, c->max_pts, c->counts, batch);
+                      (float)min_distance, c->pts_prev, c->max_pts, c->counts, nullptr, batch);
     return check_launch(c, "corner selection");
 }
 
@@ -284,7 +285,9 @@ static int fetch_corners(ofk_ctx *c, int batch, int max_corners, float *pts, int
     OFK_HIP(c, hipMemcpyAsync(flags, c->dev_flags, 16, hipMemcpyDeviceToHost, c->stream));
     OFK_HIP(c, hipMemcpyAsync(counts, c->counts, (size_t)batch * 4, hipMemcpyDeviceToHost, c->stream));
     TRY(d2h(c, pts, c->pts_prev, (size_t)c->max_pts * 8, (size_t)max_corners * 8, batch));
-    if (flags[0] & 1) {
+    bool over = (flags[0] & 1) != 0;
+    for (int b = 0; b < batch; ++b) if (counts[b] < 0) { over = true; counts[b] = 0; }
+    if (over) {
         hipMemsetAsync(c->dev_flags, 0, 16, c->stream);
         return ofk_fail(c, OFK_E_CAPACITY, "corner candidates exceeded the per-image capacity (%d)", c->cand_cap);
     }
@@ -325,7 +328,7 @@ extern "C" int ofk_good_features(ofk_ctx *c, const uint8_t *gray, const uint8_t 
                                &nseg, &segcap))
         return ofk_fail(c, OFK_E_INVALID, "corner response: block_size %d does not fit (LDS tile / key segments)", block);
     ofk_launch_select(c->stream, c->cand, c->cand_cap, c->cand_count, c->cand_seg, segcap, c->seg_count, nseg, c->maxbits, quality, w,
-                      max_corners, (float)min_distance, c->pts_prev, c->max_pts, c->counts, batch);
+                      max_corners, (float)min_distance, c->pts_prev, c->max_pts, c->counts, nullptr, batch);
     TRY(check_launch(c, "corner detection"));
     if (getenv("OFK_DEBUG")) {
         unsigned mb[4 * OFK_MAX_STRIDE] = {0}; int cc[4 * OFK_CNT_STRIDE] = {0}; int cn[4] = {0};
@@ -627,7 +630,7 @@ extern "C" int ofk_pairs_run(ofk_ctx *c, const ofk_params *p)
         {
             StageTimer t(c, OFK_STAGE_SELECT, st);
             ofk_launch_select(st, cand, c->cand_cap, cand_count, cand_seg, segcap, seg_count, nseg, maxbits, p->quality, w, p->max_corners,
-                              (float)p->min_distance, pts_prev, c->max_pts, counts, nb);
+                              (float)p->min_distance, pts_prev, c->max_pts, counts, nullptr, nb);
         }
         {
             StageTimer t(c, OFK_STAGE_LK, st);
@@ -663,7 +666,10 @@ extern "C" int ofk_pairs_download(ofk_ctx *c, double *records, float *prev_pts, 
     if (err) OFK_HIP(c, hipMemcpyAsync(err, c->err, np * 4, hipMemcpyDeviceToHost, c->stream));
     if (counts) OFK_HIP(c, hipMemcpyAsync(counts, c->counts, (size_t)B * 4, hipMemcpyDeviceToHost, c->stream));
     OFK_HIP(c, hipStreamSynchronize(c->stream));
-    if (flags[0] & 1) {
+    bool over = (flags[0] & 1) != 0;
+    if (counts)
+        for (int b = 0; b < B; ++b) if (counts[b] < 0) { over = true; counts[b] = 0; }
+    if (over) {
         hipMemsetAsync(c->dev_flags, 0, 16, c->stream);
         return ofk_fail(c, OFK_E_CAPACITY, "corner candidates exceeded the per-image capacity (%d)", c->cand_cap);
     }
@@ -675,6 +681,120 @@ extern "C" int ofk_pairs_export_records_f32(ofk_ctx *c, void *device_dst, int ba
     if (!c || !device_dst || batch < 1 || batch > c->cur_batch) return ofk_fail(c, OFK_E_INVALID, "ofk_pairs_export_records_f32: bad argument");
     ofk_launch_records_f32(c->stream, c->records, (float *)device_dst, batch);
     return check_launch(c, "k_records_f32");
+}
+
+// ------------------------------------------------------------------------------------------------ video streams
+static int stream_alloc(ofk_ctx *c)
+{
+    if (!c->pts_new) {
+        OFK_HIP(c, hipMalloc((void **)&c->pts_new, (size_t)c->max_batch * c->max_pts * 8));
+        OFK_HIP(c, hipMalloc((void **)&c->new_counts, (size_t)c->max_batch * 4));
+        OFK_HIP(c, hipMalloc((void **)&c->limit, (size_t)c->max_batch * 4));
+    }
+    return lazy_mask(c);
+}
+
+// gray + pyramid of a batch of BGR frames (host) into pyramid slot k
+static int stream_ingest(ofk_ctx *c, int k, const uint8_t *bgr, int batch, int h, int w, const ofk_levels &lv)
+{
+    TRY(h2d(c, c->bgr[k], c->bgr_stride, bgr, (size_t)h * w * 3, batch));
+    ofk_launch_gray(c->stream, c->bgr[k], c->bgr_stride, c->pyr[k], c->pyr_stride, batch, h, w);
+    for (int l = 1; l <= lv.n; ++l)
+        ofk_launch_pyr_down(c->stream, c->pyr[k] + lv.off[l - 1], c->pyr_stride, lv.h[l - 1], lv.w[l - 1], c->pyr[k] + lv.off[l],
+                            c->pyr_stride, batch);
+    return OFK_OK;
+}
+
+// corners of pyramid slot k (level 0) -> dst/dst_counts, optional mask and per-stream budget
+static int stream_detect(ofk_ctx *c, int k, const uint8_t *dmask, const int *limit, int batch, int h, int w, const ofk_params *p,
+                         float *dst, int *dst_counts)
+{
+    int nseg = 0, segcap = 0;
+    OFK_HIP(c, hipMemsetAsync(c->maxbits, 0, (size_t)batch * OFK_MAX_STRIDE * 4, c->stream));
+    OFK_HIP(c, hipMemsetAsync(c->cand_count, 0, (size_t)batch * OFK_CNT_STRIDE * 4, c->stream));
+    if (ofk_launch_mineig_cand(c->stream, c->pyr[k], c->pyr_stride, h, w, p->block_size, c->maxbits, dmask, c->img_stride, p->quality, c->cand,
+                               c->cand_cap, c->cand_count, c->cand_seg, c->seg_keys, c->seg_count, OFK_SEG_MAX, c->dev_flags, batch, &nseg,
+                               &segcap))
+        return ofk_fail(c, OFK_E_INVALID, "corner response: block_size %d does not fit (LDS tile / key segments)", p->block_size);
+    ofk_launch_select(c->stream, c->cand, c->cand_cap, c->cand_count, c->cand_seg, segcap, c->seg_count, nseg, c->maxbits, p->quality, w,
+                      p->max_corners, (float)p->min_distance, dst, c->max_pts, dst_counts, limit, batch);
+    return check_launch(c, "stream corner detection");
+}
+
+static int stream_fetch_tracks(ofk_ctx *c, int batch, int max_corners, float *tracks, int *counts)
+{
+    int flags[4];
+    if (!c->h_counts) c->h_counts = (int *)calloc(c->max_batch, sizeof(int));
+    OFK_HIP(c, hipMemcpyAsync(flags, c->dev_flags, 16, hipMemcpyDeviceToHost, c->stream));
+    OFK_HIP(c, hipMemcpyAsync(c->h_counts, c->counts, (size_t)batch * 4, hipMemcpyDeviceToHost, c->stream));   // also tells the next step who re-detects
+    if (tracks) OFK_HIP(c, hipMemcpy2DAsync(tracks, (size_t)max_corners * 8, c->pts_prev, (size_t)c->max_pts * 8, (size_t)max_corners * 8, batch,
+                                            hipMemcpyDeviceToHost, c->stream));
+    OFK_HIP(c, hipStreamSynchronize(c->stream));
+    bool over = (flags[0] & 1) != 0;
+    for (int b = 0; b < batch; ++b) if (c->h_counts[b] < 0) { over = true; c->h_counts[b] = 0; }
+    if (counts) memcpy(counts, c->h_counts, (size_t)batch * 4);
+    if (over) {
+        hipMemsetAsync(c->dev_flags, 0, 16, c->stream);
+        return ofk_fail(c, OFK_E_CAPACITY, "corner candidates exceeded the per-image capacity (%d)", c->cand_cap);
+    }
+    return OFK_OK;
+}
+
+extern "C" int ofk_stream_begin(ofk_ctx *c, const uint8_t *first_bgr, int batch, int h, int w, const ofk_params *p, float *tracks,
+                                int *counts)
+{
+    TRY(check_geom(c, batch, h, w, "ofk_stream_begin"));
+    if (!first_bgr || !p) return ofk_fail(c, OFK_E_INVALID, "ofk_stream_begin: NULL argument");
+    TRY(check_block(c, h, w, p->block_size));
+    TRY(check_select(c, p->max_corners, p->quality, p->min_distance));
+    TRY(check_lk(c, h, w, p->win, p->max_level));
+    TRY(stream_alloc(c));
+    const ofk_levels lv = ofk_make_levels(h, w, p->win, p->max_level);
+    TRY(stream_ingest(c, 0, first_bgr, batch, h, w, lv));
+    TRY(stream_detect(c, 0, nullptr, nullptr, batch, h, w, p, c->pts_prev, c->counts));
+    c->stream_h = h; c->stream_w = w; c->stream_batch = batch;
+    return stream_fetch_tracks(c, batch, p->max_corners, tracks, counts);
+}
+
+extern "C" int ofk_stream_step(ofk_ctx *c, const uint8_t *next_bgr, const double *sensors, const ofk_params *p, int min_features,
+                               int mask_radius, double *records, float *tracks, int *counts)
+{
+    if (!c || !next_bgr || !sensors || !p) return ofk_fail(c, OFK_E_INVALID, "ofk_stream_step: NULL argument");
+    if (c->stream_batch < 1) return ofk_fail(c, OFK_E_INVALID, "ofk_stream_step: call ofk_stream_begin first");
+    if (hipSetDevice(c->device) != hipSuccess) return ofk_fail(c, OFK_E_HIP, "hipSetDevice failed");
+    const int B = c->stream_batch, h = c->stream_h, w = c->stream_w;
+    TRY(check_block(c, h, w, p->block_size));
+    TRY(check_select(c, p->max_corners, p->quality, p->min_distance));
+    TRY(check_lk(c, h, w, p->win, p->max_level));
+    if (mask_radius < 0 || mask_radius > 255) return ofk_fail(c, OFK_E_INVALID, "mask_radius outside 0..255");
+    if (p->solve_variant != OFK_SOLVE_NODE && p->solve_variant != OFK_SOLVE_SIM) return ofk_fail(c, OFK_E_INVALID, "solve_variant must be NODE or SIM");
+    const ofk_levels lv = ofk_make_levels(h, w, p->win, p->max_level);
+    OFK_HIP(c, hipMemcpyAsync(c->sensors, sensors, (size_t)B * OFK_SENSOR_DOUBLES * 8, hipMemcpyHostToDevice, c->stream));
+    TRY(stream_ingest(c, 1, next_bgr, B, h, w, lv));
+    // track (node:133), solve on the tracked points (node:229-258)
+    ofk_launch_lk(c->stream, c->pyr[0], c->pyr[1], c->pyr_stride, lv, c->pts_prev, c->counts, c->max_pts, p->win, p->max_count, p->eps,
+                  p->min_eig_thr, c->pts_next, c->status, c->err, B);
+    ofk_launch_pairs_solve(c->stream, c->pts_prev, c->pts_next, c->status, c->counts, c->max_pts, c->sensors, p->solve_variant,
+                           p->use_feasibility, p->feas_T, nullptr, c->records, B);
+    // re-detection for the streams that had few features (node:157-166): mask = discs around the OLD positions, image = OLD frame.
+    // The host knows the track counts from the previous call, so the whole branch is skipped when no stream needs it.
+    bool any = false;
+    for (int b = 0; b < B; ++b) any = any || (c->h_counts && c->h_counts[b] <= min_features);
+    if (any) {
+        ofk_launch_redetect_limits(c->stream, c->counts, min_features, p->max_corners, c->limit, B);
+        OFK_HIP(c, hipMemsetAsync(c->mask, 1, (size_t)B * c->img_stride, c->stream));
+        ofk_launch_disc_mask(c->stream, c->mask, c->img_stride, h, w, c->pts_prev, c->counts, c->max_pts, mask_radius, c->limit, B);
+        TRY(stream_detect(c, 0, c->mask, c->limit, B, h, w, p, c->pts_new, c->new_counts));
+    }
+    // tracks := new[status == 1] ++ re-detected (node:134,166); the new frame becomes the previous one (node:175)
+    ofk_launch_update_tracks(c->stream, c->pts_next, c->status, c->counts, c->max_pts, any ? c->pts_new : nullptr, any ? c->new_counts : nullptr,
+                             c->pts_prev, c->counts, p->max_corners, B);
+    TRY(check_launch(c, "ofk_stream_step"));
+    if (records) OFK_HIP(c, hipMemcpyAsync(records, c->records, (size_t)B * OFK_RECORD_DOUBLES * 8, hipMemcpyDeviceToHost, c->stream));
+    TRY(stream_fetch_tracks(c, B, p->max_corners, tracks, counts));
+    uint8_t *t = c->pyr[0]; c->pyr[0] = c->pyr[1]; c->pyr[1] = t;
+    t = c->bgr[0]; c->bgr[0] = c->bgr[1]; c->bgr[1] = t;
+    return OFK_OK;
 }
 
 extern "C" int ofk_set_streams(ofk_ctx *c, int nstreams)

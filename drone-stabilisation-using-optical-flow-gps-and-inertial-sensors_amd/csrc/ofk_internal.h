@@ -46,6 +46,10 @@ struct ofk_ctx {
     uint8_t *status;                // [B][max_pts]
     float *err;                     // [B][max_pts]
     int *counts;                    // [B]                        corners per image
+    float *pts_new;                 // [B][max_pts][2]            re-detected corners of a stream step (lazily allocated)
+    int *new_counts, *limit;        // [B]                        their counts / per-stream re-detection budget
+    int stream_h, stream_w, stream_batch;         // geometry of the active video streams (ofk_stream_begin), 0 = none
+    int *h_counts;                                // host copy of the streams' track counts after the last call
     double *sensors;                // [B][OFK_SENSOR_DOUBLES]
     double *records;                // [B][OFK_RECORD_DOUBLES]
     int *dev_flags;                 // [4]                        device-side error flags (bit 0: candidate overflow)
@@ -92,7 +96,12 @@ int  ofk_launch_mineig_cand(hipStream_t s, const uint8_t *gray, size_t gray_stri
 void ofk_stream_geometry(int h, int w, int block, int batch, int *rows, int *nseg, int *seg_cap);
 void ofk_launch_select(hipStream_t s, unsigned long long *cand, int cand_cap, int *cand_count, const unsigned long long *seg,
                        int seg_cap, const int *seg_count, int nseg, const unsigned int *maxbits, double quality, int w,
-                       int max_corners, float min_distance, float *pts, int pts_stride, int *counts, int batch);
+                       int max_corners, float min_distance, float *pts, int pts_stride, int *counts, const int *limit, int batch);
+void ofk_launch_disc_mask(hipStream_t s, uint8_t *mask, size_t mask_stride, int h, int w, const float *pts, const int *counts,
+                          int pts_stride, int radius, const int *limit, int batch);
+void ofk_launch_redetect_limits(hipStream_t s, const int *counts, int min_feat, int max_feat, int *limit, int batch);
+void ofk_launch_update_tracks(hipStream_t s, const float *next_pts, const uint8_t *status, const int *counts_in, int pts_stride,
+                              const float *new_pts, const int *new_counts, float *tracks, int *counts_out, int max_total, int batch);
 void ofk_launch_lk(hipStream_t s, const uint8_t *prev, const uint8_t *next, size_t pyr_stride, const ofk_levels &lv,
                    const float *prev_pts, const int *counts, int pts_stride, int win, int max_count, double eps,
                    double min_eig_thr, float *next_pts, uint8_t *status, float *err, int batch);

@@ -26,8 +26,8 @@ SYMBOLS = (
     "ofk_gray_bgr8", "ofk_pyr_down_u8", "ofk_scharr_s16", "ofk_mineig_response", "ofk_select_corners",
     "ofk_good_features", "ofk_lk_pyr", "ofk_flow_model", "ofk_feasibility", "ofk_velocity_solve", "ofk_imu_propagate",
     "ofk_post_solve", "ofk_kf_predict_update", "ofk_of_simulation", "ofk_pairs_upload", "ofk_pairs_set_sensors",
-    "ofk_pairs_run", "ofk_pairs_download", "ofk_pairs_export_records_f32", "ofk_set_streams", "ofk_profile_enable",
-    "ofk_profile_read",
+    "ofk_pairs_run", "ofk_pairs_download", "ofk_pairs_export_records_f32", "ofk_stream_begin", "ofk_stream_step",
+    "ofk_set_streams", "ofk_profile_enable", "ofk_profile_read",
 )
 
 
@@ -82,6 +82,8 @@ def load_library():
         L.ofk_pairs_run.argtypes = [vp, C.POINTER(Params)]
         L.ofk_pairs_download.argtypes = [vp, vp, vp, vp, vp, vp, vp]
         L.ofk_pairs_export_records_f32.argtypes = [vp, vp, i]
+        L.ofk_stream_begin.argtypes = [vp, vp, i, i, i, C.POINTER(Params), vp, vp]
+        L.ofk_stream_step.argtypes = [vp, vp, vp, C.POINTER(Params), i, i, vp, vp, vp]
         L.ofk_set_streams.argtypes = [vp, i]
         L.ofk_profile_enable.argtypes = [vp, i]
         L.ofk_profile_read.argtypes = [vp, vp, vp]
@@ -375,6 +377,33 @@ class Context:
     def pairs_export_records_f32(self, device_ptr, batch):
         with self._lock:
             self._ck(self._L.ofk_pairs_export_records_f32(self._h, C.c_void_p(int(device_ptr)), int(batch)))
+
+    # ------------------------------------------------------------------ video streams (persistent tracks on the device)
+    def stream_begin(self, first_bgr, params):
+        first_bgr, _ = self._batched(first_bgr, 3)
+        first_bgr = _arr(first_bgr, np.uint8)
+        B, h, w, ch = first_bgr.shape
+        if ch != 3:
+            raise ValueError("expected [B,h,w,3] BGR frames")
+        mc = int(params.max_corners)
+        tracks = np.zeros((B, mc, 2), np.float32); counts = np.zeros(B, np.int32)
+        with self._lock:
+            self._ck(self._L.ofk_stream_begin(self._h, _p(first_bgr), B, h, w, C.byref(params), _p(tracks), _p(counts)))
+        self._stream = (B, h, w)
+        return tracks, counts
+
+    def stream_step(self, next_bgr, sensors, params, min_features, mask_radius):
+        B, h, w = self._stream
+        next_bgr, _ = self._batched(next_bgr, 3)
+        next_bgr = _arr(next_bgr, np.uint8, (B, h, w, 3))
+        sensors = _arr(sensors, np.float64).reshape(B, SENSOR_DOUBLES)
+        mc = int(params.max_corners)
+        rec = np.zeros((B, RECORD_DOUBLES), np.float64)
+        tracks = np.zeros((B, mc, 2), np.float32); counts = np.zeros(B, np.int32)
+        with self._lock:
+            self._ck(self._L.ofk_stream_step(self._h, _p(next_bgr), _p(sensors), C.byref(params), int(min_features), int(mask_radius),
+                                             _p(rec), _p(tracks), _p(counts)))
+        return rec, tracks, counts
 
     def set_streams(self, n):
         self._ck(self._L.ofk_set_streams(self._h, int(n)))

@@ -53,6 +53,32 @@ class PipelineConfig:
                           int(self.solve_variant), 1 if self.use_feasibility else 0, float(self.feas_T))
 
 
+class FlowStream:
+    """`batch` independent video streams with persistent tracks on the device: the loop of velocity_measurment_node:92-177
+    (commented-out blocks restored) / of_module.py:78-167 / evaluate_exp.py:77-121, one frame per `step`.
+
+        fs = FlowStream(1280, 960, batch=1, cfg=PipelineConfig.node(), min_features=20, mask_radius=30)
+        tracks, counts = fs.begin(first_frames)                 # goodFeaturesToTrack on the first frames
+        records, tracks, counts = fs.step(frames, sensors)      # LK, velocity, status filter, re-detection, frame swap
+    """
+
+    def __init__(self, width, height, batch=1, cfg=None, device=0, min_features=20, mask_radius=30):
+        self.cfg = cfg or PipelineConfig.node()
+        self.batch = batch
+        self.min_features, self.mask_radius = int(min_features), int(mask_radius)
+        self.ctx = ofk.Context(device, width, height, batch, max(1, self.cfg.max_corners), max(0, self.cfg.max_level))
+        self._params = self.cfg.to_params()
+
+    def begin(self, first_bgr):
+        return self.ctx.stream_begin(first_bgr, self._params)
+
+    def step(self, next_bgr, sensors):
+        return self.ctx.stream_step(next_bgr, sensors, self._params, self.min_features, self.mask_radius)
+
+    def close(self):
+        self.ctx.close()
+
+
 class FlowPipeline:
     def __init__(self, width, height, batch=1, cfg=None, device=0, streams=1):
         self.cfg = cfg or PipelineConfig.baseline_1080p()

@@ -88,6 +88,31 @@ def render_pair(h, w, seed, v=(0.003, -0.002, 0.001), omega=(0.002, -0.001, 0.00
                 omega=np.asarray(omega, np.float64), d=float(d), n=np.asarray(n, np.float64))
 
 
+def render_sequence(h, w, seed, n_frames, v=(0.003, -0.002, 0.001), omega=(0.002, -0.001, 0.003), d=1.0, n=(0, 0, 1),
+                    scaling=None, margin=96):
+    """`n_frames` BGR frames of one stream under constant per-frame motion: frame k shows the texture through H^k.
+    Returns (frames [n,h,w,3] uint8, info dict as render_pair)."""
+    scaling = scaling or 1.0 / max(h, w)
+    cx, cy = w / 2.0, h / 2.0
+    T = make_texture(h + 2 * margin, w + 2 * margin, seed)
+    T2 = make_texture(h + 2 * margin, w + 2 * margin, seed + 7919, sigma=3.0)
+    H = pixel_homography(v, omega, d, n, scaling, cx, cy)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    frames = np.empty((n_frames, h, w, 3), np.uint8)
+    Hk = np.eye(3)
+    for k in range(n_frames):
+        Hi = np.linalg.inv(Hk)
+        den = Hi[2, 0] * xx + Hi[2, 1] * yy + Hi[2, 2]
+        sx = (Hi[0, 0] * xx + Hi[0, 1] * yy + Hi[0, 2]) / den + margin
+        sy = (Hi[1, 0] * xx + Hi[1, 1] * yy + Hi[1, 2]) / den + margin
+        base, tint = _bilinear(T, sx, sy), _bilinear(T2, sx, sy)
+        for ch, g in enumerate((0.10, -0.06, 0.08)):
+            frames[k, ..., ch] = np.clip(np.rint(base + g * (tint - 127.5)), 0, 255).astype(np.uint8)
+        Hk = H @ Hk
+    return frames, dict(H=H, scaling=scaling, cx=cx, cy=cy, v=np.asarray(v, np.float64), omega=np.asarray(omega, np.float64),
+                        d=float(d), n=np.asarray(n, np.float64))
+
+
 def true_flow_px(H, pts_xy):
     """Exact displacement (pixels) of prev-frame points under the pair's homography."""
     p = np.concatenate([np.asarray(pts_xy, np.float64).reshape(-1, 2), np.ones((len(pts_xy), 1))], 1) @ H.T

@@ -182,6 +182,22 @@ int ofk_pairs_download(ofk_ctx *ctx, double *records, float *prev_pts, float *ne
  * DEVICE pointer owned by the caller (the buffer an RCCL all_gather sends), asynchronously on the context's stream. */
 int ofk_pairs_export_records_f32(ofk_ctx *ctx, void *device_dst, int batch);
 
+/* ------------------------------------------------- video streams: persistent tracks on the device (feature lifecycle)
+ * velocity_measurment_node:92-177 with its commented-out blocks restored (of_module.py:78-167 and evaluate_exp.py:77-121
+ * follow the same loop): `batch` independent streams advance one frame per call.
+ *   begin : gray + pyramid of the first frames, goodFeaturesToTrack -> tracks                       (node:117-128, :120)
+ *   step  : gray + pyramid of the new frames; LK from the tracks (node:133); velocity solve on the tracked points with
+ *           x = new position, u = new - old (node:134-136, :229-258); tracks := new[status == 1];
+ *           streams that had <= min_features tracks re-detect on the PREVIOUS frame with discs of mask_radius around
+ *           the old positions masked out, maxCorners = p->max_corners - (old count), and append (node:157-166);
+ *           the new frame becomes the previous one (node:175).
+ * sensors as in ofk_pairs_set_sensors.  records [batch][16] as in ofk_pairs_download (slot 12 = tracks before the step,
+ * 13 = tracked), tracks [batch][p->max_corners][2] f32 and counts [batch] = the tracks AFTER the step; any may be NULL. */
+int ofk_stream_begin(ofk_ctx *ctx, const uint8_t *first_bgr, int batch, int h, int w, const ofk_params *p, float *tracks,
+                     int *counts);
+int ofk_stream_step(ofk_ctx *ctx, const uint8_t *next_bgr, const double *sensors, const ofk_params *p, int min_features,
+                    int mask_radius, double *records, float *tracks, int *counts);
+
 /* Number of concurrent slices ofk_pairs_run cuts the batch into (1..8, default 1): each slice runs the whole stage chain on
  * its own HIP stream so that latency-bound stages overlap with streaming ones; results do not depend on it. */
 int ofk_set_streams(ofk_ctx *ctx, int nstreams);

@@ -1,0 +1,96 @@
+"""GPU: persistent tracks of a video stream (feature lifecycle) — the loop of
+velocity_measurment_node:92-177 with its commented-out blocks restored — against the same loop written with the
+oracle's functions.  Tracks, counts and velocities must agree frame by frame (tracks bit-exact)."""
+import numpy as np
+import pytest
+
+from oracle import image_oracle as io, estimation_oracle as eo
+
+pytestmark = pytest.mark.gpu
+
+
+def disc_mask(h, w, pts, radius):
+    m = np.ones((h, w), np.uint8)
+    for x, y in pts:
+        cx, cy = int(x), int(y)
+        y0, y1 = max(0, cy - radius), min(h, cy + radius + 1); x0, x1 = max(0, cx - radius), min(w, cx + radius + 1)
+        if y0 < y1 and x0 < x1:
+            yy, xx = np.ogrid[y0:y1, x0:x1]
+            m[y0:y1, x0:x1][(yy - cy) ** 2 + (xx - cx) ** 2 <= radius * radius] = 0
+    return m
+
+
+def oracle_stream(frames, cfg, sensors, min_feat, radius):
+    """node:117-175 (restored): returns per step (v_obs or None, tracks after the step, n_old, n_tracked)."""
+    h, w = frames.shape[1:3]
+    g_prev = io.gray_bgr8(frames[0])
+    tracks = io.good_features(g_prev, cfg.max_corners, cfg.quality, cfg.min_distance, cfg.block_size).reshape(-1, 2)
+    first = tracks.copy()
+    steps = []
+    for t in range(1, len(frames)):
+        g = io.gray_bgr8(frames[t])
+        old = tracks; n_old = len(old)
+        if n_old:
+            new, st, _ = io.lk_pyr(g_prev, g, old, cfg.win, cfg.max_level, cfg.max_count, cfg.eps, cfg.min_eig_thr)
+            new = new.reshape(-1, 2); ok = st.ravel() == 1
+        else:
+            new = np.zeros((0, 2), np.float32); ok = np.zeros(0, bool)
+        sr = sensors
+        x = (new[ok].astype(np.float64) - [sr[20], sr[21]]) * sr[19]; u = (new[ok].astype(np.float64) - old[ok]) * sr[19]
+        v = eo.solve_lgs_node(x, u, sr[0], sr[1:4], sr[4:7])[0] if len(x) >= 3 else None
+        tracked = new[ok]
+        if n_old <= min_feat and cfg.max_corners - n_old > 0:
+            mask = disc_mask(h, w, old, radius)
+            newf = io.good_features(g_prev, cfg.max_corners - n_old, cfg.quality, cfg.min_distance, cfg.block_size, mask=mask).reshape(-1, 2)
+            tracks = np.concatenate([tracked, newf])[:cfg.max_corners]
+        else:
+            tracks = tracked
+        steps.append((v, tracks.copy(), n_old, int(ok.sum())))
+        g_prev = g
+    return first, steps
+
+
+@pytest.mark.parametrize("min_feat,motion", [(90, (0.02, 0.008, 0.0)), (70, (0.012, 0.004, 0.0)), (10, (0.004, -0.003, 0.002))])
+def test_stream_tracks_match_oracle_loop(pkg, ofk, min_feat, motion):
+    from of_amd import synth
+    from of_amd.pipeline import FlowStream, PipelineConfig
+    h, w, nf = 240, 320, 7
+    cfg = PipelineConfig(max_corners=90, quality=0.04, min_distance=9, block_size=7, win=15, max_level=2, max_count=20, eps=0.03)
+    seqs = [synth.render_sequence(h, w, 500 + b, nf, v=motion, omega=(0.0, 0.0, 0.004 * b), d=1.0) for b in range(2)]
+    frames = np.stack([s[0] for s in seqs])                      # [B, nf, h, w, 3]
+    infos = [s[1] for s in seqs]
+    sensors = np.concatenate([ofk.make_sensors(1, d=i["d"], normal=i["n"], omega=i["omega"], scaling=i["scaling"], cx=i["cx"], cy=i["cy"]) for i in infos])
+    fs = FlowStream(w, h, batch=2, cfg=cfg, min_features=min_feat, mask_radius=12)
+    tracks, counts = fs.begin(frames[:, 0])
+    refs = [oracle_stream(frames[b], cfg, sensors[b], min_feat, 12) for b in range(2)]
+    for b in range(2):
+        assert counts[b] == len(refs[b][0]) and np.array_equal(tracks[b, :counts[b]], refs[b][0])
+    redetected = False
+    for t in range(1, nf):
+        rec, tracks, counts = fs.step(frames[:, t], sensors)
+        for b in range(2):
+            v, tr, n_old, n_tracked = refs[b][1][t - 1]
+            assert counts[b] == len(tr), (t, b, counts[b], len(tr))
+            assert np.array_equal(tracks[b, :counts[b]].view(np.uint32), tr.astype(np.float32).view(np.uint32)), (t, b)
+            assert rec[b, 12] == n_old and rec[b, 13] == n_tracked
+            if v is not None:
+                np.testing.assert_allclose(rec[b, :3], v, rtol=1e-9, atol=1e-13)
+            redetected = redetected or len(tr) > n_tracked
+    if min_feat == 90:
+        assert redetected                                      # min_features == maxCorners: every lost track is replaced
+    fs.close()
+
+
+def test_stream_velocity_is_physical(pkg, ofk):
+    from of_amd import synth
+    from of_amd.pipeline import FlowStream, PipelineConfig
+    h, w = 480, 640
+    frames, info = synth.render_sequence(h, w, 9, 5, v=(0.004, -0.003, 0.002), omega=(0.002, 0.001, -0.003), d=1.0)
+    cfg = PipelineConfig(max_corners=150, quality=0.02, min_distance=10, block_size=7)
+    sensors = ofk.make_sensors(1, d=1.0, normal=info["n"], omega=info["omega"], scaling=info["scaling"], cx=info["cx"], cy=info["cy"])
+    fs = FlowStream(w, h, 1, cfg, min_features=20, mask_radius=30)
+    fs.begin(frames[0][None])
+    for t in range(1, 5):
+        rec, tracks, counts = fs.step(frames[t][None], sensors)
+        assert rec[0, 4] == 3 and np.linalg.norm(rec[0, :3] - info["v"]) < 0.15 * np.linalg.norm(info["v"])
+    fs.close()

@@ -31,7 +31,7 @@ int main()
         hipMemset(d_max, 0, 4 * B * OFK_MAX_STRIDE); hipMemset(d_cnt, 0, 4 * OFK_CNT_STRIDE * B);
         ofk_launch_mineig_cand(0, d_img, (size_t)h * w, h, w, 7, d_max, nullptr, 0, 0.01, d_c, cap, d_cnt, d_seg, seg_keys, d_sc, 2048, d_fl, B, &nseg, &segcap);
         hipEventRecord(e0);
-        ofk_launch_select(0, d_c, cap, d_cnt, d_seg, segcap, d_sc, nseg, d_max, 0.01, w, 500, 10.f, d_pts, 512, d_counts, B);
+        ofk_launch_select(0, d_c, cap, d_cnt, d_seg, segcap, d_sc, nseg, d_max, 0.01, w, 500, 10.f, d_pts, 512, d_counts, nullptr, B);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         long long st[8]; hipMemcpy(st, d_st, sizeof st, hipMemcpyDeviceToHost);
