@@ -79,7 +79,7 @@ __global__ __launch_bounds__(64) void k_lk(const uint8_t *__restrict__ prev, con
         if (l == lv.n) { qx = px; qy = py; } else { qx = nx * 2.f; qy = ny * 2.f; }
         nx = qx; ny = qy;
         px -= half; py -= half;
-        const int ipx = (int)floorf(px), ipy = (int)floorf(py);
+        const int ipx = __builtin_amdgcn_readfirstlane((int)floorf(px)), ipy = __builtin_amdgcn_readfirstlane((int)floorf(py));
         if (ipx < -win || ipx >= lw || ipy < -win || ipy >= lh) {
             if (l == 0) { st = 0; errv = 0.f; }
             continue;
@@ -155,7 +155,8 @@ __global__ __launch_bounds__(64) void k_lk(const uint8_t *__restrict__ prev, con
             jvalid = true;
         };
         for (int j = 0; j < max_count; ++j) {
-            const int iqx = (int)floorf(qx), iqy = (int)floorf(qy);
+            // every lane holds the same position: move the integer part to the scalar unit (bounds tests, LDS offsets)
+            const int iqx = __builtin_amdgcn_readfirstlane((int)floorf(qx)), iqy = __builtin_amdgcn_readfirstlane((int)floorf(qy));
             if (iqx < -win || iqx >= lw || iqy < -win || iqy >= lh) {
                 if (l == 0) st = 0;
                 break;
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(64) void k_lk(const uint8_t *__restrict__ prev, con
         }
         if (st && l == 0) {
             const float ex = nx - half, ey = ny - half;
-            const int iex = (int)floorf(ex), iey = (int)floorf(ey);
+            const int iex = __builtin_amdgcn_readfirstlane((int)floorf(ex)), iey = __builtin_amdgcn_readfirstlane((int)floorf(ey));
             if (iex < -win || iex >= lw || iey < -win || iey >= lh) { st = 0; continue; }
             if (!jvalid || iex < jx0 || iex > jx0 + 2 * LK_M || iey < jy0 || iey > jy0 + 2 * LK_M) stage_J(iex, iey);
             jwx = iex - jx0; jwy = iey - jy0;
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(64) void k_lk15(const uint8_t *__restrict__ prev, c
         if (l == lv.n) { qx = px; qy = py; } else { qx = nx * 2.f; qy = ny * 2.f; }
         nx = qx; ny = qy;
         px -= half; py -= half;
-        const int ipx = (int)floorf(px), ipy = (int)floorf(py);
+        const int ipx = __builtin_amdgcn_readfirstlane((int)floorf(px)), ipy = __builtin_amdgcn_readfirstlane((int)floorf(py));
         if (ipx < -win || ipx >= lw || ipy < -win || ipy >= lh) {
             if (l == 0) { st = 0; errv = 0.f; }
             continue;
@@ -364,7 +365,8 @@ __global__ __launch_bounds__(64) void k_lk15(const uint8_t *__restrict__ prev, c
             }
         }
         {
-            const int iqx = (int)floorf(qx), iqy = (int)floorf(qy);
+            // every lane holds the same position: move the integer part to the scalar unit (bounds tests, LDS offsets)
+            const int iqx = __builtin_amdgcn_readfirstlane((int)floorf(qx)), iqy = __builtin_amdgcn_readfirstlane((int)floorf(qy));
             if (!(iqx < -win || iqx >= lw || iqy < -win || iqy >= lh)) stage_J(iqx, iqy);
             else __syncthreads();
         }
@@ -377,17 +379,29 @@ __global__ __launch_bounds__(64) void k_lk15(const uint8_t *__restrict__ prev, c
             int n[4][7];                                                   // rows wy..wy+3 of s_I, cols wx0..wx0+6
 #pragma unroll
             for (int r = 0; r < 4; ++r) lds_read7(s_I, (wy + r) * LKF_IP + wx0, n[r]);
-            int dxv[2][5], dyv[2][5];                                      // Scharr at window taps (rows wy, wy+1; cols wx0..wx0+4)
+            // Scharr at the window taps (rows wy, wy+1; cols wx0..wx0+4), separable: per neighbourhood row the horizontal
+            // difference hd and the horizontal [3 10 3] smooth hs, then dx = 3 hd_r + 10 hd_{r+1} + 3 hd_{r+2}, dy = hs_{r+2} - hs_r
+            int dxv[2][5], dyv[2][5];
 #pragma unroll
-            for (int r = 0; r < 2; ++r)
+            for (int c = 0; c < 5; ++c) {                                  // column by column: 8 temporaries live at a time
+                int hd[4], hs[4];
 #pragma unroll
-                for (int c = 0; c < 5; ++c) {
-                    const int X = ipx + wx0 + c, Y = ipy + wy + r;
-                    const bool in = X >= 0 && X < lw && Y >= 0 && Y < lh;   // derivative image has a constant-0 border
-                    const int dx = 3 * (n[r][c + 2] - n[r][c]) + 10 * (n[r + 1][c + 2] - n[r + 1][c]) + 3 * (n[r + 2][c + 2] - n[r + 2][c]);
-                    const int dy = 3 * (n[r + 2][c] - n[r][c]) + 10 * (n[r + 2][c + 1] - n[r][c + 1]) + 3 * (n[r + 2][c + 2] - n[r][c + 2]);
-                    dxv[r][c] = in ? dx : 0; dyv[r][c] = in ? dy : 0;
+                for (int r = 0; r < 4; ++r) {
+                    hd[r] = n[r][c + 2] - n[r][c];
+                    hs[r] = 3 * (n[r][c] + n[r][c + 2]) + 10 * n[r][c + 1];
                 }
+                dxv[0][c] = 3 * (hd[0] + hd[2]) + 10 * hd[1]; dxv[1][c] = 3 * (hd[1] + hd[3]) + 10 * hd[2];
+                dyv[0][c] = hs[2] - hs[0]; dyv[1][c] = hs[3] - hs[1];
+            }
+            if (!(ipx >= 0 && ipx + win < lw && ipy >= 0 && ipy + win < lh)) {      // wave-uniform: the window touches the border
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) {
+                        const int X = ipx + wx0 + c, Y = ipy + wy + r;
+                        if (!(X >= 0 && X < lw && Y >= 0 && Y < lh)) { dxv[r][c] = 0; dyv[r][c] = 0; }   // constant-0 derivative border
+                    }
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (k < npx) {
@@ -409,7 +423,8 @@ __global__ __launch_bounds__(64) void k_lk15(const uint8_t *__restrict__ prev, c
         D = 1.f / D;
         float pdx = 0.f, pdy = 0.f;
         for (int j = 0; j < max_count; ++j) {
-            const int iqx = (int)floorf(qx), iqy = (int)floorf(qy);
+            // every lane holds the same position: move the integer part to the scalar unit (bounds tests, LDS offsets)
+            const int iqx = __builtin_amdgcn_readfirstlane((int)floorf(qx)), iqy = __builtin_amdgcn_readfirstlane((int)floorf(qy));
             if (iqx < -win || iqx >= lw || iqy < -win || iqy >= lh) {
                 if (l == 0) st = 0;
                 break;
@@ -441,7 +456,7 @@ __global__ __launch_bounds__(64) void k_lk15(const uint8_t *__restrict__ prev, c
         }
         if (st && l == 0) {
             const float ex = nx - half, ey = ny - half;
-            const int iex = (int)floorf(ex), iey = (int)floorf(ey);
+            const int iex = __builtin_amdgcn_readfirstlane((int)floorf(ex)), iey = __builtin_amdgcn_readfirstlane((int)floorf(ey));
             if (iex < -win || iex >= lw || iey < -win || iey >= lh) { st = 0; continue; }
             if (!jvalid || iex < jx0 || iex > jx0 + 2 * LK_M || iey < jy0 || iey > jy0 + 2 * LK_M) stage_J(iex, iey);
             lk_weights(ex - (float)iex, ey - (float)iey, w00, w01, w10, w11);

@@ -135,9 +135,8 @@ class optical_fusion:
                     ft_mask = np.ones_like(image_gray)
                     of.circles(self.feat, ft_mask, 30)
                     new = cv2.goodFeaturesToTrack(image_gray, mask=ft_mask, maxCorners=self.max_feat - len(self.feat), **self.feature_params)
-                    if new is not None:
+                    if new is not None:                      # appended features have no flow yet (node:166 appends to feat only)
                         self.feat = np.append(self.feat, new.reshape(len(new), 2), axis=0)
-                        self.flow = np.append(np.asarray(self.flow).reshape(-1, 1, 2), np.zeros((len(new), 1, 2), np.float32), axis=0)
             self.old_pic = image_gray
             self.first = False
 
@@ -156,7 +155,11 @@ class optical_fusion:
             u = np.asarray(self.flow, np.float64).reshape(len(self.flow), 2) * self.scaling
             if self.synthetic_test:
                 u = generate_test_data(x, np.array([1, 1, 1]), np.array([0, 0, 0]), self.d, np.array([0, 0, 1]))   # node:236
-            if len(u) != len(x):
+            n_new = 0
+            if len(u) < len(x):                       # features re-detected this frame sit behind the tracked ones and have no flow:
+                n_new = len(x) - len(u)                # the solve uses the tracked ones only (the reference would fail on the mismatch)
+                x = x[:len(u)]
+            elif len(u) > len(x):
                 self.got_picture_ = False
                 return None
             feasibility, dummy_d = of.r_tilde(x, u, self.normal, self.vel, self.d)
@@ -164,7 +167,7 @@ class optical_fusion:
                 feasibility = -1 * np.ones(len(x))                                                                  # node:240
             keep = feasibility <= self.T
             x = x[keep]; u = u[keep]; dummy_d = dummy_d[keep]
-            self.feat = self.feat[keep]
+            self.feat = np.concatenate([self.feat[:len(keep)][keep], self.feat[len(keep):]]) if n_new else self.feat[keep]
             if not self.synthetic_test:
                 self.flow = np.asarray(self.flow).reshape(-1, 1, 2)[keep]
             v_obs = None
