@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=128, help="frame pairs per GPU per step")
     ap.add_argument("--streams", type=int, default=1, help="concurrent slices of the batch (HIP streams) per GPU")
+    ap.add_argument("--no-overlap", action="store_true", help="run every stage of a step serially on one stream")
     ap.add_argument("--cpu-sample", type=int, default=24, help="pairs timed on the CPU oracle (0 = skip)")
     args = ap.parse_args()
 
@@ -130,6 +131,8 @@ def main():
     p0 = base[0]
     sensors = ofk.make_sensors(B, d=p0["d"], normal=p0["n"], omega=p0["omega"], scaling=p0["scaling"], cx=p0["cx"], cy=p0["cy"])
     pipe = FlowPipeline(W, H, B, cfg, device=local, streams=args.streams)
+    if args.no_overlap:
+        pipe.ctx.set_overlap(False)
     pipe.upload(prev, nxt, sensors)
 
     gathered = rec_t = None
@@ -164,6 +167,19 @@ def main():
     dt = time.perf_counter() - t0
     prof = pipe.ctx.profile_read()
     pipe.ctx.profile_enable(0)
+    # Outside the timed region: the same K steps once more with every stage serial on one stream, so that each kernel's
+    # duration is its own (under overlap two kernels share the chip and each one's event time includes the other).
+    iso = prof
+    if not args.no_overlap:
+        pipe.ctx.set_overlap(False)
+        pipe.run_async(); pipe.sync()
+        pipe.ctx.profile_enable(0x7f)
+        for _ in range(args.steps):
+            pipe.run_async()
+        pipe.sync()
+        iso = pipe.ctx.profile_read()
+        pipe.ctx.profile_enable(0)
+        pipe.ctx.set_overlap(True)
 
     if dist is not None:
         dt = sharding.max_over_ranks(dist, dt, device=f"cuda:{local}")
@@ -180,7 +196,11 @@ def main():
             per_step = ms / args.steps                   # summed over the slices (streams) of a step
             stages[s] = {"ms_per_step": round(per_step, 4), "launches_per_step": nl // max(1, args.steps),
                          "algorithmic_GBps": round(ab[s] * B / (per_step * 1e-3) / 1e9, 2) if per_step > 0 else None}
-        dom = max(ofk.STAGES, key=lambda s: prof[s][0])
+        # dominant kernel = the longest stage on the step's critical path.  With overlap on, gray and the pyramids run on
+        # the auxiliary stream beside the response kernel and LK (their event times then include the contention and
+        # are not on the critical path), so the candidates are the stages of the context's own stream.
+        critical = ofk.STAGES if args.no_overlap else [s for s in ofk.STAGES if s not in ("gray", "pyr")]
+        dom = max(critical, key=lambda s: prof[s][0])
         slices = max(1, prof[dom][1] // max(1, args.steps))       # event pairs (= stage launches) per step
         dom_ms = prof[dom][0] / max(1, prof[dom][1])             # mean duration of one bracketed launch group
         achieved = ab[dom] * (B / slices) / (dom_ms * 1e-3) / 1e9
@@ -205,6 +225,12 @@ def main():
                          "algorithmic_bytes_per_launch": int(ab[dom] * B / slices), "avg_ms": round(dom_ms, 4)},
             "pipeline_algorithmic_GBps": round(sum(ab.values()) * world * B * args.steps / dt / 1e9, 1),
             "stages": stages,
+            # every stage alone on the chip (serial pass outside the timed region) and the HBM-bound group BASELINE.json's
+            # target names (pyramid construction; LK itself is VALU-bound)
+            "stages_isolated": {s: {"ms_per_step": round(iso[s][0] / args.steps, 4),
+                                    "algorithmic_GBps": round(ab[s] * B / (iso[s][0] / args.steps * 1e-3) / 1e9, 2) if iso[s][0] > 0 else None,
+                                    "hbm_frac": round(ab[s] * B / (iso[s][0] / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if iso[s][0] > 0 else None}
+                                for s in ofk.STAGES},
             "velocity_sample": [round(float(x), 6) for x in rec[0, :3]],
             "velocity_truth": list(truth["v"]),
         }

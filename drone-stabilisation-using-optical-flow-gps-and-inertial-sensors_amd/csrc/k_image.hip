@@ -160,9 +160,111 @@ __global__ __launch_bounds__(256) void k_pyr_down(const uint8_t *__restrict__ sr
     }
 }
 
+// Streaming pyrDown (widths that are multiples of 8): one WAVE per strip of 496 source columns, marching down the rows —
+// no LDS, no barriers, every source byte fetched once per strip.
+//   lane = 8 source columns (one dwordx2 load per source row) = 4 output columns (one dword store per output row); lanes
+//   0 and 63 only feed their neighbours (the 2-column halo travels through DPP wave shifts), so a strip yields 248 outputs.
+//   The horizontal [1 4 6 4 1] runs on PAIRS of u16 packed in a dword (even bytes / odd bytes of the loaded dwords, the
+//   shifted pairs through v_alignbit): a horizontal sum is <= 4080 and a vertical one <= 65280 + 128, so the two halves
+//   never carry into each other and plain 32-bit adds are exact.  The vertical pass keeps the last three horizontal rows in
+//   registers and consumes two new ones per output row; v_perm picks the rounded high bytes into the output dword.
+#define PDS_COLS 496                    // source columns per strip (62 lanes x 8)
+__device__ __forceinline__ void pds_hrow(uint2 d, bool first, bool last, unsigned &h01, unsigned &h23)
+{
+    const unsigned A = d.x & 0x00ff00ffu, C = (d.x >> 8) & 0x00ff00ffu;      // (b0,b2) (b1,b3)
+    const unsigned B = d.y & 0x00ff00ffu, D = (d.y >> 8) & 0x00ff00ffu;      // (b4,b6) (b5,b7)
+    unsigned pB = (unsigned)__builtin_amdgcn_update_dpp(0, (int)B, 0x138, 0xF, 0xF, true);   // lane-1: (.., b6) of the 8 columns to the left
+    unsigned pD = (unsigned)__builtin_amdgcn_update_dpp(0, (int)D, 0x138, 0xF, 0xF, true);   //         (.., b7)
+    unsigned nA = (unsigned)__builtin_amdgcn_update_dpp(0, (int)A, 0x130, 0xF, 0xF, true);   // lane+1: (b0, ..) of the 8 columns to the right
+    if (first) { pB = A; pD = C << 16; }                        // columns -2,-1 mirror 2,1
+    if (last) nA = B >> 16;                                     // column w mirrors w-2
+    const unsigned le01 = __builtin_amdgcn_alignbit(A, pB, 16);  // (p6,b0)
+    const unsigned lo01 = __builtin_amdgcn_alignbit(C, pD, 16);  // (p7,b1)
+    const unsigned re01 = __builtin_amdgcn_alignbit(B, A, 16);   // (b2,b4)
+    const unsigned lo23 = __builtin_amdgcn_alignbit(D, C, 16);   // (b3,b5)
+    const unsigned re23 = __builtin_amdgcn_alignbit(nA, B, 16);  // (b6,n0)
+    h01 = 6u * A + 4u * (lo01 + C) + le01 + re01;               // centres b0, b2
+    h23 = 6u * B + 4u * (lo23 + D) + re01 + re23;               // centres b4, b6
+}
+
+__global__ __launch_bounds__(256) void k_pyr_down_stream(const uint8_t *__restrict__ src0, const uint8_t *__restrict__ src1,
+                                                         size_t src_stride, int h, int w, uint8_t *__restrict__ dst0,
+                                                         uint8_t *__restrict__ dst1, size_t dst_stride, int dh, int dw, int batch,
+                                                         int rows, int nstrips, int nchunks)
+{
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));   // wave-uniform: row math stays scalar
+    if (wid >= nstrips * nchunks) return;                       // whole wave
+    const int strip = wid % nstrips, chunk = wid / nstrips;
+    const int z = blockIdx.y;
+    const uint8_t *img = z < batch ? src0 + (size_t)z * src_stride : src1 + (size_t)(z - batch) * src_stride;
+    uint8_t *out = z < batch ? dst0 + (size_t)z * dst_stride : dst1 + (size_t)(z - batch) * dst_stride;
+    const int c0 = strip * PDS_COLS - 8 + 8 * lane;             // first source column of this lane
+    const int sc = min(max(c0, 0), w - 8);                      // clamped: lanes outside the image load something valid
+    const bool first = c0 == 0, last = c0 == w - 8;
+    const int ox = strip * (PDS_COLS / 2) - 4 + 4 * lane;
+    const bool store_ok = lane >= 1 && lane <= 62 && ox < dw;
+    const int oy0 = chunk * rows, oy1 = min(dh, oy0 + rows);
+    // one branch-free reflection covers every row that is used (h >= 4: -2 -> 2, h+1 -> h-3); the clamp only catches the
+    // prefetch running past the chunk, whose values are never consumed
+    auto ld = [&](int sy) -> uint2 {
+        sy = sy < 0 ? -sy : sy;
+        sy = sy >= h ? 2 * (h - 1) - sy : sy;
+        const uint8_t *rowp = img + (size_t)__builtin_amdgcn_readfirstlane(max(sy, 0)) * (unsigned)w;   // scalar base + lane offset
+        return *reinterpret_cast<const uint2 *>(rowp + (unsigned)sc);
+    };
+    unsigned a01, a23, b01, b23, c01, c23;
+    {
+        const uint2 r0 = ld(2 * oy0 - 2), r1 = ld(2 * oy0 - 1), r2 = ld(2 * oy0);
+        pds_hrow(r0, first, last, a01, a23);
+        pds_hrow(r1, first, last, b01, b23);
+        pds_hrow(r2, first, last, c01, c23);
+    }
+    uint2 q0 = ld(2 * oy0 + 1), q1 = ld(2 * oy0 + 2), q2 = ld(2 * oy0 + 3), q3 = ld(2 * oy0 + 4);
+    uint2 q4 = ld(2 * oy0 + 5), q5 = ld(2 * oy0 + 6);
+    auto step = [&](uint2 u0, uint2 u1, int oy) {
+        unsigned d01, d23, e01, e23;
+        pds_hrow(u0, first, last, d01, d23);
+        pds_hrow(u1, first, last, e01, e23);
+        // a + e + 4(b + d) + 6c + 128 as shifts and adds (a 32-bit multiply by 6 would not fit v_mul_u32_u24)
+        const unsigned v01 = ((b01 + d01 + c01) << 2) + a01 + ((c01 << 1) + e01) + 0x00800080u;
+        const unsigned v23 = ((b23 + d23 + c23) << 2) + a23 + ((c23 << 1) + e23) + 0x00800080u;
+        const unsigned pk = __builtin_amdgcn_perm(v23, v01, 0x07050301u);      // (v >> 8) of the four u16 halves
+        if (store_ok && oy < oy1) *reinterpret_cast<unsigned *>(out + (size_t)oy * dw + ox) = pk;
+        a01 = c01; a23 = c23; b01 = d01; b23 = d23; c01 = e01; c23 = e23;
+    };
+    for (int oy = oy0; oy < oy1; oy += 3) {                     // six rows in flight per wave; unrolled so the queue renames
+        uint2 u0 = q0, u1 = q1;
+        q0 = ld(2 * oy + 7); q1 = ld(2 * oy + 8);
+        step(u0, u1, oy);
+        u0 = q2; u1 = q3;
+        q2 = ld(2 * oy + 9); q3 = ld(2 * oy + 10);
+        step(u0, u1, oy + 1);
+        u0 = q4; u1 = q5;
+        q4 = ld(2 * oy + 11); q5 = ld(2 * oy + 12);
+        step(u0, u1, oy + 2);
+    }
+}
+
+static bool pyr_stream_ok(int h, int w) { return (w & 7) == 0 && w >= 16 && h >= 4; }
+
+static void launch_pyr_stream(hipStream_t s, const uint8_t *src0, const uint8_t *src1, size_t src_stride, int h, int w,
+                              uint8_t *dst0, uint8_t *dst1, size_t dst_stride, int batch, int images)
+{
+    const int dh = (h + 1) / 2, dw = (w + 1) / 2;
+    const int nstrips = (w + PDS_COLS - 1) / PDS_COLS;
+    int rows = images >= 32 ? 32 : 8;                           // fewer, longer strips when the batch already fills the chip
+    if (const char *e = getenv("OFK_PYR_ROWS")) { const int v = atoi(e); if (v >= 1 && v <= 4096) rows = v; }   // tuning knob
+    const int nchunks = (dh + rows - 1) / rows;
+    dim3 grid((nstrips * nchunks + 3) / 4, images);
+    hipLaunchKernelGGL(k_pyr_down_stream, grid, dim3(256), 0, s, src0, src1, src_stride, h, w, dst0, dst1, dst_stride, dh, dw, batch,
+                       rows, nstrips, nchunks);
+}
+
 void ofk_launch_pyr_down(hipStream_t s, const uint8_t *src, size_t src_stride, int h, int w, uint8_t *dst,
                          size_t dst_stride, int batch)
 {
+    if (pyr_stream_ok(h, w)) { launch_pyr_stream(s, src, nullptr, src_stride, h, w, dst, nullptr, dst_stride, batch, batch); return; }
     const int dh = (h + 1) / 2, dw = (w + 1) / 2;
     dim3 grid((dw + PD_TW - 1) / PD_TW, (dh + PD_TH - 1) / PD_TH, batch);
     hipLaunchKernelGGL(k_pyr_down, grid, dim3(256), 0, s, src, (const uint8_t *)nullptr, src_stride, h, w, dst, (uint8_t *)nullptr,
@@ -173,6 +275,7 @@ void ofk_launch_pyr_down(hipStream_t s, const uint8_t *src, size_t src_stride, i
 void ofk_launch_pyr_down2(hipStream_t s, const uint8_t *src0, const uint8_t *src1, size_t src_stride, int h, int w,
                           uint8_t *dst0, uint8_t *dst1, size_t dst_stride, int batch)
 {
+    if (pyr_stream_ok(h, w)) { launch_pyr_stream(s, src0, src1, src_stride, h, w, dst0, dst1, dst_stride, batch, 2 * batch); return; }
     const int dh = (h + 1) / 2, dw = (w + 1) / 2;
     dim3 grid((dw + PD_TW - 1) / PD_TW, (dh + PD_TH - 1) / PD_TH, 2 * batch);
     hipLaunchKernelGGL(k_pyr_down, grid, dim3(256), 0, s, src0, src1, src_stride, h, w, dst0, dst1, dst_stride, dh, dw, batch);

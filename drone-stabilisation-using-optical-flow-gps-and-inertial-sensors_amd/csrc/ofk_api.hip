@@ -104,6 +104,18 @@ extern "C" int ofk_create(int device, int max_w, int max_h, int max_batch, int m
         }
     }
     hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    c->overlap = 1;
+    for (int k = 0; k < OFK_MAX_STREAMS; ++k) {
+        if (hipStreamCreateWithFlags(&c->aux[k], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_g0[k], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_aux[k], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_lkdone[0][k], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_lkdone[1][k], hipEventDisableTiming) != hipSuccess) {
+            ofk_fail(nullptr, OFK_E_HIP, "hipStreamCreate (auxiliary stream %d) failed", k);
+            ofk_destroy(c);
+            return OFK_E_HIP;
+        }
+    }
     const size_t B = (size_t)max_batch;
     for (int k = 0; k < 2; ++k) { ALLOC(c->bgr[k], B * c->bgr_stride); ALLOC(c->pyr[k], B * c->pyr_stride); }
     ALLOC(c->eig, B * c->img_stride * sizeof(float));
@@ -141,6 +153,13 @@ extern "C" int ofk_destroy(ofk_ctx *c)
     free(c->ev_stage);
     free(c->h_counts);
     for (int k = 1; k < OFK_MAX_STREAMS; ++k) { if (c->streams[k]) hipStreamDestroy(c->streams[k]); if (c->ev_join[k]) hipEventDestroy(c->ev_join[k]); }
+    for (int k = 0; k < OFK_MAX_STREAMS; ++k) {
+        if (c->aux[k]) hipStreamDestroy(c->aux[k]);
+        if (c->ev_g0[k]) hipEventDestroy(c->ev_g0[k]);
+        if (c->ev_aux[k]) hipEventDestroy(c->ev_aux[k]);
+        for (int s = 0; s < 2; ++s) if (c->ev_lkdone[s][k]) hipEventDestroy(c->ev_lkdone[s][k]);
+    }
+    for (int k = 0; k < 2; ++k) if (c->pyr_alt[k]) hipFree(c->pyr_alt[k]);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->stream) hipStreamDestroy(c->stream);
     free(c);
@@ -589,6 +608,19 @@ extern "C" int ofk_pairs_run(ofk_ctx *c, const ofk_params *p)
     // latency-bound stages of one slice (corner selection: one workgroup per image; the per-pair solve) overlap with the
     // streaming stages of the others.  Pairs are independent, so slices share nothing.
     const int S = c->nstreams < 1 ? 1 : (c->nstreams > B ? B : c->nstreams);
+    // Inside a slice the chain forks once more: the response kernel and LK are VALU-bound, the gray conversions and the
+    // pyramids HBM-bound, so the two kinds run beside each other.  The gray conversions and the pyramids (HBM-bound) run on an auxiliary stream and may even run AHEAD of the context's
+    // stream: they write one of two pyramid buffer sets, alternating per call, so the next call's conversions overlap this
+    // call's LK.  The only hazard is the set itself, still read by the LK of the call that used it last (ev_lkdone).
+    bool overlap = c->overlap != 0;
+    if (overlap && !c->pyr_alt[0]) {
+        for (int k = 0; k < 2 && overlap; ++k)
+            if (hipMalloc((void **)&c->pyr_alt[k], (size_t)c->max_batch * c->pyr_stride) != hipSuccess) { (void)hipGetLastError(); overlap = false; }
+        if (!overlap) { for (int k = 0; k < 2; ++k) if (c->pyr_alt[k]) { hipFree(c->pyr_alt[k]); c->pyr_alt[k] = nullptr; } c->overlap = 0; }
+    }
+    int set = 0;
+    if (overlap) { set = c->pyr_set; c->pyr_set ^= 1; }
+    uint8_t *const P0 = set ? c->pyr_alt[0] : c->pyr[0], *const P1 = set ? c->pyr_alt[1] : c->pyr[1];
     if (S > 1) {
         hipEventRecord(c->ev_fork, c->stream);
         for (int k = 1; k < S; ++k) hipStreamWaitEvent(c->streams[k], c->ev_fork, 0);
@@ -597,8 +629,10 @@ extern "C" int ofk_pairs_run(ofk_ctx *c, const ofk_params *p)
         const int b0 = (int)((long long)B * k / S), nb = (int)((long long)B * (k + 1) / S) - b0;
         if (nb <= 0) continue;
         hipStream_t st = k == 0 ? c->stream : c->streams[k];
+        hipStream_t sa = overlap ? c->aux[k] : st;
+        if (overlap) hipStreamWaitEvent(sa, c->ev_lkdone[set][k], 0);
         uint8_t *bgr0 = c->bgr[0] + (size_t)b0 * c->bgr_stride, *bgr1 = c->bgr[1] + (size_t)b0 * c->bgr_stride;
-        uint8_t *pyr0 = c->pyr[0] + (size_t)b0 * c->pyr_stride, *pyr1 = c->pyr[1] + (size_t)b0 * c->pyr_stride;
+        uint8_t *pyr0 = P0 + (size_t)b0 * c->pyr_stride, *pyr1 = P1 + (size_t)b0 * c->pyr_stride;
         unsigned int *maxbits = c->maxbits + (size_t)b0 * OFK_MAX_STRIDE;
         int *cand_count = c->cand_count + (size_t)b0 * OFK_CNT_STRIDE;
         unsigned long long *cand = c->cand + (size_t)b0 * c->cand_cap, *cand_seg = c->cand_seg + (size_t)b0 * c->seg_keys;
@@ -609,15 +643,23 @@ extern "C" int ofk_pairs_run(ofk_ctx *c, const ofk_params *p)
         int *counts = c->counts + b0;
         int nseg = 0, segcap = 0;
         {
-            StageTimer t(c, OFK_STAGE_GRAY, st);
-            ofk_launch_gray(st, bgr0, c->bgr_stride, pyr0, c->pyr_stride, nb, h, w);
-            ofk_launch_gray(st, bgr1, c->bgr_stride, pyr1, c->pyr_stride, nb, h, w);
+            StageTimer t(c, OFK_STAGE_GRAY, sa);
+            ofk_launch_gray(sa, bgr0, c->bgr_stride, pyr0, c->pyr_stride, nb, h, w);
+        }
+        if (overlap) hipEventRecord(c->ev_g0[k], sa);
+        {
+            StageTimer t(c, OFK_STAGE_GRAY, sa);
+            ofk_launch_gray(sa, bgr1, c->bgr_stride, pyr1, c->pyr_stride, nb, h, w);
         }
         {
-            StageTimer t(c, OFK_STAGE_PYR, st);
+            StageTimer t(c, OFK_STAGE_PYR, sa);
             for (int l = 1; l <= lv.n; ++l)
-                ofk_launch_pyr_down2(st, pyr0 + lv.off[l - 1], pyr1 + lv.off[l - 1], c->pyr_stride, lv.h[l - 1], lv.w[l - 1], pyr0 + lv.off[l],
+                ofk_launch_pyr_down2(sa, pyr0 + lv.off[l - 1], pyr1 + lv.off[l - 1], c->pyr_stride, lv.h[l - 1], lv.w[l - 1], pyr0 + lv.off[l],
                                      pyr1 + lv.off[l], c->pyr_stride, nb);
+        }
+        if (overlap) {
+            hipEventRecord(c->ev_aux[k], sa);
+            hipStreamWaitEvent(st, c->ev_g0[k], 0);              // the response kernel needs the previous frame's gray level
         }
         {
             StageTimer t(c, OFK_STAGE_EIG, st);                  // response + 3x3 NMS + candidate keys, no map in HBM
@@ -632,11 +674,13 @@ extern "C" int ofk_pairs_run(ofk_ctx *c, const ofk_params *p)
             ofk_launch_select(st, cand, c->cand_cap, cand_count, cand_seg, segcap, seg_count, nseg, maxbits, p->quality, w, p->max_corners,
                               (float)p->min_distance, pts_prev, c->max_pts, counts, nullptr, nb);
         }
+        if (overlap) hipStreamWaitEvent(st, c->ev_aux[k], 0);    // LK needs both pyramids
         {
             StageTimer t(c, OFK_STAGE_LK, st);
             ofk_launch_lk(st, pyr0, pyr1, c->pyr_stride, lv, pts_prev, counts, c->max_pts, p->win, p->max_count, p->eps, p->min_eig_thr,
                           pts_next, status, err, nb);
         }
+        if (overlap) hipEventRecord(c->ev_lkdone[set][k], st);   // this pyramid set may be rewritten from here on
         {
             StageTimer t(c, OFK_STAGE_SOLVE, st);
             ofk_launch_pairs_solve(st, pts_prev, pts_next, status, counts, c->max_pts, c->sensors + (size_t)b0 * OFK_SENSOR_DOUBLES,
@@ -801,6 +845,13 @@ extern "C" int ofk_set_streams(ofk_ctx *c, int nstreams)
 {
     if (!c || nstreams < 1 || nstreams > OFK_MAX_STREAMS) return ofk_fail(c, OFK_E_INVALID, "ofk_set_streams: 1..%d", OFK_MAX_STREAMS);
     c->nstreams = nstreams;
+    return OFK_OK;
+}
+
+extern "C" int ofk_set_overlap(ofk_ctx *c, int on)
+{
+    if (!c) return OFK_E_INVALID;
+    c->overlap = on ? 1 : 0;
     return OFK_OK;
 }
 

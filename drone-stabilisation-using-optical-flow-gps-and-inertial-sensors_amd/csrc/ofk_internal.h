@@ -24,6 +24,10 @@ struct ofk_ctx {
     hipStream_t stream;                           // the context's stream (slice 0); entry points synchronise on it
     hipStream_t streams[OFK_MAX_STREAMS]; int nstreams;   // extra slice streams, joined back into `stream` by events
     hipEvent_t ev_fork, ev_join[OFK_MAX_STREAMS];
+    hipStream_t aux[OFK_MAX_STREAMS]; int overlap;        // per-slice auxiliary stream: next-frame gray + pyramids beside the response kernel
+    hipEvent_t ev_g0[OFK_MAX_STREAMS], ev_aux[OFK_MAX_STREAMS];
+    uint8_t *pyr_alt[2]; int pyr_set;                     // second pyramid set: the auxiliary stream runs one call ahead
+    hipEvent_t ev_lkdone[2][OFK_MAX_STREAMS];             // LK of the call that last read a set has finished
     int max_w, max_h, max_batch, max_pts, max_level;
     size_t P;                       // max_w * max_h
     size_t bgr_stride;              // bytes between images in bgr[], 256-B aligned

@@ -27,7 +27,7 @@ SYMBOLS = (
     "ofk_good_features", "ofk_lk_pyr", "ofk_flow_model", "ofk_feasibility", "ofk_velocity_solve", "ofk_imu_propagate",
     "ofk_post_solve", "ofk_kf_predict_update", "ofk_of_simulation", "ofk_pairs_upload", "ofk_pairs_set_sensors",
     "ofk_pairs_run", "ofk_pairs_download", "ofk_pairs_export_records_f32", "ofk_stream_begin", "ofk_stream_step",
-    "ofk_set_streams", "ofk_profile_enable", "ofk_profile_read",
+    "ofk_set_streams", "ofk_set_overlap", "ofk_profile_enable", "ofk_profile_read",
 )
 
 
@@ -85,6 +85,7 @@ def load_library():
         L.ofk_stream_begin.argtypes = [vp, vp, i, i, i, C.POINTER(Params), vp, vp]
         L.ofk_stream_step.argtypes = [vp, vp, vp, C.POINTER(Params), i, i, vp, vp, vp]
         L.ofk_set_streams.argtypes = [vp, i]
+        L.ofk_set_overlap.argtypes = [vp, i]
         L.ofk_profile_enable.argtypes = [vp, i]
         L.ofk_profile_read.argtypes = [vp, vp, vp]
         for s in SYMBOLS:
@@ -404,6 +405,9 @@ class Context:
             self._ck(self._L.ofk_stream_step(self._h, _p(next_bgr), _p(sensors), C.byref(params), int(min_features), int(mask_radius),
                                              _p(rec), _p(tracks), _p(counts)))
         return rec, tracks, counts
+
+    def set_overlap(self, on):
+        self._ck(self._L.ofk_set_overlap(self._h, 1 if on else 0))
 
     def set_streams(self, n):
         self._ck(self._L.ofk_set_streams(self._h, int(n)))

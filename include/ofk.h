@@ -201,6 +201,9 @@ int ofk_stream_step(ofk_ctx *ctx, const uint8_t *next_bgr, const double *sensors
 /* Number of concurrent slices ofk_pairs_run cuts the batch into (1..8, default 1): each slice runs the whole stage chain on
  * its own HIP stream so that latency-bound stages overlap with streaming ones; results do not depend on it. */
 int ofk_set_streams(ofk_ctx *ctx, int nstreams);
+/* ofk_pairs_run scheduling (default on): run the HBM-bound work the corner response does not depend on (gray of the next
+ * frame, both pyramids) on an auxiliary stream beside the VALU-bound response kernel; joined before LK.  Results identical. */
+int ofk_set_overlap(ofk_ctx *ctx, int on);
 
 /* Per-stage HIP-event timing on the context's stream. */
 #define OFK_STAGE_GRAY    0

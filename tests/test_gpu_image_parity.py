@@ -32,7 +32,12 @@ def test_gray(gpu_ctx, shape):
     assert g[0, 0] == 255 and g[1, 0] == 29 and g[2, 0] == 150 and g[3, 0] == 76 and g[4, 0] == 0
 
 
-@pytest.mark.parametrize("shape", SHAPES + [(16, 17), (2, 2), (3, 300)])
+# widths that are multiples of 8 run the streaming kernel (strips of 496 source columns): one strip, exactly one strip,
+# the right edge in the strip's last lane / first lanes of the next strip, odd heights, the smallest size it accepts
+PYR_STREAM_SHAPES = [(4, 16), (5, 24), (37, 496), (64, 504), (35, 512), (21, 992), (67, 1000), (135, 960), (540, 960), (3, 16)]
+
+
+@pytest.mark.parametrize("shape", SHAPES + [(16, 17), (2, 2), (3, 300)] + PYR_STREAM_SHAPES)
 def test_pyr_down(gpu_ctx, shape):
     src = rand_u8((2,) + shape, 2)
     got = gpu_ctx.pyr_down(src)

@@ -110,10 +110,13 @@ def test_streams_do_not_change_results(pkg, ofk):
     sensors = ofk.make_sensors(5, scaling=base[0]["scaling"], cx=base[0]["cx"], cy=base[0]["cy"])
     cfg = PipelineConfig(max_corners=80, quality=0.03, min_distance=6)
     outs = []
-    for streams in (1, 2, 4, 8):
+    for streams, overlap in ((1, False), (1, True), (2, True), (4, False), (8, True)):
         pipe = FlowPipeline(320, 240, 5, cfg, streams=streams)
+        pipe.ctx.set_overlap(overlap)
         pipe.upload(prev, nxt, sensors)
-        outs.append(pipe.run())
+        for _ in range(3):
+            pipe.run_async()                                   # back to back: the auxiliary stream runs a call ahead
+        outs.append(pipe.run())                                # 4th run: both pyramid sets reused under the same schedule
         pipe.close()
     for o in outs[1:]:
         assert np.array_equal(o["counts"], outs[0]["counts"])
@@ -134,6 +137,7 @@ def test_profile_and_export(pkg, ofk):
     for _ in range(3):
         pipe.run_async()
     prof = pipe.ctx.profile_read()
-    # 'nms' has no launches of its own: threshold + 3x3 NMS are fused into the response kernel ('eig')
-    assert all(prof[s][1] == 3 and prof[s][0] > 0 for s in ofk.STAGES if s != "nms") and prof["nms"][1] == 0
+    # 'nms' has no launches of its own: threshold + 3x3 NMS are fused into the response kernel ('eig'); 'gray' is timed
+    # once per frame of the pair (the two conversions are separate launches on the auxiliary stream)
+    assert all(prof[s][1] == (6 if s == "gray" else 3) and prof[s][0] > 0 for s in ofk.STAGES if s != "nms") and prof["nms"][1] == 0
     pipe.close()
