@@ -305,8 +305,107 @@ __device__ __forceinline__ float wave_max_f32(float v)
     return fmaxf(fmaxf(a, b), fmaxf(c, d));
 }
 
+// Correctly rounded sqrt for x = 0 or x in the normal range well away from the denormals (here x = (a-c)^2 + b^2 with a, b, c
+// integer multiples of ~1e-8: zero or >= 1e-16).  v_sqrt_f32 is within 1 ulp; the two fused residuals pick the neighbour
+// that rounds correctly — the compiler's own sqrtf expansion, minus its rescaling of denormal inputs and its inf check.
+__device__ __forceinline__ float sqrt_rn_normal(float x)
+{
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float dn = __int_as_float(__float_as_int(s) - 1), up = __int_as_float(__float_as_int(s) + 1);
+    const float rdn = __builtin_fmaf(-dn, s, x), rup = __builtin_fmaf(-up, s, x);
+    float r = rdn <= 0.f ? dn : s;
+    r = rup > 0.f ? up : r;
+    return r;
+}
+
+// Horizontal box sum of BS consecutive lanes (x-BS+1 .. x).  A Horner chain of wave shifts costs BS-1 VALU slots, and the
+// kernel is bound by VALU issue while the LDS pipe idles — so beyond BS = 3 only the pair sum uses a DPP add and the pairs
+// (quads for BS = 12) are gathered with ds_bpermute, which runs on the LDS pipe: 3 VALU + 3 LDS instead of 6 (11) VALU.
+// Lanes below BS-1 receive garbage (bpermute wraps around), exactly the lanes that are never used.
+template <int BS>
+__device__ __forceinline__ int box_row(int a, int ad2, int ad4, int adl)
+{
+    if constexpr (BS == 5 || BS == 7 || BS == 12) {
+        const int p = DPP_SHR1(a) + a;                                           // x-1 .. x
+#ifdef OFK_ABLATE_GATHER                                                         /* timing experiment only (tools/variants.sh): wrong sums */
+        return p + (ad2 + ad4) + adl;
+#endif
+        if constexpr (BS == 5) return p + __builtin_amdgcn_ds_bpermute(ad2, p) + __builtin_amdgcn_ds_bpermute(ad4, a);
+        if constexpr (BS == 7) return p + __builtin_amdgcn_ds_bpermute(ad2, p) + (__builtin_amdgcn_ds_bpermute(ad4, p) + __builtin_amdgcn_ds_bpermute(adl, a));
+        if constexpr (BS == 12) {
+            const int q = p + __builtin_amdgcn_ds_bpermute(ad2, p);             // x-3 .. x
+            return q + __builtin_amdgcn_ds_bpermute(ad4, q) + __builtin_amdgcn_ds_bpermute(adl, q);
+        }
+    } else {
+        int hsum = a;
+#pragma unroll
+        for (int k = 1; k < BS; ++k) hsum = DPP_SHR1(hsum) + a;
+        return hsum;
+    }
+}
+
+// One block of BS rows of k_mineig_stream (expanded twice inside the kernel: IN = true for interior blocks).
+//  * dx is written as an ADD of the negated source: ROCm 7.2 folds `a - dpp(b)` into v_subrev_u32_dpp, which on gfx950
+//    returned shr(shl(s)) - s here (measured); v_add_u32_dpp is exact.
+//  * |dx|, |dy| <= 4080, so the products are exact in v_mul_i32_i24 (full rate; v_mul_lo_u32 is a quarter-rate
+//    instruction and three of them cost as much as twelve adds).  The empty asm keeps instruction selection from folding
+//    a product into v_mad_i32_i24 in front of the box sum, which would undo the v_add_u32_dpp pair sum.
+//  * A mirrored product row (column) has its y (x) derivative negated, which only flips the sign of dx*dy (border blocks).
+//  * Maxima run on the BIT PATTERNS as signed integers: the image maximum and every candidate are positive, and for a
+//    positive e1 "some neighbour is greater" is the same statement on floats and on their bits (negative floats are
+//    negative integers; there are no NaNs).  The row maxima hm include the centre, so max(hm0, hm1, hm2) == e1 iff none of
+//    the eight neighbours is greater — two wave shifts and two v_max3 per row.  thri >= 0, so e1i > thri implies e1 > 0.
+//  * Interior blocks take the running maximum over every lane; the columns that do not count are dropped when the maximum
+//    is published.  yo = response row completed by the step (garbage while r <= BS), yn = row whose 3x3 neighbourhood
+//    is complete.
+#define OFK_EIG_ROWS(IN)                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < BS; ++i) {                                                                   \
+        const int r = base + i;                                                                                        \
+        const int g2 = curg[i];                                                                                        \
+        const int s = g0 + 2 * g1 + g2, t = g2 - g0;                                                                   \
+        const int ns = -s;                                                                                             \
+        const int dx = DPP_SHL1(s) + DPP_SHR1(ns);                                                                     \
+        const int dy = (DPP_SHR1(t) + t) + (DPP_SHL1(t) + t);                                                          \
+        int pxx = __mul24(dx, dx), pyy = __mul24(dy, dy), pxy = __mul24(dx, dy);                                       \
+        asm("" : "+v"(pxx), "+v"(pxy), "+v"(pyy));                                                                     \
+        if (!(IN)) {                                                                                                   \
+            const int Y = Yp0 + r - 2;                                                                                 \
+            pxy = (((Y < 0) | (Y >= h)) != flipx) ? -pxy : pxy;                                                        \
+        }                                                                                                              \
+        const int hxx = box_row<BS>(pxx, ad2, ad4, adl), hxy = box_row<BS>(pxy, ad2, ad4, adl),                        \
+                  hyy = box_row<BS>(pyy, ad2, ad4, adl);                                                               \
+        vxx += hxx - ringxx[i]; vxy += hxy - ringxy[i]; vyy += hyy - ringyy[i];                                        \
+        ringxx[i] = hxx; ringxy[i] = hxy; ringyy[i] = hyy;                                                             \
+        const int yo = ya - 2 + r - BS;                                                                                \
+        const float a = (float)vxx * kd, bb = (float)vxy * ko, c = (float)vyy * kd;                                    \
+        const float amc = a - c;                                                                                       \
+        const int e2i = __float_as_int((a + c) - sqrt_rn_normal(amc * amc + bb * bb));                                 \
+        if ((IN) && !MASK) {                                                                                           \
+            lmaxi = max(lmaxi, e2i);                                                                                   \
+        } else {                                                                                                       \
+            bool cm = own_col & (yo >= ya) & (yo < yb);                                                                \
+            if (MASK) cm = cm & (mk[(size_t)min(max(yo, 0), h - 1) * w + xoc] != 0);                                   \
+            lmaxi = max(lmaxi, cm ? e2i : 0);                                                                          \
+        }                                                                                                              \
+        const int hm2 = max(max(DPP_SHR1(e2i), e2i), DPP_SHL1(e2i));                                                   \
+        const int yn = yo - 1;                                                                                         \
+        const int m = max(max(hm0, hm1), hm2);                                                                         \
+        bool is = e1i >= max(m, thr1);                                                                                 \
+        if (!(IN)) is = is & ((yn >= ya) & (yn < yb) & (yn >= 1) & (yn < h - 1));                                      \
+        if (MASK) is = is & (mk[(size_t)min(max(yn, 0), h - 1) * w + xoc] != 0);                                       \
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(is);                                                \
+        if (is) buf[cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))] =   \
+            ((unsigned long long)(~(unsigned)e1i) << 32) | (unsigned)(yn * w + xo);                                    \
+        cnt += __popcll(bal);                                                                                          \
+        e1i = e2i; hm0 = hm1; hm1 = hm2;                                                                               \
+        g0 = g1; g1 = g2;                                                                                              \
+    }
+
+#ifndef OFK_EIG_WAVES
+#define OFK_EIG_WAVES 4
+#endif
 template <int BS, bool MASK>
-__global__ __launch_bounds__(256) void k_mineig_stream(const uint8_t *__restrict__ gray, size_t gray_stride, int h, int w,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OFK_EIG_WAVES, 8))) void k_mineig_stream(const uint8_t *__restrict__ gray, size_t gray_stride, int h, int w,
                                                        int rows_per_strip, float kd, float ko,
                                                        unsigned int *__restrict__ maxbits, const uint8_t *__restrict__ mask,
                                                        size_t mask_stride, double quality,
@@ -315,8 +414,9 @@ __global__ __launch_bounds__(256) void k_mineig_stream(const uint8_t *__restrict
 {
     constexpr int AN = BS / 2, SW = 61 - BS;
     constexpr int NBUF = 64 + BS * SW;                          // keys a wave can hold between two flush points
-    __shared__ unsigned long long s_buf[4][NBUF];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ unsigned long long s_buf[4][NBUF + 64];          // + 64: a flush reads one whole 64-key chunk past the count
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform: strip geometry stays in SGPRs
     const int sx = blockIdx.x * 4 + wave;
     if (sx * SW >= w) return;                                   // whole wave
     const int b = blockIdx.z;
@@ -328,6 +428,7 @@ __global__ __launch_bounds__(256) void k_mineig_stream(const uint8_t *__restrict
     const int gx = sx * SW - 2 - AN + lane;                     // gray / product column of this lane
     const int gxr = reflect101(gx, w);
     const bool flipx = gx < 0 || gx >= w;
+    const bool edge_strip = sx * SW - 2 - AN < 0 || sx * SW - 2 - AN + 63 >= w;      // some lane is mirrored (wave-uniform)
     const int xo = gx - (BS - 1) + AN;                          // column of this lane's box sums / response
     const bool lane_ok = lane >= BS + 1 && lane <= 61;
     const bool own_col = lane_ok && xo >= 0 && xo < w;          // counted for the maximum (every pixel exactly once)
@@ -343,7 +444,8 @@ __global__ __launch_bounds__(256) void k_mineig_stream(const uint8_t *__restrict
     unsigned long long *myseg = seg + ((size_t)b * nseg + segid) * seg_cap;
     int written = 0;                                            // keys already in the segment (uniform)
     int cnt = 0;                                                // keys buffered in LDS by this wave (uniform)
-    float lmax = 0.f, published = 0.f;
+    int lmaxi = 0;                                              // bits of the running maximum (>= +0.0f)
+    float published = 0.f;
     unsigned mb_seen = __hip_atomic_load(maxbits + b * OFK_MAX_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // running maximum, refreshed per block
     float thr = (float)((double)__uint_as_float(mb_seen) * quality);
 
@@ -361,6 +463,7 @@ __global__ __launch_bounds__(256) void k_mineig_stream(const uint8_t *__restrict
     const int lrow = min(lane / 17, 2), lk = lane - 17 * (lane / 17);          // loader role of this lane (lanes >= 51: dummy)
     const unsigned ldoff = (unsigned)((gx0 & ~3) + 4 * min(lk, 16));
     const int srcsel = ((lane + sh) >> 2) * 4, bytesh = ((lane + sh) & 3) * 8;  // consumer role: source dword lane, byte
+    const int ad2 = ((lane - 2) & 63) * 4, ad4 = ((lane - 4) & 63) * 4, adl = ((lane - (BS == 12 ? 8 : 6)) & 63) * 4;   // box_row gathers
     auto row_of = [&](int r) -> int {
         int gy = Yp0 - 1 + min(r, nsteps - 1);
         gy = gy < 0 ? -gy : gy;
@@ -386,7 +489,7 @@ __global__ __launch_bounds__(256) void k_mineig_stream(const uint8_t *__restrict
 #pragma unroll
     for (int i = 0; i < BS; ++i) { ringxx[i] = 0; ringxy[i] = 0; ringyy[i] = 0; }
     int vxx = 0, vxy = 0, vyy = 0;
-    float e0 = 0.f, e1 = 0.f, hm0 = 0.f, hm1 = 0.f;
+    int e1i = 0, hm0 = 0, hm1 = 0;                              // bit patterns of f32 responses (see OFK_EIG_ROWS)
     int nextg[BS];
 #pragma unroll
     for (int i = 0; i < BS; ++i) nextg[i] = 0;
@@ -422,7 +525,7 @@ __global__ __launch_bounds__(256) void k_mineig_stream(const uint8_t *__restrict
             __builtin_amdgcn_wave_barrier();
             buf[lane] = rest;
             cnt -= nchunk * 64;
-            const float mw = wave_max_f32(lmax);
+            const float mw = wave_max_f32(own_col ? __int_as_float(lmaxi) : 0.f);
             if (mw > published) {                               // publish only when this strip raised its maximum
                 if (lane == 0) (void)atomicMax(maxbits + b * OFK_MAX_STRIDE, __float_as_uint(mw));
                 published = mw;
@@ -430,64 +533,17 @@ __global__ __launch_bounds__(256) void k_mineig_stream(const uint8_t *__restrict
             mb_seen = __hip_atomic_load(maxbits + b * OFK_MAX_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // consumed at the next block
         }
         OFK_LOAD_BLOCK(base + BS, nextg);                                      // prefetch the next block of rows
-        // ---- BS rows of straight-line code
-#pragma unroll
-        for (int i = 0; i < BS; ++i) {
-            const int r = base + i;
-#ifdef ABLATE_LOAD
-            const int g2 = (lane * 7 + r * 13) & 255;
-#else
-            const int g2 = curg[i];
-#endif
-            const int Y = Yp0 + r - 2;                          // product row
-            const bool flip = (Y < 0 || Y >= h) != flipx;
-            const int s = g0 + 2 * g1 + g2, t = g2 - g0;
-            // written as an ADD of the negated source: ROCm 7.2 folds `a - dpp(b)` into v_subrev_u32_dpp, which on gfx950
-            // returned shr(shl(s)) - s here (measured); v_add_u32_dpp is exact
-            const int ns = -s;
-            const int dx = DPP_SHL1(s) + DPP_SHR1(ns);
-            const int dy = DPP_SHR1(t) + 2 * t + DPP_SHL1(t);
-            const int pxx = dx * dx, pyy = dy * dy, pxy = flip ? -(dx * dy) : dx * dy;
-            int hxx = pxx, hxy = pxy, hyy = pyy;
-#ifndef ABLATE_HORNER
-#pragma unroll
-            for (int k = 1; k < BS; ++k) { hxx = DPP_SHR1(hxx) + pxx; hxy = DPP_SHR1(hxy) + pxy; hyy = DPP_SHR1(hyy) + pyy; }
-#endif
-            vxx += hxx - ringxx[i]; vxy += hxy - ringxy[i]; vyy += hyy - ringyy[i];
-            ringxx[i] = hxx; ringxy[i] = hxy; ringyy[i] = hyy;
-            const int yo = ya - 2 + r - BS;                     // response row completed by this step (garbage while r <= BS)
-            const float a = (float)vxx * kd, bb = (float)vxy * ko, c = (float)vyy * kd;
-            const float amc = a - c;
-#ifdef ABLATE_EIG
-            const float e2 = a + bb + c + amc;
-#else
-            const float e2 = (a + c) - sqrtf(amc * amc + bb * bb);
-#endif
-            const bool row_own = yo >= ya && yo < yb;           // uniform
-            bool cnt_max = own_col && row_own;
-            if (MASK) cnt_max = cnt_max && mk[(size_t)min(max(yo, 0), h - 1) * w + xoc] != 0;
-            lmax = cnt_max ? fmaxf(lmax, e2) : lmax;
-#ifdef OFK_DEBUG_EIG
-            if (own_col && row_own) g_dbg_eig[(size_t)yo * w + xo] = e2;
-#endif
-            const float hm2 = fmaxf(fmaxf(__int_as_float(DPP_SHR1(__float_as_int(e2))), e2), __int_as_float(DPP_SHL1(__float_as_int(e2))));
-            const int yn = yo - 1;                              // row whose 3x3 neighbourhood is now complete
-            const bool row_nms = yn >= ya && yn < yb && yn >= 1 && yn < h - 1;     // uniform
-            const float m = fmaxf(fmaxf(hm0, hm2), fmaxf(__int_as_float(DPP_SHR1(__float_as_int(e1))), __int_as_float(DPP_SHL1(__float_as_int(e1)))));
-#ifdef ABLATE_NMS
-            bool is = nms_col && row_nms && e1 > 1e30f && !(m > e1);
-#else
-            bool is = nms_col && row_nms && e1 > thr && e1 > 0.f && !(m > e1);
-#endif
-            if (MASK) is = is && mk[(size_t)min(max(yn, 0), h - 1) * w + xoc] != 0;
-            const unsigned long long bal = __ballot(is);
-            if (is) buf[cnt + __popcll(bal & ((1ull << lane) - 1))] = ((unsigned long long)(~__float_as_uint(e1)) << 32) | (unsigned)(yn * w + xo);
-            cnt += __popcll(bal);
-            e0 = e1; e1 = e2; hm0 = hm1; hm1 = hm2;
-            g0 = g1; g1 = g2;
-        }
+        // ---- BS rows of straight-line code, in two versions: most blocks are INTERIOR (no mirrored product row or
+        //      column, every response row owned by this strip, every NMS row valid) and skip the border bookkeeping
+        const int r1 = base + BS - 1;
+        const bool interior = !edge_strip && Yp0 + base - 2 >= 0 && Yp0 + r1 - 2 < h && base >= BS + 3 && ya - 3 + base - BS >= 1 &&
+                              ya - 2 + r1 - BS < yb && ya - 3 + r1 - BS < h - 1;
+        // candidate <=> e1 is a strict-or-equal 3x3 maximum (m == e1i, and m >= e1i always) above the threshold, in a
+        // column that may hold a corner: ONE compare, e1i >= max(m, thr1), with thr1 = threshold bits + 1 (never for the
+        // other columns).  A single compare feeds the ballot directly; an AND of compares costs two extra VALU slots.
+        const int thr1 = nms_col ? __float_as_int(fmaxf(thr, 0.f)) + 1 : 0x7fffffff;
+        if (interior) { OFK_EIG_ROWS(true) } else { OFK_EIG_ROWS(false) }
     }
-    (void)e0;
     // ---- tail: remaining keys, the segment's count and the strip maximum
     __builtin_amdgcn_wave_barrier();
     for (int i = lane; i < cnt; i += 64)
@@ -496,7 +552,7 @@ __global__ __launch_bounds__(256) void k_mineig_stream(const uint8_t *__restrict
         seg_count[(size_t)b * nseg + segid] = min(written + cnt, seg_cap);
         if (written + cnt > seg_cap) (void)atomicOr(flags, 1);
     }
-    const float mw = wave_max_f32(lmax);
+    const float mw = wave_max_f32(own_col ? __int_as_float(lmaxi) : 0.f);
     if (lane == 0 && mw > published) (void)atomicMax(maxbits + b * OFK_MAX_STRIDE, __float_as_uint(mw));
 }
 

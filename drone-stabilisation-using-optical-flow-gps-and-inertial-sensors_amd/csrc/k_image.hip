@@ -253,7 +253,8 @@ static void launch_pyr_stream(hipStream_t s, const uint8_t *src0, const uint8_t 
 {
     const int dh = (h + 1) / 2, dw = (w + 1) / 2;
     const int nstrips = (w + PDS_COLS - 1) / PDS_COLS;
-    int rows = images >= 32 ? 32 : 8;                           // fewer, longer strips when the batch already fills the chip
+    int rows = 32;                                              // long strips re-read fewer halo rows; shorten them until the
+    while (rows > 4 && (long long)nstrips * ((dh + rows - 1) / rows) * images < 8192) rows >>= 1;   // launch has >= 8 waves per SIMD
     if (const char *e = getenv("OFK_PYR_ROWS")) { const int v = atoi(e); if (v >= 1 && v <= 4096) rows = v; }   // tuning knob
     const int nchunks = (dh + rows - 1) / rows;
     dim3 grid((nstrips * nchunks + 3) / 4, images);

@@ -1,0 +1,36 @@
+#!/bin/bash
+# Tuning experiments for one kernel file: build libofk variants that differ in -D flags of ONE source file, then (on the
+# GPU box) time bench.py with each of them copied over the product library.  Variants live in build_variants/ (ignored
+# by git, shipped by gpurun).
+#   tools/variants.sh build k_corners.hip "w4:-DOFK_EIG_WAVES=4" "w6:-DOFK_EIG_WAVES=6" ...
+#   tools/variants.sh run   [bench.py flags]          # on the GPU box; restores nothing: the snapshot is scratch
+set -e
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+PKG="$ROOT/drone-stabilisation-using-optical-flow-gps-and-inertial-sensors_amd"
+CS="$PKG/csrc"
+OUT="$ROOT/build_variants"
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -fno-fast-math -I$ROOT/include -I$CS"
+case "$1" in
+build)
+    src=$2; shift 2
+    mkdir -p "$OUT"; rm -f "$OUT"/*.so
+    make -s -C "$CS"
+    extra=""; [ "$src" = k_corners.hip ] && extra="-fno-slp-vectorize"
+    for spec in "$@"; do
+        name=${spec%%:*}; defs=${spec#*:}
+        /opt/rocm/bin/hipcc $FLAGS $extra $defs -c "$CS/$src" -o "$OUT/$name.o"
+        objs=""
+        for o in "$CS"/build/*.o; do [ "$(basename "$o")" = "${src%.hip}.o" ] && objs="$objs $OUT/$name.o" || objs="$objs $o"; done
+        /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libofk_$name.so" $objs
+        echo "built $name ($defs)"
+    done ;;
+run)
+    shift
+    mkdir -p "$ROOT/gpurun_out"
+    for lib in "$OUT"/libofk_*.so; do
+        name=$(basename "$lib" .so); name=${name#libofk_}
+        cp "$lib" "$PKG/libofk.so"
+        timeout -k 10 200 python "$ROOT/bench.py" --cpu-sample 0 "$@" > "$ROOT/gpurun_out/var_$name.log" 2>&1 || { echo "$name failed"; tail -3 "$ROOT/gpurun_out/var_$name.log"; exit 1; }
+        echo "== $name"; python "$ROOT/tools/show_bench.py" "$ROOT/gpurun_out/var_$name.log" | grep -E "frame-pairs|eig|lk |pyr|gray"
+    done ;;
+esac
