@@ -556,11 +556,264 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OFK_EIG_WAV
     if (lane == 0 && mw > published) (void)atomicMax(maxbits + b * OFK_MAX_STRIDE, __float_as_uint(mw));
 }
 
-// Geometry of the streaming kernel's segments for an image of h x w (shared by launcher and host-side sizing).
+// ------------------------------------------------------------------------------------------------ streaming response, 2 columns / lane
+// k_mineig_pair<BS>: the same march as k_mineig_stream with every lane owning TWO adjacent columns (even slot 2l, odd slot
+// 2l+1 of a 128-column strip).  The kernel is bound by VALU issue (SQ counters: ~1 VALU instruction per 4 clocks per SIMD,
+// 98 % of the time), so what counts is instructions per pixel:
+//   * the halo (BS + 3 columns) is paid once per 128 columns instead of once per 64: 116 of 128 columns are outputs for
+//     BS = 7 (54 of 64 before);
+//   * one of the two x-neighbours of a column lives in the same lane, so Sobel and the 3x3 maximum need half the wave
+//     shifts per pixel;
+//   * the box sums work on pair sums q = a_e + a_o: for BS = 2K+1, s_o(l) = a_o(l-K) + q(l-K+1..l) and
+//     s_e(l) = a_e(l) + q(l-K..l-1) share their gathers (ds_bpermute on the otherwise idle LDS pipe);
+//   * gray rows arrive as aligned dwords, two rows per wave-load, for EVERY strip: the strip origin is a multiple of 4
+//     and mirrored border columns are patched from the lanes that hold their sources (two gathers per row, border strips
+//     only) — no byte-load path.
+// Integer sums and the f32 formula are those of k_mineig_stream (and of the oracle), so results are bit-identical.
+template <int K>
+__device__ __forceinline__ void box_pair(int ae, int ao, int ad2, int ad3, int &he, int &ho)
+{
+    const int q = ae + ao;
+    if constexpr (K == 1) {
+        ho = DPP_SHR1(ao) + q;
+        he = ae + DPP_SHR1(q);
+    } else {
+        const int P = DPP_SHR1(q) + q;                                           // q(l-1) + q(l)
+        const int g2q = __builtin_amdgcn_ds_bpermute(ad2, q);                    // q(l-2)
+        if constexpr (K == 2) {
+            ho = P + __builtin_amdgcn_ds_bpermute(ad2, ao);
+            he = (P - ao) + g2q;
+        } else {
+            ho = P + g2q + __builtin_amdgcn_ds_bpermute(ad3, ao);
+            he = (P - ao) + g2q + __builtin_amdgcn_ds_bpermute(ad3, q);
+        }
+    }
+}
+
+__device__ __forceinline__ int lambda_min_bits(int vxx, int vxy, int vyy, float kd, float ko)
+{
+    const float a = (float)vxx * kd, bb = (float)vxy * ko, c = (float)vyy * kd;
+    const float amc = a - c;
+    return __float_as_int((a + c) - sqrt_rn_normal(amc * amc + bb * bb));
+}
+
+// (Measured and dropped: the same formula on float PAIRS — v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 — executes 11 fewer
+//  instructions per row and is 10 % SLOWER: plain f32 add/mul/fma issue at twice the rate of the packed and VOP3 forms,
+//  tools/valu_rates.hip.)
+// One block of BS rows (expanded twice: IN = true for interior blocks); see OFK_EIG_ROWS for the conventions.
+#define OFK_PAIR_ROWS(IN)                                                                                             \
+    _Pragma("unroll") for (int i = 0; i < BS; ++i) {                                                                   \
+        const int r = base + i;                                                                                        \
+        int ge2 = (int)__builtin_amdgcn_ubfe((unsigned)curv[i], bsh, 8u), go2 = (int)__builtin_amdgcn_ubfe((unsigned)curv[i], bsh + 8u, 8u); \
+        if (!(IN)) {                                                                                                   \
+            if (edge_strip) { ge2 = __builtin_amdgcn_ds_bpermute(mir_e, ge2); go2 = __builtin_amdgcn_ds_bpermute(mir_o, go2); } \
+        }                                                                                                              \
+        const int se = g0e + 2 * g1e + ge2, so = g0o + 2 * g1o + go2, te = ge2 - g0e, to = go2 - g0o;                  \
+        const int nso = -so, nse = -se, tt = te + to;                                                                  \
+        const int dxe = DPP_SHR1(nso) + so;                                                                            \
+        const int dxo = DPP_SHL1(se) + nse;                                                                            \
+        const int dye = (DPP_SHR1(to) + te) + tt;                                                                      \
+        const int dyo = (DPP_SHL1(te) + to) + tt;                                                                      \
+        int pxxe = __mul24(dxe, dxe), pyye = __mul24(dye, dye), pxye = __mul24(dxe, dye);                              \
+        int pxxo = __mul24(dxo, dxo), pyyo = __mul24(dyo, dyo), pxyo = __mul24(dxo, dyo);                              \
+        asm("" : "+v"(pxxe), "+v"(pxye), "+v"(pyye), "+v"(pxxo), "+v"(pxyo), "+v"(pyyo));                              \
+        if (!(IN)) {                                                                                                   \
+            const int Y = Yp0 + r - 2;                                                                                 \
+            const bool rowflip = (Y < 0) | (Y >= h);                                                                   \
+            pxye = (rowflip != flip_e) ? -pxye : pxye;                                                                 \
+            pxyo = (rowflip != flip_o) ? -pxyo : pxyo;                                                                 \
+        }                                                                                                              \
+        int hxxe, hxxo, hxye, hxyo, hyye, hyyo;                                                                        \
+        box_pair<BS / 2>(pxxe, pxxo, ad2, ad3, hxxe, hxxo);                                                            \
+        box_pair<BS / 2>(pxye, pxyo, ad2, ad3, hxye, hxyo);                                                            \
+        box_pair<BS / 2>(pyye, pyyo, ad2, ad3, hyye, hyyo);                                                            \
+        vxxe += hxxe - rxxe[i]; vxye += hxye - rxye[i]; vyye += hyye - ryye[i];                                        \
+        vxxo += hxxo - rxxo[i]; vxyo += hxyo - rxyo[i]; vyyo += hyyo - ryyo[i];                                        \
+        rxxe[i] = hxxe; rxye[i] = hxye; ryye[i] = hyye; rxxo[i] = hxxo; rxyo[i] = hxyo; ryyo[i] = hyyo;                \
+        const int yo = ya - 2 + r - BS;                                                                                \
+        const int e2e = lambda_min_bits(vxxe, vxye, vyye, kd, ko), e2o = lambda_min_bits(vxxo, vxyo, vyyo, kd, ko);    \
+        if ((IN) && !MASK) {                                                                                           \
+            lmaxi = max(max(lmaxi, e2e), e2o);                                                                         \
+        } else {                                                                                                       \
+            const bool rown = (yo >= ya) & (yo < yb);                                                                  \
+            bool cme = own_e & rown, cmo = own_o & rown;                                                               \
+            if (MASK) {                                                                                                \
+                const uint8_t *mrow = mk + (size_t)min(max(yo, 0), h - 1) * w;                                         \
+                cme = cme & (mrow[xoc_e] != 0); cmo = cmo & (mrow[xoc_o] != 0);                                        \
+            }                                                                                                          \
+            lmaxi = max(max(lmaxi, cme ? e2e : 0), cmo ? e2o : 0);                                                     \
+        }                                                                                                              \
+        const int hm2e = max(max(DPP_SHR1(e2o), e2e), e2o);                                                            \
+        const int hm2o = max(max(DPP_SHL1(e2e), e2o), e2e);                                                            \
+        const int yn = yo - 1;                                                                                         \
+        const int me = max(max(hm0e, hm1e), hm2e), mo = max(max(hm0o, hm1o), hm2o);                                    \
+        bool ise = e1e >= max(me, thr1e), iso = e1o >= max(mo, thr1o);                                                 \
+        if (!(IN)) {                                                                                                   \
+            const bool rnms = (yn >= ya) & (yn < yb) & (yn >= 1) & (yn < h - 1);                                       \
+            ise = ise & rnms; iso = iso & rnms;                                                                        \
+        }                                                                                                              \
+        if (MASK) {                                                                                                    \
+            const uint8_t *mrow = mk + (size_t)min(max(yn, 0), h - 1) * w;                                             \
+            ise = ise & (mrow[xoc_e] != 0); iso = iso & (mrow[xoc_o] != 0);                                            \
+        }                                                                                                              \
+        const unsigned long long bale = __builtin_amdgcn_ballot_w64(ise), balo = __builtin_amdgcn_ballot_w64(iso);     \
+        const int ne = (int)__popcll(bale);                                                                            \
+        if (ise) buf[cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bale >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bale, 0u))] =   \
+            ((unsigned long long)(~(unsigned)e1e) << 32) | (unsigned)(yn * w + xo_e);                                  \
+        if (iso) buf[cnt + ne + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(balo >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)balo, 0u))] = \
+            ((unsigned long long)(~(unsigned)e1o) << 32) | (unsigned)(yn * w + xo_o);                                  \
+        cnt += ne + (int)__popcll(balo);                                                                               \
+        e1e = e2e; e1o = e2o; hm0e = hm1e; hm0o = hm1o; hm1e = hm2e; hm1o = hm2o;                                      \
+        g0e = g1e; g0o = g1o; g1e = ge2; g1o = go2;                                                                    \
+    }
+
+template <int BS> struct pair_geom {
+    static constexpr int AN = BS / 2, PAD = (2 + AN + 3) & ~3, D = PAD - 2 - AN, SW = (125 - BS) & ~3;
+};
+
+template <int BS, bool MASK>
+#ifndef OFK_PAIR_WAVES
+#define OFK_PAIR_WAVES 3                                        /* BS = 7 keeps 42 ring registers per lane: 3 waves per SIMD, no spills */
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OFK_PAIR_WAVES, 8))) void k_mineig_pair(
+    const uint8_t *__restrict__ gray, size_t gray_stride, int h, int w, int rows_per_strip, float kd, float ko,
+    unsigned int *__restrict__ maxbits, const uint8_t *__restrict__ mask, size_t mask_stride, double quality,
+    unsigned long long *__restrict__ seg, int seg_cap, int *__restrict__ seg_count, int *__restrict__ flags)
+{
+    static_assert(BS == 3 || BS == 5 || BS == 7, "pair sums are written for odd boxes up to 7");
+    constexpr int AN = pair_geom<BS>::AN, PAD = pair_geom<BS>::PAD, D = pair_geom<BS>::D, SW = pair_geom<BS>::SW;
+    constexpr int L0 = (BS + 1) / 2, L1 = (BS + 1 + SW) / 2;    // lanes [L0, L1) hold output columns (both slots)
+    constexpr int NBUF = 64 + BS * SW;                          // keys a wave can hold between two flush points
+    __shared__ unsigned long long s_buf[4][NBUF + 64];          // + 64: a flush reads one whole 64-key chunk past the count
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int sx = blockIdx.x * 4 + wave;
+    if (sx * SW - D >= w) return;                               // whole wave
+    const int b = blockIdx.z;
+    const int ya = blockIdx.y * rows_per_strip, yb = min(h, ya + rows_per_strip);
+    const uint8_t *img = gray + (size_t)b * gray_stride;
+    const uint8_t *mk = MASK ? mask + (size_t)b * mask_stride : nullptr;
+    unsigned long long *buf = s_buf[wave];
+
+    const int G0 = sx * SW - PAD;                               // gray column of lane 0's even slot: a multiple of 4
+    const int ce = G0 + 2 * lane;                               // this lane's even gray / product column (odd: ce + 1)
+    const bool edge_strip = G0 < 0 || G0 + 128 > w;             // some column is mirrored (wave-uniform)
+    const bool flip_e = ce < 0 || ce >= w, flip_o = ce + 1 < 0 || ce + 1 >= w;
+    const int xo_e = ce - (BS - 1) + AN, xo_o = xo_e + 1;       // columns of this lane's box sums / responses
+    const bool lane_ok = lane >= L0 && lane < L1;
+    const bool own_e = lane_ok && xo_e >= 0 && xo_e < w, own_o = lane_ok && xo_o >= 0 && xo_o < w;
+    const bool nms_e = lane_ok && xo_e >= 1 && xo_e < w - 1, nms_o = lane_ok && xo_o >= 1 && xo_o < w - 1;
+    const int xoc_e = min(max(xo_e, 0), w - 1), xoc_o = min(max(xo_o, 0), w - 1);
+
+    const int Yp0 = ya - 1 - AN;                                // first product row
+    const int nsteps = (yb - ya) + BS + 3;
+    const int nstrips = (w + D + SW - 1) / SW;
+    const int nseg = nstrips * (int)gridDim.y, segid = (int)blockIdx.y * nstrips + sx;
+    unsigned long long *myseg = seg + ((size_t)b * nseg + segid) * seg_cap;
+    int written = 0, cnt = 0;
+    int lmaxi = 0;
+    float published = 0.f;
+    unsigned mb_seen = __hip_atomic_load(maxbits + b * OFK_MAX_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float thr = (float)((double)__uint_as_float(mb_seen) * quality);
+
+    // loader role: lane (lrow, lk) fetches dword lk of the 128-byte row segment of row lrow of a row pair (clamped into the
+    // image: the clamped dwords only ever feed mirrored columns, which are patched below).  consumer role: the pair of
+    // bytes (2l, 2l+1) sits in dword l/2, bytes (l&1)*2 and +1.
+    const int lrow = lane >> 5, lk = lane & 31;
+    const unsigned ldoff = (unsigned)min(max(G0 + 4 * lk, 0), w - 4);
+    const int srcsel = (lane >> 1) * 4;
+    const unsigned bsh = (unsigned)(lane & 1) * 16u;
+    auto mirror = [&](int c) -> int { c = c < 0 ? -c : c; c = c >= w ? 2 * (w - 1) - c : c; return min(max((c - G0) >> 1, 0), 63) * 4; };
+    const int mir_e = mirror(ce), mir_o = mirror(ce + 1);       // lane that holds the source of a mirrored column (else: itself)
+    const int ad2 = ((lane - 2) & 63) * 4, ad3 = ((lane - 3) & 63) * 4;
+    constexpr int NL = (BS + 1) / 2;                            // dword loads per block of BS rows (two rows each)
+    auto row_of = [&](int r) -> int {
+        int gy = Yp0 - 1 + min(r, nsteps - 1);
+        gy = gy < 0 ? -gy : gy;
+        return gy >= h ? 2 * (h - 1) - gy : gy;
+    };
+#define OFK_PAIR_LOAD(R0, OUT)                                                                                         \
+    _Pragma("unroll") for (int q_ = 0; q_ < NL; ++q_) {                                                                \
+        const int a_ = row_of((R0) + 2 * q_), b_ = row_of((R0) + 2 * q_ + 1);                                          \
+        OUT[q_] = (int)*reinterpret_cast<const unsigned *>(img + (size_t)(lrow ? b_ : a_) * w + ldoff);                \
+    }
+
+    int g0e = 0, g0o = 0, g1e = 0, g1o = 0;
+    int rxxe[BS], rxye[BS], ryye[BS], rxxo[BS], rxyo[BS], ryyo[BS];
+#pragma unroll
+    for (int i = 0; i < BS; ++i) { rxxe[i] = rxye[i] = ryye[i] = rxxo[i] = rxyo[i] = ryyo[i] = 0; }
+    int vxxe = 0, vxye = 0, vyye = 0, vxxo = 0, vxyo = 0, vyyo = 0;
+    int e1e = 0, e1o = 0, hm0e = 0, hm0o = 0, hm1e = 0, hm1o = 0;
+    int nextg[NL];
+    OFK_PAIR_LOAD(0, nextg)
+
+    for (int base = 0; base < nsteps; base += BS) {
+        int curv[BS];
+#pragma unroll
+        for (int i = 0; i < BS; ++i) curv[i] = __builtin_amdgcn_ds_bpermute(srcsel + 128 * (i & 1), nextg[i >> 1]);
+        {
+            unsigned cur_seen = (unsigned)__builtin_amdgcn_readfirstlane((int)mb_seen);
+            if (__float_as_uint(published) > cur_seen) cur_seen = __float_as_uint(published);
+            thr = (float)((double)__uint_as_float(cur_seen) * quality);
+        }
+        if (cnt >= 64) {                                        // move full 64-key chunks to this strip's segment, publish the maximum
+            const int nchunk = cnt >> 6;
+            for (int q = 0; q < nchunk; ++q) {
+                const unsigned long long key = buf[q * 64 + lane];
+                if (written + q * 64 + lane < seg_cap) myseg[written + q * 64 + lane] = key;
+            }
+            written += nchunk * 64;
+            const unsigned long long rest = buf[nchunk * 64 + lane];
+            __builtin_amdgcn_wave_barrier();
+            buf[lane] = rest;
+            cnt -= nchunk * 64;
+            const float mw = wave_max_f32(lane_ok ? __int_as_float(lmaxi) : 0.f);
+            if (mw > published) {
+                if (lane == 0) (void)atomicMax(maxbits + b * OFK_MAX_STRIDE, __float_as_uint(mw));
+                published = mw;
+            }
+            mb_seen = __hip_atomic_load(maxbits + b * OFK_MAX_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        OFK_PAIR_LOAD(base + BS, nextg)                         // prefetch the next block of rows
+        const int r1 = base + BS - 1;
+        const bool interior = !edge_strip && Yp0 + base - 2 >= 0 && Yp0 + r1 - 2 < h && base >= BS + 3 && ya - 3 + base - BS >= 1 &&
+                              ya - 2 + r1 - BS < yb && ya - 3 + r1 - BS < h - 1;
+        const int thrb = __float_as_int(fmaxf(thr, 0.f)) + 1;
+        const int thr1e = nms_e ? thrb : 0x7fffffff, thr1o = nms_o ? thrb : 0x7fffffff;
+        if (interior) { OFK_PAIR_ROWS(true) } else { OFK_PAIR_ROWS(false) }
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < cnt; i += 64)
+        if (written + i < seg_cap) myseg[written + i] = buf[i];
+    if (lane == 0) {
+        seg_count[(size_t)b * nseg + segid] = min(written + cnt, seg_cap);
+        if (written + cnt > seg_cap) (void)atomicOr(flags, 1);
+    }
+    const float mw = wave_max_f32(lane_ok ? __int_as_float(lmaxi) : 0.f);
+    if (lane == 0 && mw > published) (void)atomicMax(maxbits + b * OFK_MAX_STRIDE, __float_as_uint(mw));
+}
+
+// The pair kernel takes odd boxes up to 7 on images whose rows are dword multiples and wide enough for one mirror fold.
+static bool pair_ok(int w, int block)
+{
+    static const bool off = getenv("OFK_NO_PAIR") != nullptr;   // tuning knob: one column per lane everywhere
+    return !off && (block == 3 || block == 5 || block == 7) && (w & 3) == 0 && w >= 64;
+}
+static void pair_sw(int block, int *sw, int *d)
+{
+    switch (block) {
+        case 3: *sw = pair_geom<3>::SW; *d = pair_geom<3>::D; break;
+        case 5: *sw = pair_geom<5>::SW; *d = pair_geom<5>::D; break;
+        default: *sw = pair_geom<7>::SW; *d = pair_geom<7>::D; break;
+    }
+}
+
+// Geometry of the streaming kernels' segments for an image of h x w (shared by launcher and host-side sizing).
 void ofk_stream_geometry(int h, int w, int block, int batch, int *rows, int *nseg, int *seg_cap)
 {
-    const int SW = 61 - block;
-    const int strips = (w + SW - 1) / SW;
+    int SW = 61 - block, d = 0;
+    if (pair_ok(w, block)) pair_sw(block, &SW, &d);
+    const int strips = (w + d + SW - 1) / SW;
     int r = batch >= 16 ? 128 : 32;                             // fewer, longer strips when the batch already fills the chip
     if (const char *e = getenv("OFK_EIG_ROWS")) { const int v = atoi(e); if (v >= 8 && v <= 4096) r = v; }   // tuning knob
     while (strips * ((h + r - 1) / r) > 2048) r *= 2;           // k_select walks at most 2048 segments per image
@@ -592,6 +845,30 @@ static int launch_mineig_stream(hipStream_t s, const uint8_t *gray, size_t gray_
     return 0;
 }
 
+template <int BS>
+static int launch_mineig_pair(hipStream_t s, const uint8_t *gray, size_t gray_stride, int h, int w, unsigned int *maxbits,
+                              const uint8_t *mask, size_t mask_stride, double quality, unsigned long long *seg,
+                              size_t seg_keys_per_image, int *seg_count, int seg_count_cap, int *flags, int batch, int *nseg_out,
+                              int *segcap_out)
+{
+    constexpr int SW = pair_geom<BS>::SW, D = pair_geom<BS>::D;
+    int rows, nseg, seg_cap;
+    ofk_stream_geometry(h, w, BS, batch, &rows, &nseg, &seg_cap);
+    if ((size_t)nseg * seg_cap > seg_keys_per_image || nseg > seg_count_cap) return -1;
+    const int strips = (w + D + SW - 1) / SW;
+    const double scale = 1.0 / (4.0 * BS * 255.0);
+    const float kd = (float)(0.5 * scale * scale), ko = (float)(scale * scale);
+    dim3 grid((strips + 3) / 4, (h + rows - 1) / rows, batch);
+    if (mask)
+        hipLaunchKernelGGL((k_mineig_pair<BS, true>), grid, dim3(256), 0, s, gray, gray_stride, h, w, rows, kd, ko, maxbits, mask,
+                           mask_stride, quality, seg, seg_cap, seg_count, flags);
+    else
+        hipLaunchKernelGGL((k_mineig_pair<BS, false>), grid, dim3(256), 0, s, gray, gray_stride, h, w, rows, kd, ko, maxbits, mask,
+                           mask_stride, quality, seg, seg_cap, seg_count, flags);
+    *nseg_out = nseg; *segcap_out = seg_cap;
+    return 0;
+}
+
 // Response + 3x3 NMS + candidate keys + image maximum; no map.  Block sizes 3/5/7/12 run the streaming kernel, which
 // writes per-strip SEGMENTS (*nseg_out > 0); the others run the LDS-tile kernel, which appends to the flat list.
 int ofk_launch_mineig_cand(hipStream_t s, const uint8_t *gray, size_t gray_stride, int h, int w, int block,
@@ -603,6 +880,13 @@ int ofk_launch_mineig_cand(hipStream_t s, const uint8_t *gray, size_t gray_strid
     *nseg_out = 0; *segcap_out = 0;
 #define ME_ARGS s, gray, gray_stride, h, w, block, nullptr, 0, maxbits, mask, mask_stride, quality, cand, cand_cap, cand_count, flags, batch
 #define ST_ARGS s, gray, gray_stride, h, w, maxbits, mask, mask_stride, quality, seg, seg_keys_per_image, seg_count, seg_count_cap, flags, batch, nseg_out, segcap_out
+    if (pair_ok(w, block)) {
+        switch (block) {
+            case 3: return launch_mineig_pair<3>(ST_ARGS);
+            case 5: return launch_mineig_pair<5>(ST_ARGS);
+            default: return launch_mineig_pair<7>(ST_ARGS);
+        }
+    }
     switch (block) {
         case 3: return launch_mineig_stream<3>(ST_ARGS);
         case 5: return launch_mineig_stream<5>(ST_ARGS);

@@ -31,22 +31,27 @@ __global__ __launch_bounds__(256) void k_gray_bgr8(const uint8_t *__restrict__ b
     const int p0 = t * 16;
     if (p0 >= npx) return;
     if (p0 + 16 <= npx) {
+        // 2*(3735 b + 19235 g + 9798 r) + 32768 = 256 * dot(px, HI) + dot(px, LO) + 32768 with byte-sized coefficients
+        // (7470 = 29*256 + 46, 38470 = 150*256 + 70, 19596 = 76*256 + 140): two v_dot4_u32_u8 per pixel, and the gray value
+        // (sum >> 16; the sum stays below 2^24) is byte 2 of the result — v_perm gathers four of them into the output dword.
+        // One v_alignbit brings the pixel's three bytes to the bottom of a dword (the fourth byte meets coefficient 0).
+        constexpr unsigned HI = 29u | (150u << 8) | (76u << 16), LO = 46u | (70u << 8) | (140u << 16);
         const uint4 *s4 = reinterpret_cast<const uint4 *>(src + (size_t)p0 * 3);
         const uint4 a = s4[0], c = s4[1], d = s4[2];
-        const unsigned wv[12] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+        const unsigned wv[13] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w, 0u};
+        unsigned t[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int byte = 3 * k;
+            const unsigned px = (byte & 3) ? __builtin_amdgcn_alignbit(wv[(byte >> 2) + 1], wv[byte >> 2], (byte & 3) * 8) : wv[byte >> 2];
+            t[k] = (__builtin_amdgcn_udot4(px, HI, 0u, false) << 8) + __builtin_amdgcn_udot4(px, LO, 32768u, false);
+        }
         unsigned out[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            unsigned o = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int byte = (q * 4 + k) * 3;
-                const unsigned bb = (wv[byte >> 2] >> ((byte & 3) * 8)) & 255u;
-                const unsigned gg = (wv[(byte + 1) >> 2] >> (((byte + 1) & 3) * 8)) & 255u;
-                const unsigned rr = (wv[(byte + 2) >> 2] >> (((byte + 2) & 3) * 8)) & 255u;
-                o |= gray1(bb, gg, rr) << (8 * k);
-            }
-            out[q] = o;
+            const unsigned p01 = __builtin_amdgcn_perm(t[4 * q + 1], t[4 * q], 0x0c0c0602u);      // (t0.b2, t1.b2, 0, 0)
+            const unsigned p23 = __builtin_amdgcn_perm(t[4 * q + 3], t[4 * q + 2], 0x06020c0cu);  // (0, 0, t2.b2, t3.b2)
+            out[q] = p01 | p23;
         }
         *reinterpret_cast<uint4 *>(dst + p0) = make_uint4(out[0], out[1], out[2], out[3]);
     } else {
