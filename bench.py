@@ -59,17 +59,13 @@ def algorithmic_bytes(cfg, n_pts, n_cand):
     }
 
 
-STAGE_KERNEL = {"gray": "k_gray_bgr8", "pyr": "k_pyr_down", "eig": "k_mineig_stream<7, false>", "select": "k_select", "lk": "k_lk15",
-                "solve": "k_pairs_solve"}
-
-
 def pmc_traffic(stage, pairs_per_launch):
-    """HBM bytes per launch of the stage's kernel from the committed rocprofv3 PMC passes (profiles/r01_traffic_pmc.json,
-    collected by tools/profile_round.sh on this same command), scaled to the pairs one launch processes; None if absent."""
+    """HBM bytes per launch group of the stage from the committed rocprofv3 PMC passes (profiles/r01_traffic_pmc.json,
+    written by tools/profile_round.sh + tools/make_traffic_json.py from this same command), scaled to the pairs one launch
+    group processes; None if absent."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic_pmc.json")))
-        k = t["kernels"][STAGE_KERNEL[stage]]
-        return int(k["hbm_bytes_per_launch"] * pairs_per_launch / t["batch"])
+        return int(t["stages"][stage]["hbm_bytes_per_step"] * pairs_per_launch / t["batch"])
     except Exception:
         return None
 
@@ -99,7 +95,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=128, help="frame pairs per GPU per step")
+    ap.add_argument("--batch", type=int, default=256, help="frame pairs per GPU per step")
     ap.add_argument("--streams", type=int, default=1, help="concurrent slices of the batch (HIP streams) per GPU")
     ap.add_argument("--no-overlap", action="store_true", help="run every stage of a step serially on one stream")
     ap.add_argument("--cpu-sample", type=int, default=24, help="pairs timed on the CPU oracle (0 = skip)")
@@ -137,32 +133,45 @@ def main():
 
     gathered = rec_t = None
     if dist is not None:
-        rec_t = torch.zeros((B, 8), dtype=torch.float32, device=f"cuda:{local}")
+        rec_t = [torch.zeros((B, 8), dtype=torch.float32, device=f"cuda:{local}") for _ in range(2)]
         gathered = torch.zeros((world * B, 8), dtype=torch.float32, device=f"cuda:{local}")
 
     def sync_all():
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
-        else:
-            pipe.ctx._ck(pipe.ctx._L.ofk_device_sync())
+        pipe.ctx._ck(pipe.ctx._L.ofk_device_sync())
 
-    def step():
-        pipe.run_async()
+    # The exchange is software-pipelined by one step: step k is queued on the library's stream (its records exported into
+    # buffer k%2, a completion mark behind them), then the host waits for the mark of step k-1 and all_gathers THAT
+    # buffer over RCCL while the GPU is already working on step k.  K steps issue K gathers; the last one drains below.
+    pending = []
+
+    def gather_pending():
+        if pending:
+            k = pending.pop(0)
+            pipe.ctx.mark_wait(k % 2)                    # records of step k are complete in rec_t[k % 2]
+            sharding.gather_records(dist, rec_t[k % 2], out=gathered)
+            torch.cuda.current_stream().synchronize()    # the buffer is free again before step k+2 exports into it
+
+    def run_steps(n, k0):
+        for k in range(k0, k0 + n):
+            pipe.run_async()
+            if dist is not None:
+                pipe.ctx.pairs_export_records_f32(rec_t[k % 2].data_ptr(), B)
+                pipe.ctx.mark(k % 2)
+                gather_pending()
+                pending.append(k)
         if dist is not None:
-            pipe.ctx.pairs_export_records_f32(rec_t.data_ptr(), B)
-            pipe.sync()                                  # records complete on the library's stream
-            sharding.gather_records(dist, rec_t, out=gathered)
+            gather_pending()
 
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup, 0)
     sync_all()
     pipe.ctx.profile_read()
     pipe.ctx.profile_enable(0x7f)
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run_steps(args.steps, args.warmup)
     sync_all()
     dt = time.perf_counter() - t0
     prof = pipe.ctx.profile_read()

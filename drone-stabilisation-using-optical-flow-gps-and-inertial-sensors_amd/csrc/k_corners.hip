@@ -675,7 +675,10 @@ template <int BS, bool MASK>
 #ifndef OFK_PAIR_WAVES
 #define OFK_PAIR_WAVES 3                                        /* BS = 7 keeps 42 ring registers per lane: 3 waves per SIMD, no spills */
 #endif
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OFK_PAIR_WAVES, 8))) void k_mineig_pair(
+#ifndef OFK_PAIR_VGPRS
+#define OFK_PAIR_VGPRS 168
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OFK_PAIR_WAVES, 8), amdgpu_num_vgpr(OFK_PAIR_VGPRS))) void k_mineig_pair(
     const uint8_t *__restrict__ gray, size_t gray_stride, int h, int w, int rows_per_strip, float kd, float ko,
     unsigned int *__restrict__ maxbits, const uint8_t *__restrict__ mask, size_t mask_stride, double quality,
     unsigned long long *__restrict__ seg, int seg_cap, int *__restrict__ seg_count, int *__restrict__ flags)

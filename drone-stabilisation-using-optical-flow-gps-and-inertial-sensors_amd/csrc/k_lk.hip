@@ -64,6 +64,7 @@ __global__ __launch_bounds__(64) void k_lk(const uint8_t *__restrict__ prev, con
     const float ptx = prev_pts[2 * pi], pty = prev_pts[2 * pi + 1];
     const uint8_t *Pb = prev + (size_t)b * pyr_stride, *Nb = next + (size_t)b * pyr_stride;
     const float half = (float)(win - 1) * 0.5f;
+    const float eps2_lo = (float)(eps2 * (1.0 - 1e-5)), eps2_hi = (float)(eps2 * (1.0 + 1e-5));
     const int ww = win * win;
     const int iw_ = win + 3, dw_ = win + 1, jw_ = win + 1 + 2 * LK_M;
 
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(64) void k_lk(const uint8_t *__restrict__ prev, con
     for (int l = lv.n; l >= 0; --l) {
         const int lh = lv.h[l], lw = lv.w[l];
         const uint8_t *I = Pb + lv.off[l], *J = Nb + lv.off[l];
-        const float sc = (float)(1.0 / (double)(1 << l));
+        const float sc = __int_as_float((127 - l) << 23);           // 2^-l, exactly what (float)(1.0 / (double)(1 << l)) is
         float px = ptx * sc, py = pty * sc, qx, qy;
         if (l == lv.n) { qx = px; qy = py; } else { qx = nx * 2.f; qy = ny * 2.f; }
         nx = qx; ny = qy;
@@ -183,8 +184,13 @@ __global__ __launch_bounds__(64) void k_lk(const uint8_t *__restrict__ prev, con
             const float dx = (A12 * fb2 - A22 * fb1) * D, dy = (A12 * fb1 - A11 * fb2) * D;
             qx += dx; qy += dy;
             nx = qx + half; ny = qy + half;
-            if ((double)dx * (double)dx + (double)dy * (double)dy <= eps2) break;
-            if (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) {
+            // |delta|^2 <= eps^2 is defined in f64; the f32 value decides it unless it falls within 1e-5 of the threshold
+            // (its own error is 2e-7), so the half-rate f64 instructions only run in that band
+            const float d2 = dx * dx + dy * dy;
+            if (d2 < eps2_lo) break;
+            if (d2 <= eps2_hi && (double)dx * (double)dx + (double)dy * (double)dy <= eps2) break;
+            // an f32 x satisfies |x| < 0.01 (the f64 constant) iff |x| <= 0.01f: 0.01f is the largest f32 below 0.01
+            if (j > 0 && fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f) {
                 nx -= dx * 0.5f; ny -= dy * 0.5f;
                 break;
             }
@@ -245,13 +251,39 @@ __device__ __forceinline__ long long wave_sum_rows(int v)
     return (long long)__builtin_amdgcn_readlane(v, 0) + (long long)__builtin_amdgcn_readlane(v, 16) +
            (long long)__builtin_amdgcn_readlane(v, 32) + (long long)__builtin_amdgcn_readlane(v, 48);
 }
-// f32((exact wave sum) * 2^-20): the sum of four int32 row sums is exact in f64, so this equals f32(f64(int64 sum) * 2^-20)
+// f32(S * 2^-20) of an exact integer S, round to nearest even — bit for bit what (float)((double)S * 0x1p-20) returns (the
+// double is exact, the scaling a power of two).  S is wave-uniform, so the whole conversion runs on the SCALAR unit
+// (s_flbit_i32_b64, 64-bit shifts); the f64 route cost ten half-rate VALU instructions per sum, two sums per Newton step.
+__device__ __forceinline__ float scaled_f32_from_i64(long long S)
+{
+    if (S == 0) return 0.f;
+    const unsigned sign = S < 0 ? 0x80000000u : 0u;
+    const unsigned long long M = S < 0 ? (unsigned long long)(-S) : (unsigned long long)S;
+    const int e = 63 - __builtin_clzll(M);                                        // position of the leading one
+    unsigned q;                                                                    // 24-bit significand, leading one included
+    if (e <= 23) {
+        q = (unsigned)(M << (23 - e));
+    } else {
+        const int sh = e - 23;
+        q = (unsigned)(M >> sh);
+        const unsigned long long rem = M & ((1ull << sh) - 1), half = 1ull << (sh - 1);
+        q += (unsigned)((rem > half) | ((rem == half) & (q & 1u)));               // may carry into 2^24: the add below absorbs it
+    }
+    return __uint_as_float(sign | (((unsigned)(e - 20 + 126) << 23) + q));         // (E-1) << 23 plus the significand with its leading one
+}
 __device__ __forceinline__ float wave_sum_rows_scaled(int v)
 {
     v = row_sum16(v);
+#ifdef OFK_LK_SCALAR_CVT          /* measured: the scalar route is 5 % slower (three scalar branches, 64-bit compares fall back to the VALU) */
+    const long long S = (long long)__builtin_amdgcn_readlane(v, 0) + (long long)__builtin_amdgcn_readlane(v, 16) +
+                        (long long)__builtin_amdgcn_readlane(v, 32) + (long long)__builtin_amdgcn_readlane(v, 48);
+    return scaled_f32_from_i64(S);
+#else
+    // the sum of four int32 row sums is exact in f64, so this equals f32(f64(int64 sum) * 2^-20)
     const double d = ((double)__builtin_amdgcn_readlane(v, 0) + (double)__builtin_amdgcn_readlane(v, 16)) +
                      ((double)__builtin_amdgcn_readlane(v, 32) + (double)__builtin_amdgcn_readlane(v, 48));
     return (float)(d * 0x1p-20);
+#endif
 }
 
 // 5 consecutive bytes starting at byte offset `off` of an LDS byte array (4-byte aligned base)
@@ -277,8 +309,8 @@ __device__ __forceinline__ void lds_read7(const uint8_t *base, int off, int t[7]
 __global__ __launch_bounds__(64) void k_lk15(const uint8_t *__restrict__ prev, const uint8_t *__restrict__ next,
                                              size_t pyr_stride, ofk_levels lv, const float *__restrict__ prev_pts,
                                              const int *__restrict__ counts, int pts_stride, int win, int max_count,
-                                             double eps2, double min_eig_thr, float *__restrict__ next_pts,
-                                             uint8_t *__restrict__ status, float *__restrict__ err)
+                                             double eps2, float eps2_lo, float eps2_hi, double min_eig_thr,
+                                             float *__restrict__ next_pts, uint8_t *__restrict__ status, float *__restrict__ err)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_I[20 * LKF_IP];
     __shared__ __attribute__((aligned(16))) uint8_t s_J[(LKF_JW + 1) * LKF_JW];
@@ -301,7 +333,7 @@ __global__ __launch_bounds__(64) void k_lk15(const uint8_t *__restrict__ prev, c
     for (int l = lv.n; l >= 0; --l) {
         const int lh = lv.h[l], lw = lv.w[l];
         const uint8_t *I = Pb + lv.off[l], *J = Nb + lv.off[l];
-        const float sc = (float)(1.0 / (double)(1 << l));
+        const float sc = __int_as_float((127 - l) << 23);           // 2^-l, exactly what (float)(1.0 / (double)(1 << l)) is
         float px = ptx * sc, py = pty * sc, qx, qy;
         if (l == lv.n) { qx = px; qy = py; } else { qx = nx * 2.f; qy = ny * 2.f; }
         nx = qx; ny = qy;
@@ -447,8 +479,13 @@ __global__ __launch_bounds__(64) void k_lk15(const uint8_t *__restrict__ prev, c
             const float dx = (A12 * fb2 - A22 * fb1) * D, dy = (A12 * fb1 - A11 * fb2) * D;
             qx += dx; qy += dy;
             nx = qx + half; ny = qy + half;
-            if ((double)dx * (double)dx + (double)dy * (double)dy <= eps2) break;
-            if (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) {
+            // |delta|^2 <= eps^2 is defined in f64; the f32 value decides it unless it falls within 1e-5 of the threshold
+            // (its own error is 2e-7), so the half-rate f64 instructions only run in that band
+            const float d2 = dx * dx + dy * dy;
+            if (d2 < eps2_lo) break;
+            if (d2 <= eps2_hi && (double)dx * (double)dx + (double)dy * (double)dy <= eps2) break;
+            // an f32 x satisfies |x| < 0.01 (the f64 constant) iff |x| <= 0.01f: 0.01f is the largest f32 below 0.01
+            if (j > 0 && fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f) {
                 nx -= dx * 0.5f; ny -= dy * 0.5f;
                 break;
             }
@@ -495,7 +532,7 @@ void ofk_launch_lk(hipStream_t s, const uint8_t *prev, const uint8_t *next, size
     dim3 grid(pts_stride, batch);
     if (win <= 15)
         hipLaunchKernelGGL(k_lk15, grid, dim3(64), 0, s, prev, next, pyr_stride, lv, prev_pts, counts, pts_stride, win,
-                           max_count, eps2, min_eig_thr, next_pts, status, err);
+                           max_count, eps2, (float)(eps2 * (1.0 - 1e-5)), (float)(eps2 * (1.0 + 1e-5)), min_eig_thr, next_pts, status, err);
     else if (win <= 15)
         hipLaunchKernelGGL(k_lk<15>, grid, dim3(64), 0, s, prev, next, pyr_stride, lv, prev_pts, counts, pts_stride, win,
                            max_count, eps2, min_eig_thr, next_pts, status, err);

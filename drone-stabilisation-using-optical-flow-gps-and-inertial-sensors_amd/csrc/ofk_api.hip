@@ -160,6 +160,7 @@ extern "C" int ofk_destroy(ofk_ctx *c)
         for (int s = 0; s < 2; ++s) if (c->ev_lkdone[s][k]) hipEventDestroy(c->ev_lkdone[s][k]);
     }
     for (int k = 0; k < 2; ++k) if (c->pyr_alt[k]) hipFree(c->pyr_alt[k]);
+    for (int k = 0; k < 8; ++k) if (c->marks[k]) hipEventDestroy(c->marks[k]);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->stream) hipStreamDestroy(c->stream);
     free(c);
@@ -852,6 +853,23 @@ extern "C" int ofk_set_overlap(ofk_ctx *c, int on)
 {
     if (!c) return OFK_E_INVALID;
     c->overlap = on ? 1 : 0;
+    return OFK_OK;
+}
+
+extern "C" int ofk_mark(ofk_ctx *c, int slot)
+{
+    if (!c || slot < 0 || slot >= 8) return ofk_fail(c, OFK_E_INVALID, "ofk_mark: slot 0..7");
+    OFK_HIP(c, hipSetDevice(c->device));
+    if (!c->marks[slot]) OFK_HIP(c, hipEventCreateWithFlags(&c->marks[slot], hipEventDisableTiming));
+    OFK_HIP(c, hipEventRecord(c->marks[slot], c->stream));
+    return OFK_OK;
+}
+
+extern "C" int ofk_mark_wait(ofk_ctx *c, int slot)
+{
+    if (!c || slot < 0 || slot >= 8) return ofk_fail(c, OFK_E_INVALID, "ofk_mark_wait: slot 0..7");
+    if (!c->marks[slot]) return OFK_OK;
+    OFK_HIP(c, hipEventSynchronize(c->marks[slot]));
     return OFK_OK;
 }
 

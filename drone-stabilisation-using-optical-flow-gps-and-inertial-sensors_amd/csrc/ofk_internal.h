@@ -28,6 +28,7 @@ struct ofk_ctx {
     hipEvent_t ev_g0[OFK_MAX_STREAMS], ev_aux[OFK_MAX_STREAMS];
     uint8_t *pyr_alt[2]; int pyr_set;                     // second pyramid set: the auxiliary stream runs one call ahead
     hipEvent_t ev_lkdone[2][OFK_MAX_STREAMS];             // LK of the call that last read a set has finished
+    hipEvent_t marks[8];                                  // ofk_mark / ofk_mark_wait
     int max_w, max_h, max_batch, max_pts, max_level;
     size_t P;                       // max_w * max_h
     size_t bgr_stride;              // bytes between images in bgr[], 256-B aligned

@@ -27,7 +27,7 @@ SYMBOLS = (
     "ofk_good_features", "ofk_lk_pyr", "ofk_flow_model", "ofk_feasibility", "ofk_velocity_solve", "ofk_imu_propagate",
     "ofk_post_solve", "ofk_kf_predict_update", "ofk_of_simulation", "ofk_pairs_upload", "ofk_pairs_set_sensors",
     "ofk_pairs_run", "ofk_pairs_download", "ofk_pairs_export_records_f32", "ofk_stream_begin", "ofk_stream_step",
-    "ofk_set_streams", "ofk_set_overlap", "ofk_profile_enable", "ofk_profile_read",
+    "ofk_set_streams", "ofk_set_overlap", "ofk_mark", "ofk_mark_wait", "ofk_profile_enable", "ofk_profile_read",
 )
 
 
@@ -86,6 +86,7 @@ def load_library():
         L.ofk_stream_step.argtypes = [vp, vp, vp, C.POINTER(Params), i, i, vp, vp, vp]
         L.ofk_set_streams.argtypes = [vp, i]
         L.ofk_set_overlap.argtypes = [vp, i]
+        L.ofk_mark.argtypes = [vp, i]; L.ofk_mark_wait.argtypes = [vp, i]
         L.ofk_profile_enable.argtypes = [vp, i]
         L.ofk_profile_read.argtypes = [vp, vp, vp]
         for s in SYMBOLS:
@@ -408,6 +409,14 @@ class Context:
 
     def set_overlap(self, on):
         self._ck(self._L.ofk_set_overlap(self._h, 1 if on else 0))
+
+    def mark(self, slot=0):
+        """Records a completion mark behind everything queued on the context's stream (slots 0..7)."""
+        self._ck(self._L.ofk_mark(self._h, int(slot)))
+
+    def mark_wait(self, slot=0):
+        """Blocks the host until mark `slot` has been reached; later work keeps running."""
+        self._ck(self._L.ofk_mark_wait(self._h, int(slot)))
 
     def set_streams(self, n):
         self._ck(self._L.ofk_set_streams(self._h, int(n)))

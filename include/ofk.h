@@ -201,9 +201,15 @@ int ofk_stream_step(ofk_ctx *ctx, const uint8_t *next_bgr, const double *sensors
 /* Number of concurrent slices ofk_pairs_run cuts the batch into (1..8, default 1): each slice runs the whole stage chain on
  * its own HIP stream so that latency-bound stages overlap with streaming ones; results do not depend on it. */
 int ofk_set_streams(ofk_ctx *ctx, int nstreams);
-/* ofk_pairs_run scheduling (default on): run the HBM-bound work the corner response does not depend on (gray of the next
- * frame, both pyramids) on an auxiliary stream beside the VALU-bound response kernel; joined before LK.  Results identical. */
+/* ofk_pairs_run scheduling (default on): the HBM-bound gray conversions and pyramids run on an auxiliary stream into one
+ * of two pyramid buffer sets, alternating per call, so that they overlap the VALU-bound response kernel and LK — of this call
+ * and, when calls are queued back to back, of the previous one.  Results identical. */
 int ofk_set_overlap(ofk_ctx *ctx, int on);
+/* Completion marks on the context's stream (slots 0..7): ofk_mark records one behind everything queued so far, ofk_mark_wait
+ * blocks the host until it has been reached (returns at once for a slot never marked).  They let a caller hand step k's
+ * records to another library (an RCCL gather) while step k+1 is already queued, without draining the stream. */
+int ofk_mark(ofk_ctx *ctx, int slot);
+int ofk_mark_wait(ofk_ctx *ctx, int slot);
 
 /* Per-stage HIP-event timing on the context's stream. */
 #define OFK_STAGE_GRAY    0

@@ -127,6 +127,27 @@ def test_streams_do_not_change_results(pkg, ofk):
         assert np.array_equal(o["records"], outs[0]["records"])
 
 
+def test_marks(pkg, ofk):
+    """ofk_mark / ofk_mark_wait: waiting for step k's mark returns its complete records while step k+1 is queued behind."""
+    from of_amd import synth
+    from of_amd.pipeline import FlowPipeline, PipelineConfig
+    prev, nxt, base = synth.make_batch(3, 240, 320, seed=12, distinct=3)
+    pipe = FlowPipeline(320, 240, 3, PipelineConfig(max_corners=64, quality=0.05))
+    pipe.upload(prev, nxt, ofk.make_sensors(3, scaling=base[0]["scaling"], cx=base[0]["cx"], cy=base[0]["cy"]))
+    ref = pipe.run()["records"]
+    pipe.ctx.mark_wait(5)                                       # never marked: returns at once
+    for k in range(4):
+        pipe.run_async()
+        pipe.ctx.mark(k % 2)
+        if k:
+            pipe.ctx.mark_wait((k - 1) % 2)
+    pipe.ctx.mark_wait(1)
+    assert np.array_equal(pipe.ctx.pairs_download(points=False)["records"], ref)
+    with pytest.raises(ofk.OfkError):
+        pipe.ctx.mark(8)
+    pipe.close()
+
+
 def test_profile_and_export(pkg, ofk):
     from of_amd import synth
     from of_amd.pipeline import FlowPipeline, PipelineConfig
