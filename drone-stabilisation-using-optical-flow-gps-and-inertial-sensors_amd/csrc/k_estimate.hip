@@ -567,3 +567,64 @@ void ofk_launch_of_simulation(hipStream_t s, const double *truth, const double *
 {
     hipLaunchKernelGGL(k_of_simulation, dim3(trials), dim3(256), 0, s, truth, sig, pos, true_flow, n, z, v_obs, bound);
 }
+
+// ------------------------------------------------------------------------------------------------ sensor association (ingest)
+// evaluate_exp.py:77-95 — for every image time the nearest IMU and range samples (np.argmin(np.abs(values - t)): the FIRST
+// minimum), then d = range, R from the IMU quaternion, normal = R e_z, omega = angular velocity, written into the pair's
+// sensor row (d, normal, omega, rotation; the other fields are left as they are).  One block per image.
+__device__ int nearest_sample(const double *__restrict__ ts, int n, double t, double *s_v, int *s_i)
+{
+    const int tid = threadIdx.x;
+    double best = INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < n; i += 256) {
+        const double d = fabs(ts[i] - t);
+        if (d < best) { best = d; bi = i; }                     // strict: the earliest of equal distances stays
+    }
+    s_v[tid] = best; s_i[tid] = bi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+            const double v = s_v[tid + o];
+            const int j = s_i[tid + o];
+            if (v < s_v[tid] || (v == s_v[tid] && j < s_i[tid])) { s_v[tid] = v; s_i[tid] = j; }
+        }
+        __syncthreads();
+    }
+    const int r = s_i[0];
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(256) void k_associate(const double *__restrict__ t_img, int n_imu, const double *__restrict__ imu_t,
+                                                   const double *__restrict__ imu_q, const double *__restrict__ imu_w, int n_hgt,
+                                                   const double *__restrict__ hgt_t, const double *__restrict__ hgt_r,
+                                                   double *__restrict__ sensors, int *__restrict__ imu_idx, int *__restrict__ hgt_idx)
+{
+    __shared__ double s_v[256];
+    __shared__ int s_i[256];
+    const int b = blockIdx.x;
+    const double t = t_img[b];
+    const int ii = nearest_sample(imu_t, n_imu, t, s_v, s_i);
+    const int hi = nearest_sample(hgt_t, n_hgt, t, s_v, s_i);
+    if (threadIdx.x != 0) return;
+    imu_idx[b] = ii; hgt_idx[b] = hi;
+    const double x = imu_q[4 * ii], y = imu_q[4 * ii + 1], z = imu_q[4 * ii + 2], w = imu_q[4 * ii + 3];
+    double *sr = sensors + (size_t)b * OFK_SENSOR_DOUBLES;
+    double R[9];
+    R[0] = 1.0 - 2 * (y * y + z * z); R[1] = 2 * (x * y - w * z);       R[2] = 2 * (w * y + x * z);
+    R[3] = 2 * (x * y + w * z);       R[4] = 1.0 - 2 * (x * x + z * z); R[5] = 2 * (y * z - w * x);
+    R[6] = 2 * (x * z - w * y);       R[7] = 2 * (w * x + y * z);       R[8] = 1.0 - 2 * (x * x + y * y);
+    sr[0] = hgt_r[hi];
+    sr[1] = R[2]; sr[2] = R[5]; sr[3] = R[8];                   // R (0,0,1)^T
+    sr[4] = imu_w[3 * ii]; sr[5] = imu_w[3 * ii + 1]; sr[6] = imu_w[3 * ii + 2];
+    for (int k = 0; k < 9; ++k) sr[7 + k] = R[k];
+}
+
+void ofk_launch_associate(hipStream_t s, const double *t_img, int n_img, int n_imu, const double *imu_t, const double *imu_q,
+                          const double *imu_w, int n_hgt, const double *hgt_t, const double *hgt_r, double *sensors, int *imu_idx,
+                          int *hgt_idx)
+{
+    hipLaunchKernelGGL(k_associate, dim3(n_img), dim3(256), 0, s, t_img, n_imu, imu_t, imu_q, imu_w, n_hgt, hgt_t, hgt_r, sensors,
+                       imu_idx, hgt_idx);
+}

@@ -519,6 +519,26 @@ extern "C" int ofk_post_solve(ofk_ctx *c, const double *v_obs, const double *rot
     return get(c, v_uav, dout, batch * 24);
 }
 
+extern "C" int ofk_associate_sensors(ofk_ctx *c, const double *t_img, int n_img, const double *imu_t, const double *imu_quat,
+                                     const double *imu_omega, int n_imu, const double *hgt_t, const double *hgt_range, int n_hgt,
+                                     double *sensors, int *imu_index, int *hgt_index)
+{
+    if (!c || !t_img || !imu_t || !imu_quat || !imu_omega || !hgt_t || !hgt_range || !sensors || n_img < 1 || n_imu < 1 || n_hgt < 1)
+        return ofk_fail(c, OFK_E_INVALID, "ofk_associate_sensors: bad argument (every log needs at least one sample)");
+    Bump bp;
+    TRY(est_begin(c, ((size_t)n_img * (1 + OFK_SENSOR_DOUBLES + 1) + (size_t)n_imu * 8 + (size_t)n_hgt * 2) * 8, bp));
+    double *dt = bp.put(t_img, (size_t)n_img * 8), *dit = bp.put(imu_t, (size_t)n_imu * 8), *diq = bp.put(imu_quat, (size_t)n_imu * 32),
+           *diw = bp.put(imu_omega, (size_t)n_imu * 24), *dht = bp.put(hgt_t, (size_t)n_hgt * 8), *dhr = bp.put(hgt_range, (size_t)n_hgt * 8),
+           *ds = bp.put(sensors, (size_t)n_img * OFK_SENSOR_DOUBLES * 8);
+    int *dii = (int *)bp.take((size_t)n_img * 4), *dhi = (int *)bp.take((size_t)n_img * 4);
+    if (bp.rc) return ofk_fail(c, OFK_E_HIP, "ofk_associate_sensors: upload failed");
+    ofk_launch_associate(c->stream, dt, n_img, n_imu, dit, diq, diw, n_hgt, dht, dhr, ds, dii, dhi);
+    TRY(check_launch(c, "k_associate"));
+    if (imu_index) TRY(get(c, imu_index, dii, (size_t)n_img * 4));
+    if (hgt_index) TRY(get(c, hgt_index, dhi, (size_t)n_img * 4));
+    return get(c, sensors, ds, (size_t)n_img * OFK_SENSOR_DOUBLES * 8);
+}
+
 extern "C" int ofk_kf_predict_update(ofk_ctx *c, int ns, int nm, int nc, const double *F, const double *Bm, const double *H,
                                      const double *Q, const double *Rm, double *x, double *P, const double *u, const double *z,
                                      int batch, int do_predict)

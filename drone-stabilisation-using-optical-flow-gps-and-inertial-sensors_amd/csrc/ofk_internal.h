@@ -132,3 +132,6 @@ void ofk_launch_kf(hipStream_t s, int ns, int nm, int nc, const double *F, const
 void ofk_launch_of_simulation(hipStream_t s, const double *truth, const double *sig, const double *pos,
                               const double *true_flow, int n, const double *z, int trials, double *v_obs,
                               double *bound);
+void ofk_launch_associate(hipStream_t s, const double *t_img, int n_img, int n_imu, const double *imu_t, const double *imu_q,
+                          const double *imu_w, int n_hgt, const double *hgt_t, const double *hgt_r, double *sensors, int *imu_idx,
+                          int *hgt_idx);

@@ -284,33 +284,18 @@ def read_yaml_imu(yamlfile):
     logs with a SAFE loader that maps the `!!python/object` tags to plain dicts; entries are
     [t, orientation, orientation_cov, linear_acc, linear_acc_cov, angular_velocity, angular_velocity_cov],
     built from the last message backwards like the reference."""
-    import yaml
-
-    class _Loader(yaml.SafeLoader):
-        pass
-
-    def _any(loader, suffix, node):
-        if isinstance(node, yaml.MappingNode):
-            m = loader.construct_mapping(node, deep=True)
-            return m.get("state", m)
-        if isinstance(node, yaml.SequenceNode):
-            return loader.construct_sequence(node, deep=True)
-        return loader.construct_scalar(node)
-
-    _Loader.add_multi_constructor("tag:yaml.org,2002:python/", _any)
-    with open(yamlfile, "r") as fh:
-        data = yaml.load(fh, Loader=_Loader)
+    from .ingest import load_ros_yaml
 
     def vec(v, keys):
-        return [v[k] for k in keys] if isinstance(v, dict) else list(v)
+        return [getattr(v, k) for k in keys]
 
     stack = []
-    for entry in reversed(data or []):
-        st = entry["header"]["stamp"]
-        stack.append([st["secs"] + float(st["nsecs"] / 10 ** 6), vec(entry["orientation"], "xyzw"),
-                      entry.get("orientation_covariance"), vec(entry["linear_acceleration"], "xyz"),
-                      entry.get("linear_acceleration_covariance"), vec(entry["angular_velocity"], "xyz"),
-                      entry.get("angular_velocity_covariance")])
+    for entry in reversed(load_ros_yaml(yamlfile)):
+        st = entry.header.stamp
+        stack.append([st.secs + float(st.nsecs / 10 ** 6), vec(entry.orientation, "xyzw"),
+                      getattr(entry, "orientation_covariance", None), vec(entry.linear_acceleration, "xyz"),
+                      getattr(entry, "linear_acceleration_covariance", None), vec(entry.angular_velocity, "xyz"),
+                      getattr(entry, "angular_velocity_covariance", None)])
     return stack
 
 

@@ -25,7 +25,7 @@ SYMBOLS = (
     "ofk_version", "ofk_last_error", "ofk_device_count", "ofk_create", "ofk_destroy", "ofk_sync", "ofk_device_sync",
     "ofk_gray_bgr8", "ofk_pyr_down_u8", "ofk_scharr_s16", "ofk_mineig_response", "ofk_select_corners",
     "ofk_good_features", "ofk_lk_pyr", "ofk_flow_model", "ofk_feasibility", "ofk_velocity_solve", "ofk_imu_propagate",
-    "ofk_post_solve", "ofk_kf_predict_update", "ofk_of_simulation", "ofk_pairs_upload", "ofk_pairs_set_sensors",
+    "ofk_post_solve", "ofk_kf_predict_update", "ofk_of_simulation", "ofk_associate_sensors", "ofk_pairs_upload", "ofk_pairs_set_sensors",
     "ofk_pairs_run", "ofk_pairs_download", "ofk_pairs_export_records_f32", "ofk_stream_begin", "ofk_stream_step",
     "ofk_set_streams", "ofk_set_overlap", "ofk_mark", "ofk_mark_wait", "ofk_profile_enable", "ofk_profile_read",
 )
@@ -75,6 +75,7 @@ def load_library():
         L.ofk_velocity_solve.argtypes = [vp, i, vp, vp, vp, i, i, vp, vp, vp, vp, vp, vp]
         L.ofk_imu_propagate.argtypes = [vp, vp, vp, i]
         L.ofk_post_solve.argtypes = [vp, vp, vp, vp, vp, i, vp]
+        L.ofk_associate_sensors.argtypes = [vp, vp, i, vp, vp, vp, i, vp, vp, i, vp, vp, vp]
         L.ofk_kf_predict_update.argtypes = [vp, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i]
         L.ofk_of_simulation.argtypes = [vp, vp, vp, vp, vp, i, vp, i, vp, vp]
         L.ofk_pairs_upload.argtypes = [vp, vp, vp, i, i, i]
@@ -314,6 +315,20 @@ class Context:
         with self._lock:
             self._ck(self._L.ofk_post_solve(self._h, _p(v2), _p(R), _p(ang), _p(offset), B, _p(out)))
         return out[0] if single else out
+
+    def associate_sensors(self, t_img, imu_t, imu_quat, imu_omega, hgt_t, hgt_range, sensors=None):
+        """evaluate_exp.py:68-95 on the device: nearest IMU / range sample per image time -> (sensors, imu_index, hgt_index).
+        `sensors` ([n_img, 28]) supplies the fields the association does not touch (offset, scaling, centre, prior)."""
+        t_img = _arr(np.atleast_1d(t_img), np.float64); n = len(t_img)
+        imu_t = _arr(imu_t, np.float64); ni = len(imu_t)
+        q = _arr(imu_quat, np.float64, (ni, 4)); w = _arr(imu_omega, np.float64, (ni, 3))
+        hgt_t = _arr(hgt_t, np.float64); nh = len(hgt_t); r = _arr(hgt_range, np.float64, (nh,))
+        out = make_sensors(n) if sensors is None else np.array(_arr(sensors, np.float64, (n, SENSOR_DOUBLES)))
+        ii = np.empty(n, np.int32); hi = np.empty(n, np.int32)
+        with self._lock:
+            self._ck(self._L.ofk_associate_sensors(self._h, _p(t_img), n, _p(imu_t), _p(q), _p(w), ni, _p(hgt_t), _p(r), nh,
+                                                   _p(out), _p(ii), _p(hi)))
+        return out, ii, hi
 
     def kf_predict_update(self, F, H, Q, R, x, P, B=None, u=None, z=None, do_predict=True):
         F = _arr(F, np.float64); H = _arr(H, np.float64); Q = _arr(Q, np.float64); R = _arr(R, np.float64)

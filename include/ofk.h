@@ -122,6 +122,15 @@ int ofk_velocity_solve(ofk_ctx *ctx, int variant, const double *x, const double 
 #define OFK_IMU_MSG   15
 int ofk_imu_propagate(ofk_ctx *ctx, double *state, const double *msg, int batch);
 
+/* evaluate_exp.py:68-95 — sensor association for replayed logs: for every image time t_img[k] (seconds, as the script forms
+ * them: float(secs - secs0) + float(nsecs)/1e9) the nearest IMU and range samples (np.argmin(np.abs(values - t)): the first
+ * minimum), then d = range, R from the IMU quaternion (x,y,z,w), normal = R e_z, omega = angular velocity.  Fills fields
+ * 0-15 of sensors[k] (see OFK_SENSOR_DOUBLES below; the other fields keep their values) and, when not NULL, the chosen
+ * indices.  imu_quat [n_imu][4], imu_omega [n_imu][3]. */
+int ofk_associate_sensors(ofk_ctx *ctx, const double *t_img, int n_img, const double *imu_t, const double *imu_quat,
+                          const double *imu_omega, int n_imu, const double *hgt_t, const double *hgt_range, int n_hgt,
+                          double *sensors, int *imu_index, int *hgt_index);
+
 /* node:258 — v_uav = R (v_obs - [w]x offset).  v_obs, ang, offset [batch][3]; rotation [batch][9]; v_uav [batch][3]. */
 int ofk_post_solve(ofk_ctx *ctx, const double *v_obs, const double *rotation, const double *ang, const double *offset,
                    int batch, double *v_uav);

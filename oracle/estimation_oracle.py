@@ -230,3 +230,17 @@ def of_simulation(linear_velocity, angular_velocity, height_above_gr, normal_vec
         Rb[i] = np.sqrt(np.sum(part ** 2)) + np.linalg.norm(av) * sig[1] + sig[0] * np.linalg.norm(tr) + sig[0] * sig[1]
         feas = feasibility_sim(pos_err, lv, flow_err, ang_err, tr_err, normal_err)
     return v_obs, feas, Rb
+
+
+def associate(t_img, imu_t, imu_q, imu_w, hgt_t, hgt_r):
+    """evaluate_exp.py:77-95 for a batch of image times: nearest IMU / range sample (np.argmin of the absolute time
+    difference: the first minimum), dist = range, R from the quaternion (same expression as quat_to_rot), normal = R e_z,
+    omega = angular velocity.  Returns (imu_index, hgt_index, d, R [n,3,3], normal [n,3], omega [n,3])."""
+    t_img = np.atleast_1d(np.asarray(t_img, np.float64))
+    imu_t = np.asarray(imu_t, np.float64); hgt_t = np.asarray(hgt_t, np.float64)
+    imu_q = np.asarray(imu_q, np.float64).reshape(-1, 4); imu_w = np.asarray(imu_w, np.float64).reshape(-1, 3)
+    ii = np.array([int(np.argmin(np.abs(imu_t - t))) for t in t_img])
+    hi = np.array([int(np.argmin(np.abs(hgt_t - t))) for t in t_img])
+    R = np.array([quat_to_rot(*imu_q[k]) for k in ii])
+    normal = np.array([np.dot(Rk, np.array([0, 0, 1])) for Rk in R])
+    return ii, hi, np.asarray(hgt_r, np.float64)[hi], R, normal, imu_w[ii]
