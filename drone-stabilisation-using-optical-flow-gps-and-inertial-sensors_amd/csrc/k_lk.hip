@@ -278,11 +278,17 @@ __device__ __forceinline__ float wave_sum_rows_scaled(int v)
     const long long S = (long long)__builtin_amdgcn_readlane(v, 0) + (long long)__builtin_amdgcn_readlane(v, 16) +
                         (long long)__builtin_amdgcn_readlane(v, 32) + (long long)__builtin_amdgcn_readlane(v, 48);
     return scaled_f32_from_i64(S);
-#else
+#elif defined(OFK_LK_F64_ADDS)
     // the sum of four int32 row sums is exact in f64, so this equals f32(f64(int64 sum) * 2^-20)
     const double d = ((double)__builtin_amdgcn_readlane(v, 0) + (double)__builtin_amdgcn_readlane(v, 16)) +
                      ((double)__builtin_amdgcn_readlane(v, 32) + (double)__builtin_amdgcn_readlane(v, 48));
     return (float)(d * 0x1p-20);
+#else
+    // the four row sums are added as 64-bit integers on the scalar unit (they sit in SGPRs after v_readlane); the int64 is
+    // below 2^33, so its f64 image and the scaling are exact and one rounding to f32 remains — as in the oracle
+    const long long S = ((long long)__builtin_amdgcn_readlane(v, 0) + (long long)__builtin_amdgcn_readlane(v, 16)) +
+                        ((long long)__builtin_amdgcn_readlane(v, 32) + (long long)__builtin_amdgcn_readlane(v, 48));
+    return (float)((double)S * 0x1p-20);
 #endif
 }
 
