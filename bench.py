@@ -14,10 +14,16 @@ barrier + device synchronize on both sides, MAX over ranks.  Under torchrun the 
 torch.distributed (nccl = RCCL) and torch.cuda.synchronize(); a plain single-process run (N=1) has nothing to
 exchange and uses hipDeviceSynchronize through the library, so torch is not imported at all.
 
+Under torchrun the gather is pipelined one step behind the compute (ofk_mark / ofk_mark_wait): step k's records
+travel while step k+1 runs; K steps issue K gathers inside the timed region.
+
 The JSON line also carries
-  roofline     : the stage with the largest share of the step, from HIP events recorded on the library's stream inside
-                 the timed region; achieved = SURVEY.md §8(d) algorithmic bytes per pair x B / mean stage time.
-  stages       : the same for every stage (ms per step, algorithmic GB/s).
+  roofline     : the longest stage on the step's critical path, from HIP events recorded inside the timed region on the
+                 stream the stage is launched on; achieved = SURVEY.md §8(d) algorithmic bytes per pair x B / mean stage
+                 time, traffic = HBM bytes from the committed PMC passes; `valu` = the same kernel against the VALU
+                 issue peak (its real bound), from the committed SQ_INSTS_VALU count and its time alone on the chip.
+  stages       : the same for every stage (ms per step, algorithmic GB/s) under the default overlapped schedule.
+  stages_isolated : every stage alone on the chip (serial pass after the timed region), with its HBM fraction.
   cpu_baseline : the CPU oracle (oracle/, single thread, kind "port") timed on this host over a bounded sample of the
                  same frame pairs (rank 0, N=1 only).
 """
@@ -66,6 +72,19 @@ def pmc_traffic(stage, pairs_per_launch):
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic_pmc.json")))
         return int(t["stages"][stage]["hbm_bytes_per_step"] * pairs_per_launch / t["batch"])
+    except Exception:
+        return None
+
+
+def valu_roof(stage, pairs_per_launch, isolated_ms):
+    """VALU issue rate of the stage's kernel against the chip's issue peak (one wave instruction per 4 clocks per SIMD):
+    wave-level instruction count per pair from the committed PMC pass x pairs / the kernel's time alone on the chip."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r01_valu_pmc.json")))
+        n = t["stages"][stage]["SQ_INSTS_VALU_per_launch"] * pairs_per_launch / t["batch"]
+        rate = n / (isolated_ms * 1e-3) / 1e9
+        return {"achieved": round(rate, 1), "peak": t["valu_peak_ginstr_per_s"], "unit": "G wave-instr/s",
+                "frac": round(rate / t["valu_peak_ginstr_per_s"], 4), "isolated_ms": round(isolated_ms, 4)}
     except Exception:
         return None
 
@@ -231,7 +250,10 @@ def main():
                        "sharding": f"{world} x independent pair batches, all_gather of [B,8] f32 records"},
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom, B / slices),
-                         "algorithmic_bytes_per_launch": int(ab[dom] * B / slices), "avg_ms": round(dom_ms, 4)},
+                         "algorithmic_bytes_per_launch": int(ab[dom] * B / slices), "avg_ms": round(dom_ms, 4),
+                         # the response and LK kernels are bound by VALU issue, not by HBM: their real roof, from the
+                         # committed SQ_INSTS_VALU counts (profiles/r01_valu_pmc.json) and this run's isolated kernel time
+                         "valu": valu_roof(dom, B / slices, iso[dom][0] / max(1, iso[dom][1]))},
             "pipeline_algorithmic_GBps": round(sum(ab.values()) * world * B * args.steps / dt / 1e9, 1),
             "stages": stages,
             # every stage alone on the chip (serial pass outside the timed region) and the HBM-bound group BASELINE.json's

@@ -236,6 +236,9 @@ __global__ __launch_bounds__(64) void k_lk(const uint8_t *__restrict__ prev, con
 //     4 v_readlane, int64 scalar adds — no LDS traffic, no ds_bpermute.
 #define LKF_IP 24                                  // pitch of the staged prev neighbourhood (18 x 18 used)
 #define LKF_JW 32                                  // staged next region: 32 x 32 = win + 1 + 2*LK_M at win 15
+#ifndef LKF_JP
+#define LKF_JP 40                                  // its LDS pitch: 10 banks per row, so the 16 rows a wave reads together hit 16 different bank groups (pitch 32: 4-way conflicts)
+#endif
 
 __device__ __forceinline__ int row_sum16(int v)
 {
@@ -319,7 +322,7 @@ __global__ __launch_bounds__(64) void k_lk15(const uint8_t *__restrict__ prev, c
                                              float *__restrict__ next_pts, uint8_t *__restrict__ status, float *__restrict__ err)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_I[20 * LKF_IP];
-    __shared__ __attribute__((aligned(16))) uint8_t s_J[(LKF_JW + 1) * LKF_JW];
+    __shared__ __attribute__((aligned(16))) uint8_t s_J[(LKF_JW + 1) * LKF_JP];
 
     const int b = blockIdx.y, p = blockIdx.x, lane = threadIdx.x;
     if (p >= counts[b]) return;
@@ -368,11 +371,12 @@ __global__ __launch_bounds__(64) void k_lk15(const uint8_t *__restrict__ prev, c
                 o.y = __builtin_amdgcn_alignbyte(d2, d1, sh);
                 o.z = __builtin_amdgcn_alignbyte(d3, d2, sh);
                 o.w = __builtin_amdgcn_alignbyte(d4, d3, sh);
-                *reinterpret_cast<uint4 *>(s_J + r * LKF_JW + 16 * hf) = o;
+                uint2 *dstp = reinterpret_cast<uint2 *>(s_J + r * LKF_JP + 16 * hf);      // the pitch keeps 8-byte alignment only
+                dstp[0] = make_uint2(o.x, o.y); dstp[1] = make_uint2(o.z, o.w);
             } else {
                 for (int i = lane; i < jw_ * jw_; i += 64) {
                     const int r = i / jw_, c = i - r * jw_;
-                    s_J[r * LKF_JW + c] = J[(size_t)reflect101(jy0 + r, lh) * lw + reflect101(jx0 + c, lw)];
+                    s_J[r * LKF_JP + c] = J[(size_t)reflect101(jy0 + r, lh) * lw + reflect101(jx0 + c, lw)];
                 }
             }
             __syncthreads();
@@ -472,8 +476,8 @@ __global__ __launch_bounds__(64) void k_lk15(const uint8_t *__restrict__ prev, c
             int b1 = 0, b2 = 0;
             if (npx > 0) {
                 int t0[5], t1[5];
-                const int off = (iqy - jy0 + wy) * LKF_JW + (iqx - jx0) + wx0;
-                lds_read5(s_J, off, t0); lds_read5(s_J, off + LKF_JW, t1);
+                const int off = (iqy - jy0 + wy) * LKF_JP + (iqx - jx0) + wx0;
+                lds_read5(s_J, off, t0); lds_read5(s_J, off + LKF_JP, t1);
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     if (k < npx) {
@@ -506,8 +510,8 @@ __global__ __launch_bounds__(64) void k_lk15(const uint8_t *__restrict__ prev, c
             int se = 0;
             if (npx > 0) {
                 int t0[5], t1[5];
-                const int off = (iey - jy0 + wy) * LKF_JW + (iex - jx0) + wx0;
-                lds_read5(s_J, off, t0); lds_read5(s_J, off + LKF_JW, t1);
+                const int off = (iey - jy0 + wy) * LKF_JP + (iex - jx0) + wx0;
+                lds_read5(s_J, off, t0); lds_read5(s_J, off + LKF_JP, t1);
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     if (k < npx) {
