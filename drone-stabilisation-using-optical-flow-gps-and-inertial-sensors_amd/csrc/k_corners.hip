@@ -671,14 +671,13 @@ template <int BS> struct pair_geom {
     static constexpr int AN = BS / 2, PAD = (2 + AN + 3) & ~3, D = PAD - 2 - AN, SW = (125 - BS) & ~3;
 };
 
+// BS = 7 keeps 42 ring registers per lane: 168 VGPRs = 3 waves per SIMD without spills (a 4th wave spills 43 dwords and
+// runs 1.65x slower; two waves per SIMD, forced by padding the LDS, 1.35x slower)
+#ifndef OFK_PAIR_ATTR
+#define OFK_PAIR_ATTR __attribute__((amdgpu_waves_per_eu(3, 8)))
+#endif
 template <int BS, bool MASK>
-#ifndef OFK_PAIR_WAVES
-#define OFK_PAIR_WAVES 3                                        /* BS = 7 keeps 42 ring registers per lane: 3 waves per SIMD, no spills */
-#endif
-#ifndef OFK_PAIR_VGPRS
-#define OFK_PAIR_VGPRS 168
-#endif
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OFK_PAIR_WAVES, 8), amdgpu_num_vgpr(OFK_PAIR_VGPRS))) void k_mineig_pair(
+__global__ __launch_bounds__(256) OFK_PAIR_ATTR void k_mineig_pair(
     const uint8_t *__restrict__ gray, size_t gray_stride, int h, int w, int rows_per_strip, float kd, float ko,
     unsigned int *__restrict__ maxbits, const uint8_t *__restrict__ mask, size_t mask_stride, double quality,
     unsigned long long *__restrict__ seg, int seg_cap, int *__restrict__ seg_count, int *__restrict__ flags)

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Throughput of the resident pair pipeline on the other BASELINE.json configurations (not the bench contract's line):
+C3 = 1024 x 640x480 pairs (+ a 6-state Kalman update per pair), C5 = 3840x2160 pairs, 2000 corners, 5-level pyramid.
+  python tools/bench_configs.py [c3] [c5]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package  # noqa: E402
+
+
+def run(name, w, h, batch, cfg, steps, kf=False):
+    import of_amd.ofk as ofk
+    from of_amd import synth
+    from of_amd.pipeline import FlowPipeline
+    prev, nxt, base = synth.make_batch(batch, h, w, seed=77, distinct=4)
+    sensors = ofk.make_sensors(batch, scaling=base[0]["scaling"], cx=base[0]["cx"], cy=base[0]["cy"])
+    pipe = FlowPipeline(w, h, batch, cfg)
+    pipe.upload(prev, nxt, sensors)
+    for _ in range(2):
+        pipe.run_async()
+    pipe.sync()
+    pipe.ctx.profile_read(); pipe.ctx.profile_enable(0x7f)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pipe.run_async()
+    pipe.sync()
+    dt = time.perf_counter() - t0
+    prof = pipe.ctx.profile_read()
+    out = pipe.ctx.pairs_download(points=False)
+    line = f"{name}: {w}x{h} B={batch} corners={np.mean(out['counts']):.0f}: {batch * steps / dt:.0f} pairs/s ({dt / steps * 1e3:.3f} ms/step)  " + \
+        " ".join(f"{s}={prof[s][0] / steps:.3f}" for s in ofk.STAGES if prof[s][1])
+    if kf:                                                      # of_module.py:63-76 shaped filter with 6 states on every pair's velocity
+        ns, nm = 6, 3
+        F = np.eye(ns); F[:3, 3:] = np.eye(3) / 30.0
+        H = np.zeros((nm, ns)); H[:, :3] = np.eye(3)
+        x = np.zeros((batch, ns)); P = np.tile(np.eye(ns), (batch, 1, 1))
+        z = out["records"][:, 0:3].copy()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            x, P = pipe.ctx.kf_predict_update(F, H, 1e-4 * np.eye(ns), 1e-2 * np.eye(nm), x, P, z=z)
+        line += f"  | kalman(6 states, host buffers): {(time.perf_counter() - t0) / steps * 1e3:.3f} ms per {batch} filters"
+    print(line, flush=True)
+    pipe.close()
+
+
+def main():
+    load_package()
+    from of_amd.pipeline import PipelineConfig
+    which = sys.argv[1:] or ["c3", "c5"]
+    if "c3" in which:
+        run("C3", 640, 480, 1024, PipelineConfig(max_corners=500, quality=0.01, min_distance=10, block_size=7, win=15, max_level=3), 10, kf=True)
+    if "c5" in which:
+        run("C5", 3840, 2160, 32, PipelineConfig(max_corners=2000, quality=0.01, min_distance=10, block_size=7, win=15, max_level=5), 10)
+
+
+if __name__ == "__main__":
+    main()
