@@ -234,6 +234,11 @@ __global__ __launch_bounds__(64) void k_lk(const uint8_t *__restrict__ prev, con
 //   * the Scharr derivatives of the lane's own 2x5 taps are computed from its 4x7 neighbourhood in registers;
 //   * reductions: 4 DPP adds inside each 16-lane row (int32 is exact: 16 lanes x 4 px x 8160 x 4080 < 2^31),
 //     4 v_readlane, int64 scalar adds — no LDS traffic, no ds_bpermute.
+// compiler-level ordering of LDS accesses inside the single wave of a workgroup (see the staging code of k_lk15)
+#define LDS_FENCE() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+#ifndef LK_ITER_CAP
+#define LK_ITER_CAP(n) (n)                            /* timing experiments only (tools/variants.sh): cap the Newton iterations */
+#endif
 #define LKF_IP 24                                  // pitch of the staged prev neighbourhood (18 x 18 used)
 #define LKF_JW 32                                  // staged next region: 32 x 32 = win + 1 + 2*LK_M at win 15
 #ifndef LKF_JP
@@ -355,43 +360,57 @@ __global__ __launch_bounds__(64) void k_lk15(const uint8_t *__restrict__ prev, c
         qx -= half; qy -= half;
         int jx0 = 0, jy0 = 0;
         bool jvalid = false;
-        // ---- stage the next-frame region around the initial guess (loads issued now, consumed after the I patch)
-        auto stage_J = [&](int iqx, int iqy) {
+        // ---- staging.  One wave per workgroup: the LDS operations of a wave execute in order, so staging and reading need no
+        //      s_barrier and, unlike __syncthreads(), no wait for outstanding GLOBAL loads — LDS_FENCE only keeps the compiler
+        //      from moving LDS accesses across it.  The loads of the previous-frame neighbourhood and of the next-frame region
+        //      are issued back to back (one memory round trip per level instead of two), then both are written to LDS.
+        unsigned jd0 = 0, jd1 = 0, jd2 = 0, jd3 = 0, jd4 = 0, jsh = 0;
+        bool jinner = false;
+        auto J_issue = [&](int iqx, int iqy) {
             jx0 = iqx - LK_M; jy0 = iqy - LK_M;
-            __syncthreads();
-            const bool inner = jx0 >= 4 && jy0 >= 0 && jx0 + jw_ + 8 <= lw && jy0 + jw_ <= lh && (lw & 3) == 0 && jw_ == LKF_JW;
-            if (inner) {
+            jinner = jx0 >= 4 && jy0 >= 0 && jx0 + jw_ + 8 <= lw && jy0 + jw_ <= lh && (lw & 3) == 0 && jw_ == LKF_JW;
+            if (jinner) {
                 const int r = lane >> 1, hf = lane & 1;                   // 32 rows x 2 halves of 16 bytes
                 const size_t addr = (size_t)(jy0 + r) * lw + jx0 + 16 * hf;
-                const unsigned sh = (unsigned)addr & 3u;
+                jsh = (unsigned)addr & 3u;
                 const unsigned *g = reinterpret_cast<const unsigned *>(J + (addr & ~(size_t)3));
-                const unsigned d0 = g[0], d1 = g[1], d2 = g[2], d3 = g[3], d4 = g[4];
-                uint4 o;
-                o.x = __builtin_amdgcn_alignbyte(d1, d0, sh);
-                o.y = __builtin_amdgcn_alignbyte(d2, d1, sh);
-                o.z = __builtin_amdgcn_alignbyte(d3, d2, sh);
-                o.w = __builtin_amdgcn_alignbyte(d4, d3, sh);
+                jd0 = g[0]; jd1 = g[1]; jd2 = g[2]; jd3 = g[3]; jd4 = g[4];
+            }
+        };
+        auto J_commit = [&]() {
+            LDS_FENCE();                                                  // earlier readers of s_J are done
+            if (jinner) {
+                const int r = lane >> 1, hf = lane & 1;
                 uint2 *dstp = reinterpret_cast<uint2 *>(s_J + r * LKF_JP + 16 * hf);      // the pitch keeps 8-byte alignment only
-                dstp[0] = make_uint2(o.x, o.y); dstp[1] = make_uint2(o.z, o.w);
+                dstp[0] = make_uint2(__builtin_amdgcn_alignbyte(jd1, jd0, jsh), __builtin_amdgcn_alignbyte(jd2, jd1, jsh));
+                dstp[1] = make_uint2(__builtin_amdgcn_alignbyte(jd3, jd2, jsh), __builtin_amdgcn_alignbyte(jd4, jd3, jsh));
             } else {
                 for (int i = lane; i < jw_ * jw_; i += 64) {
                     const int r = i / jw_, c = i - r * jw_;
                     s_J[r * LKF_JP + c] = J[(size_t)reflect101(jy0 + r, lh) * lw + reflect101(jx0 + c, lw)];
                 }
             }
-            __syncthreads();
+            LDS_FENCE();
             jvalid = true;
         };
-        // ---- stage the prev neighbourhood (origin ipx-1, ipy-1), (win+3)^2
-        __syncthreads();
+        auto stage_J = [&](int iqx, int iqy) { J_issue(iqx, iqy); J_commit(); };
         {
+            // the prev neighbourhood (origin ipx-1, ipy-1), (win+3)^2: one row of <= 18 bytes per lane, 6 dwords in, 5 out
             const bool inner = ipx >= 5 && ipy >= 1 && ipx - 1 + 28 <= lw && ipy - 1 + iw_ <= lh && (lw & 3) == 0;
+            unsigned d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0, d5 = 0, sh = 0;
+            if (inner && lane < iw_) {
+                const size_t addr = (size_t)(ipy - 1 + lane) * lw + (ipx - 1);
+                sh = (unsigned)addr & 3u;
+                const unsigned *g = reinterpret_cast<const unsigned *>(I + (addr & ~(size_t)3));
+                d0 = g[0]; d1 = g[1]; d2 = g[2]; d3 = g[3]; d4 = g[4]; d5 = g[5];
+            }
+            // every lane holds the same position: move the integer part to the scalar unit (bounds tests, LDS offsets)
+            const int iqx = __builtin_amdgcn_readfirstlane((int)floorf(qx)), iqy = __builtin_amdgcn_readfirstlane((int)floorf(qy));
+            const bool doJ = !(iqx < -win || iqx >= lw || iqy < -win || iqy >= lh);
+            if (doJ) J_issue(iqx, iqy);
+            LDS_FENCE();                                                  // the previous level's readers of s_I are done
             if (inner) {
-                if (lane < iw_) {                                          // one row of <= 18 bytes per lane: 6 dwords in, 5 out
-                    const size_t addr = (size_t)(ipy - 1 + lane) * lw + (ipx - 1);
-                    const unsigned sh = (unsigned)addr & 3u;
-                    const unsigned *g = reinterpret_cast<const unsigned *>(I + (addr & ~(size_t)3));
-                    const unsigned d0 = g[0], d1 = g[1], d2 = g[2], d3 = g[3], d4 = g[4], d5 = g[5];
+                if (lane < iw_) {
                     unsigned *o = reinterpret_cast<unsigned *>(s_I + lane * LKF_IP);
                     o[0] = __builtin_amdgcn_alignbyte(d1, d0, sh);
                     o[1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
@@ -405,12 +424,8 @@ __global__ __launch_bounds__(64) void k_lk15(const uint8_t *__restrict__ prev, c
                     s_I[r * LKF_IP + c] = I[(size_t)reflect101(ipy - 1 + r, lh) * lw + reflect101(ipx - 1 + c, lw)];
                 }
             }
-        }
-        {
-            // every lane holds the same position: move the integer part to the scalar unit (bounds tests, LDS offsets)
-            const int iqx = __builtin_amdgcn_readfirstlane((int)floorf(qx)), iqy = __builtin_amdgcn_readfirstlane((int)floorf(qy));
-            if (!(iqx < -win || iqx >= lw || iqy < -win || iqy >= lh)) stage_J(iqx, iqy);
-            else __syncthreads();
+            if (doJ) J_commit();
+            else LDS_FENCE();
         }
         // ---- patch: I (5 fractional bits), Ix, Iy of the lane's pixels; exact integer normal matrix
         int w00, w01, w10, w11;
@@ -464,7 +479,7 @@ __global__ __launch_bounds__(64) void k_lk15(const uint8_t *__restrict__ prev, c
         }
         D = 1.f / D;
         float pdx = 0.f, pdy = 0.f;
-        for (int j = 0; j < max_count; ++j) {
+        for (int j = 0; j < LK_ITER_CAP(max_count); ++j) {
             // every lane holds the same position: move the integer part to the scalar unit (bounds tests, LDS offsets)
             const int iqx = __builtin_amdgcn_readfirstlane((int)floorf(qx)), iqy = __builtin_amdgcn_readfirstlane((int)floorf(qy));
             if (iqx < -win || iqx >= lw || iqy < -win || iqy >= lh) {
