@@ -236,6 +236,9 @@ __global__ __launch_bounds__(64) void k_lk(const uint8_t *__restrict__ prev, con
 //     4 v_readlane, int64 scalar adds — no LDS traffic, no ds_bpermute.
 // compiler-level ordering of LDS accesses inside the single wave of a workgroup (see the staging code of k_lk15)
 #define LDS_FENCE() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+#ifndef LK_PATCH_ON
+#define LK_PATCH_ON true                             /* timing experiments only */
+#endif
 #ifndef LK_ITER_CAP
 #define LK_ITER_CAP(n) (n)                            /* timing experiments only (tools/variants.sh): cap the Newton iterations */
 #endif
@@ -320,6 +323,16 @@ __device__ __forceinline__ void lds_read7(const uint8_t *base, int off, int t[7]
     t[4] = hi & 255; t[5] = (hi >> 8) & 255; t[6] = (hi >> 16) & 255;
 }
 
+// Packed 16-bit arithmetic of k_lk15.  Pixels, Scharr sums (<= 16 * 255) and the 14-bit interpolation weights all fit 16 bits,
+// so two adjacent columns travel in one register: v_perm expands byte pairs (b_k, b_k+1) to u16 pairs, v_pk_* instructions run
+// the separable Scharr on two columns at once, and ONE v_dot2_i32_i16 evaluates a row of the bilinear interpolation
+// (a*w0 + b*w1 + acc) — every sum is an exact integer, so the results are those of the scalar formulation bit for bit.
+typedef short lk_s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ lk_s2 lk_as_s2(unsigned v) { return __builtin_bit_cast(lk_s2, v); }
+__device__ __forceinline__ unsigned lk_as_u(lk_s2 v) { return __builtin_bit_cast(unsigned, v); }
+__device__ __forceinline__ int lk_dot2(unsigned a, unsigned w, int acc) { return __builtin_amdgcn_sdot2(lk_as_s2(a), lk_as_s2(w), acc, false); }
+#define LK_PAIR_SEL(k) ((unsigned)(k) | 0x0c00u | ((unsigned)((k) + 1) << 16) | 0x0c000000u)   /* v_perm selector: (byte k, 0, byte k+1, 0) */
+
 __global__ __launch_bounds__(64) void k_lk15(const uint8_t *__restrict__ prev, const uint8_t *__restrict__ next,
                                              size_t pyr_stride, ofk_levels lv, const float *__restrict__ prev_pts,
                                              const int *__restrict__ counts, int pts_stride, int win, int max_count,
@@ -368,10 +381,12 @@ __global__ __launch_bounds__(64) void k_lk15(const uint8_t *__restrict__ prev, c
         bool jinner = false;
         auto J_issue = [&](int iqx, int iqy) {
             jx0 = iqx - LK_M; jy0 = iqy - LK_M;
-            jinner = jx0 >= 4 && jy0 >= 0 && jx0 + jw_ + 8 <= lw && jy0 + jw_ <= lh && (lw & 3) == 0 && jw_ == LKF_JW;
+            // dword path whenever the COLUMNS lie inside the image; rows are mirrored per lane (at the coarse levels a third
+            // of the regions cross the top or bottom border, and the byte-wise path costs ~400 VALU instructions)
+            jinner = jx0 >= 4 && jx0 + jw_ + 8 <= lw && (lw & 3) == 0 && jw_ == LKF_JW;
             if (jinner) {
                 const int r = lane >> 1, hf = lane & 1;                   // 32 rows x 2 halves of 16 bytes
-                const size_t addr = (size_t)(jy0 + r) * lw + jx0 + 16 * hf;
+                const size_t addr = (size_t)reflect101(jy0 + r, lh) * lw + jx0 + 16 * hf;
                 jsh = (unsigned)addr & 3u;
                 const unsigned *g = reinterpret_cast<const unsigned *>(J + (addr & ~(size_t)3));
                 jd0 = g[0]; jd1 = g[1]; jd2 = g[2]; jd3 = g[3]; jd4 = g[4];
@@ -396,10 +411,10 @@ __global__ __launch_bounds__(64) void k_lk15(const uint8_t *__restrict__ prev, c
         auto stage_J = [&](int iqx, int iqy) { J_issue(iqx, iqy); J_commit(); };
         {
             // the prev neighbourhood (origin ipx-1, ipy-1), (win+3)^2: one row of <= 18 bytes per lane, 6 dwords in, 5 out
-            const bool inner = ipx >= 5 && ipy >= 1 && ipx - 1 + 28 <= lw && ipy - 1 + iw_ <= lh && (lw & 3) == 0;
+            const bool inner = ipx >= 5 && ipx - 1 + 28 <= lw && (lw & 3) == 0;         // columns inside; rows mirrored per lane
             unsigned d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0, d5 = 0, sh = 0;
             if (inner && lane < iw_) {
-                const size_t addr = (size_t)(ipy - 1 + lane) * lw + (ipx - 1);
+                const size_t addr = (size_t)reflect101(ipy - 1 + lane, lh) * lw + (ipx - 1);
                 sh = (unsigned)addr & 3u;
                 const unsigned *g = reinterpret_cast<const unsigned *>(I + (addr & ~(size_t)3));
                 d0 = g[0]; d1 = g[1]; d2 = g[2]; d3 = g[3]; d4 = g[4]; d5 = g[5];
@@ -432,39 +447,60 @@ __global__ __launch_bounds__(64) void k_lk15(const uint8_t *__restrict__ prev, c
         lk_weights(px - (float)ipx, py - (float)ipy, w00, w01, w10, w11);
         int a11 = 0, a12 = 0, a22 = 0;
         pI[0] = pI[1] = pI[2] = pI[3] = 0; pIx[0] = pIx[1] = pIx[2] = pIx[3] = 0; pIy[0] = pIy[1] = pIy[2] = pIy[3] = 0;
-        if (npx > 0) {
-            int n[4][7];                                                   // rows wy..wy+3 of s_I, cols wx0..wx0+6
+        if (LK_PATCH_ON && npx > 0) {
+            // rows wy..wy+3 of s_I, columns wx0..wx0+7 (the staged rows are dword aligned): P[r][k] = (n[r][k], n[r][k+1])
+            unsigned P[4][7];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) lds_read7(s_I, (wy + r) * LKF_IP + wx0, n[r]);
-            // Scharr at the window taps (rows wy, wy+1; cols wx0..wx0+4), separable: per neighbourhood row the horizontal
-            // difference hd and the horizontal [3 10 3] smooth hs, then dx = 3 hd_r + 10 hd_{r+1} + 3 hd_{r+2}, dy = hs_{r+2} - hs_r
-            int dxv[2][5], dyv[2][5];
+            for (int r = 0; r < 4; ++r) {
+                const unsigned *pr = reinterpret_cast<const unsigned *>(s_I + (wy + r) * LKF_IP + wx0);
+                const unsigned d0 = pr[0], d1 = pr[1];
 #pragma unroll
-            for (int c = 0; c < 5; ++c) {                                  // column by column: 8 temporaries live at a time
-                int hd[4], hs[4];
+                for (int k = 0; k < 7; ++k) P[r][k] = __builtin_amdgcn_perm(d1, d0, LK_PAIR_SEL(k));
+            }
+            // Scharr at the window taps (rows wy, wy+1; columns wx0..wx0+4), separable and two columns per instruction:
+            // slot s = columns (2s, 2s+1).  hd = n[c+2] - n[c], hs = 3 (n[c] + n[c+2]) + 10 n[c+1] per neighbourhood row,
+            // dx = 3 (hd_r + hd_{r+2}) + 10 hd_{r+1}, dy = hs_{r+2} - hs_r.  (The upper half of slot 2 is column 5: unused.)
+            unsigned DX[2][3], DY[2][3];
+#pragma unroll
+            for (int sl = 0; sl < 3; ++sl) {
+                lk_s2 hd[4], hs[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    hd[r] = n[r][c + 2] - n[r][c];
-                    hs[r] = 3 * (n[r][c] + n[r][c + 2]) + 10 * n[r][c + 1];
+                    const lk_s2 a = lk_as_s2(P[r][2 * sl]), m = lk_as_s2(P[r][2 * sl + 1]), c2 = lk_as_s2(P[r][2 * sl + 2]);
+                    hd[r] = c2 - a;
+                    hs[r] = (a + c2) * (short)3 + m * (short)10;
                 }
-                dxv[0][c] = 3 * (hd[0] + hd[2]) + 10 * hd[1]; dxv[1][c] = 3 * (hd[1] + hd[3]) + 10 * hd[2];
-                dyv[0][c] = hs[2] - hs[0]; dyv[1][c] = hs[3] - hs[1];
+                DX[0][sl] = lk_as_u((hd[0] + hd[2]) * (short)3 + hd[1] * (short)10); DX[1][sl] = lk_as_u((hd[1] + hd[3]) * (short)3 + hd[2] * (short)10);
+                DY[0][sl] = lk_as_u(hs[2] - hs[0]); DY[1][sl] = lk_as_u(hs[3] - hs[1]);
             }
             if (!(ipx >= 0 && ipx + win < lw && ipy >= 0 && ipy + win < lh)) {      // wave-uniform: the window touches the border
 #pragma unroll
                 for (int r = 0; r < 2; ++r)
 #pragma unroll
-                    for (int c = 0; c < 5; ++c) {
-                        const int X = ipx + wx0 + c, Y = ipy + wy + r;
-                        if (!(X >= 0 && X < lw && Y >= 0 && Y < lh)) { dxv[r][c] = 0; dyv[r][c] = 0; }   // constant-0 derivative border
+                    for (int sl = 0; sl < 3; ++sl) {
+                        const int X = ipx + wx0 + 2 * sl, Y = ipy + wy + r;
+                        const bool rowok = Y >= 0 && Y < lh;
+                        const unsigned keep = ((rowok && X >= 0 && X < lw) ? 0x0000ffffu : 0u) | ((rowok && X + 1 >= 0 && X + 1 < lw) ? 0xffff0000u : 0u);
+                        DX[r][sl] &= keep; DY[r][sl] &= keep;                   // constant-0 derivative border
                     }
             }
+            // pairs starting at column k = 0..3: (k, k+1)
+            unsigned QX[2][4], QY[2][4];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                QX[r][0] = DX[r][0]; QX[r][1] = __builtin_amdgcn_alignbit(DX[r][1], DX[r][0], 16); QX[r][2] = DX[r][1];
+                QX[r][3] = __builtin_amdgcn_alignbit(DX[r][2], DX[r][1], 16);
+                QY[r][0] = DY[r][0]; QY[r][1] = __builtin_amdgcn_alignbit(DY[r][1], DY[r][0], 16); QY[r][2] = DY[r][1];
+                QY[r][3] = __builtin_amdgcn_alignbit(DY[r][2], DY[r][1], 16);
+            }
+            const unsigned W0 = (unsigned)w00 | ((unsigned)w01 << 16), W1 = (unsigned)w10 | ((unsigned)w11 << 16);
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (k < npx) {
-                    const int iv = descale(__mul24(n[1][k + 1], w00) + __mul24(n[1][k + 2], w01) + __mul24(n[2][k + 1], w10) + __mul24(n[2][k + 2], w11), 9);
-                    const int ix = descale(__mul24(dxv[0][k], w00) + __mul24(dxv[0][k + 1], w01) + __mul24(dxv[1][k], w10) + __mul24(dxv[1][k + 1], w11), 14);
-                    const int iy = descale(__mul24(dyv[0][k], w00) + __mul24(dyv[0][k + 1], w01) + __mul24(dyv[1][k], w10) + __mul24(dyv[1][k + 1], w11), 14);
+                    // descale(a w00 + b w01 + c w10 + d w11, n) = (two dot products + 2^(n-1)) >> n
+                    const int iv = lk_dot2(P[1][k + 1], W0, lk_dot2(P[2][k + 1], W1, 1 << 8)) >> 9;
+                    const int ix = lk_dot2(QX[0][k], W0, lk_dot2(QX[1][k], W1, 1 << 13)) >> 14;
+                    const int iy = lk_dot2(QY[0][k], W0, lk_dot2(QY[1][k], W1, 1 << 13)) >> 14;
                     pI[k] = iv; pIx[k] = ix; pIy[k] = iy;
                     a11 += __mul24(ix, ix); a12 += __mul24(ix, iy); a22 += __mul24(iy, iy);
                 }
@@ -490,13 +526,18 @@ __global__ __launch_bounds__(64) void k_lk15(const uint8_t *__restrict__ prev, c
             lk_weights(qx - (float)iqx, qy - (float)iqy, w00, w01, w10, w11);
             int b1 = 0, b2 = 0;
             if (npx > 0) {
-                int t0[5], t1[5];
+                // two rows of 5 bytes at byte offset sh = (iqx - jx0) & 3 of two dwords each; the offset is wave-uniform, so the
+                // v_perm selectors that expand the byte pairs (t[k], t[k+1]) come from the scalar unit
                 const int off = (iqy - jy0 + wy) * LKF_JP + (iqx - jx0) + wx0;
-                lds_read5(s_J, off, t0); lds_read5(s_J, off + LKF_JP, t1);
+                const unsigned *r0 = reinterpret_cast<const unsigned *>(s_J + (off & ~3)), *r1 = reinterpret_cast<const unsigned *>(s_J + ((off + LKF_JP) & ~3));
+                const unsigned d0 = r0[0], d1 = r0[1], e0 = r1[0], e1 = r1[1];
+                const unsigned shs = (unsigned)__builtin_amdgcn_readfirstlane((iqx - jx0) & 3) * 0x00010001u;
+                const unsigned W0 = (unsigned)w00 | ((unsigned)w01 << 16), W1 = (unsigned)w10 | ((unsigned)w11 << 16);
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     if (k < npx) {
-                        const int diff = descale(__mul24(t0[k], w00) + __mul24(t0[k + 1], w01) + __mul24(t1[k], w10) + __mul24(t1[k + 1], w11), 9) - pI[k];
+                        const unsigned sel = LK_PAIR_SEL(k) + shs;
+                        const int diff = (lk_dot2(__builtin_amdgcn_perm(d1, d0, sel), W0, lk_dot2(__builtin_amdgcn_perm(e1, e0, sel), W1, 1 << 8)) >> 9) - pI[k];
                         b1 += __mul24(diff, pIx[k]); b2 += __mul24(diff, pIy[k]);
                     }
             }
@@ -524,13 +565,16 @@ __global__ __launch_bounds__(64) void k_lk15(const uint8_t *__restrict__ prev, c
             lk_weights(ex - (float)iex, ey - (float)iey, w00, w01, w10, w11);
             int se = 0;
             if (npx > 0) {
-                int t0[5], t1[5];
                 const int off = (iey - jy0 + wy) * LKF_JP + (iex - jx0) + wx0;
-                lds_read5(s_J, off, t0); lds_read5(s_J, off + LKF_JP, t1);
+                const unsigned *r0 = reinterpret_cast<const unsigned *>(s_J + (off & ~3)), *r1 = reinterpret_cast<const unsigned *>(s_J + ((off + LKF_JP) & ~3));
+                const unsigned d0 = r0[0], d1 = r0[1], e0 = r1[0], e1 = r1[1];
+                const unsigned shs = (unsigned)__builtin_amdgcn_readfirstlane((iex - jx0) & 3) * 0x00010001u;
+                const unsigned W0 = (unsigned)w00 | ((unsigned)w01 << 16), W1 = (unsigned)w10 | ((unsigned)w11 << 16);
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     if (k < npx) {
-                        const int diff = descale(__mul24(t0[k], w00) + __mul24(t0[k + 1], w01) + __mul24(t1[k], w10) + __mul24(t1[k + 1], w11), 9) - pI[k];
+                        const unsigned sel = LK_PAIR_SEL(k) + shs;
+                        const int diff = (lk_dot2(__builtin_amdgcn_perm(d1, d0, sel), W0, lk_dot2(__builtin_amdgcn_perm(e1, e0, sel), W1, 1 << 8)) >> 9) - pI[k];
                         se += diff < 0 ? -diff : diff;
                     }
             }
