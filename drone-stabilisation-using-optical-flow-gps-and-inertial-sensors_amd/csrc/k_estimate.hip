@@ -568,6 +568,156 @@ void ofk_launch_of_simulation(hipStream_t s, const double *truth, const double *
     hipLaunchKernelGGL(k_of_simulation, dim3(trials), dim3(256), 0, s, truth, sig, pos, true_flow, n, z, v_obs, bound);
 }
 
+// ------------------------------------------------------------------------------------------------ per-feature estimators
+// of_library.py:270-286 (calc_height), :53-75 + :100-114 (convert_to_of inside dynamic_immobile), :291-317 (eval_ft), batched
+// over track sets: one block per set.  The reference's functions carry undefined names; the formulas are the
+// ones they spell out, restated in oracle/estimation_oracle.py.  f64 throughout, same operation order as the oracle.
+__device__ __forceinline__ double block_minmax(double v, bool want_max, double *s_red)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double u = __shfl_xor(v, o);
+        v = want_max ? fmax(v, u) : fmin(v, u);
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const double a = want_max ? fmax(s_red[0], s_red[1]) : fmin(s_red[0], s_red[1]);
+    const double b = want_max ? fmax(s_red[2], s_red[3]) : fmin(s_red[2], s_red[3]);
+    return want_max ? fmax(a, b) : fmin(a, b);
+}
+
+__global__ __launch_bounds__(256) void k_feature_eval(const double *__restrict__ pos, const double *__restrict__ pos_err,
+                                                      const double *__restrict__ oldpos, const double *__restrict__ oldpos_err,
+                                                      const int *__restrict__ counts, int stride, const double *__restrict__ vel,
+                                                      const double *__restrict__ vel_err, double focal, double dummy, double tx,
+                                                      double ty, const double *__restrict__ weight, double *__restrict__ height,
+                                                      double *__restrict__ height_err, uint8_t *__restrict__ immobile,
+                                                      double *__restrict__ score, int *__restrict__ order, int *__restrict__ flags)
+{
+    __shared__ double s_red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = min(max(counts[b], 0), stride);
+    const size_t o = (size_t)b * stride;
+    const double vx = vel[3 * b], vy = vel[3 * b + 1], vz = vel[3 * b + 2];
+    const double vex = vel_err[3 * b], vey = vel_err[3 * b + 1], vez = vel_err[3 * b + 2];
+    double hmin = INFINITY, hmax = -INFINITY, emin = INFINITY, emax = -INFINITY, pmin = INFINITY, pmax = -INFINITY, qmax = -INFINITY;
+    bool bad = false;
+    for (int i = tid; i < n; i += 256) {
+        const double px = pos[2 * (o + i)], py = pos[2 * (o + i) + 1], e = pos_err[o + i];
+        const double ox = oldpos[2 * (o + i)], oy = oldpos[2 * (o + i) + 1], oe = oldpos_err[o + i];
+        const double ofx = px - ox, ofy = py - oy;
+        // calc_height: (f v_x - x v_z) / u_x, mean of the x and y estimates, summed variances
+        const double nx = focal * vx - px * vz, ny = focal * vy - py * vz;
+        const double hx = nx / ofx, hy = ny / ofy;
+        const double a0 = focal * vex / ofx, a1 = nx * e / (ofx * ofx), a2 = e * vz / ofx, a3 = px * vez / ofx;
+        const double b0 = focal * vey / ofy, b1 = ny * e / (ofy * ofy), b2 = e * vz / ofy, b3 = py * vez / ofy;
+        const double h = 0.5 * (hx + hy), he = (a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3) + (b0 * b0 + b1 * b1 + b2 * b2 + b3 * b3);
+        height[o + i] = h; height_err[o + i] = he;
+        // dynamic_immobile: (observed - expected flow)^2 < var(observed) + var(expected), expected from convert_to_of
+        if (!(h >= 2.220446049250313e-16)) bad = true;          // the reference raises ValueError on a non-positive height
+        const double xe = (focal - (px - tx) / h) * vx / h, ye = (focal - (py - ty) / h) * vy / h;
+        const double fx = focal - px + tx, fy = focal - py + ty;
+        const double c0 = e * vx / h, c1 = fx * vex / h, c2 = fx * vx * he / (h * h);
+        const double d0 = e * vy / h, d1 = fy * vey / h, d2 = fy * vy * he / (h * h);
+        const double xee = c0 * c0 + c1 * c1 + c2 * c2, yee = d0 * d0 + d1 * d1 + d2 * d2;
+        const double obs_err = oe * oe + e * e;
+        const bool okx = (ofx - xe) * (ofx - xe) < obs_err + xee, oky = (ofy - ye) * (ofy - ye) < obs_err + yee;
+        immobile[o + i] = (uint8_t)(okx && oky && ox != dummy && oy != dummy);
+        const double q = (px - tx) * (px - tx) + (py - ty) * (py - ty);
+        hmin = fmin(hmin, h); hmax = fmax(hmax, h); emin = fmin(emin, he); emax = fmax(emax, he);
+        pmin = fmin(pmin, e); pmax = fmax(pmax, e); qmax = fmax(qmax, q);
+    }
+    hmin = block_minmax(hmin, false, s_red); hmax = block_minmax(hmax, true, s_red);
+    emin = block_minmax(emin, false, s_red); emax = block_minmax(emax, true, s_red);
+    pmin = block_minmax(pmin, false, s_red); pmax = block_minmax(pmax, true, s_red);
+    qmax = block_minmax(qmax, true, s_red);
+    if (bad) atomicOr(flags + 1, 1);
+    // eval_ft: weighted score of normalised height, height variance, centre distance and track error
+    const double w0 = weight[0], w1 = weight[1], w2 = weight[2], w3 = weight[3];
+    for (int i = tid; i < n; i += 256) {
+        const double px = pos[2 * (o + i)], py = pos[2 * (o + i) + 1];
+        const double hn = hmax - hmin > 0 ? (height[o + i] - hmin) / (hmax - hmin) : 0.0;
+        const double en = emax - emin > 0 ? (height_err[o + i] - emin) / (emax - emin) : 0.0;
+        const double pn = pmax - pmin > 0 ? (pos_err[o + i] - pmin) / (pmax - pmin) : 0.0;
+        const double q = (px - tx) * (px - tx) + (py - ty) * (py - ty);
+        const double dn = qmax > 0 ? q / qmax : 0.0;
+        score[o + i] = w0 * (1 - hn) + w1 * en + w2 * (1 - dn) + w3 * pn;
+    }
+    __syncthreads();
+    // ascending stable order (NaN last, as numpy sorts): rank by counting
+    for (int i = tid; i < n; i += 256) {
+        const double si = score[o + i];
+        const bool ni = si != si;
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            const double sj = score[o + j];
+            const bool nj = sj != sj;
+            const bool less = (!nj && ni) || (!nj && !ni && sj < si) || (nj == ni && (ni || sj == si) && j < i);
+            rank += less ? 1 : 0;
+        }
+        order[o + rank] = i;
+    }
+}
+
+void ofk_launch_feature_eval(hipStream_t s, const double *pos, const double *pos_err, const double *oldpos, const double *oldpos_err,
+                             const int *counts, int batch, int stride, const double *vel, const double *vel_err, double focal,
+                             double dummy, double tx, double ty, const double *weight, double *height, double *height_err,
+                             uint8_t *immobile, double *score, int *order, int *flags)
+{
+    hipLaunchKernelGGL(k_feature_eval, dim3(batch), dim3(256), 0, s, pos, pos_err, oldpos, oldpos_err, counts, stride, vel, vel_err, focal,
+                       dummy, tx, ty, weight, height, height_err, immobile, score, order, flags);
+}
+
+// ------------------------------------------------------------------------------------------------ plane-distance statistics
+// velocity_measurment_node:249-252 — d_sorted = np.sort(d); d_diff = consecutive differences; the commented line there marks a
+// split where a gap reaches the expected distance error (several ground planes in view).  One block per set: bitonic sort in
+// LDS (sets are padded with +inf to a power of two <= 4096), gaps, and the number of gaps >= d_exp_err.
+#define DSPLIT_MAX 4096
+__global__ __launch_bounds__(256) void k_d_split(const double *__restrict__ d, const int *__restrict__ counts, int stride, double d_exp_err,
+                                                 double *__restrict__ sorted, double *__restrict__ diff, int *__restrict__ nsplit)
+{
+    __shared__ double s[DSPLIT_MAX];
+    __shared__ int s_cnt;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = min(max(counts[b], 0), stride);
+    int m = 1;
+    while (m < n) m <<= 1;
+    for (int i = tid; i < m; i += 256) s[i] = i < n ? d[(size_t)b * stride + i] : INFINITY;
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    for (int k = 2; k <= m; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < m; i += 256) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const double a = s[i], c = s[p];
+                    const bool up = (i & k) == 0;
+                    if ((a > c) == up) { s[i] = c; s[p] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    int local = 0;
+    for (int i = tid; i < n; i += 256) {
+        sorted[(size_t)b * stride + i] = s[i];
+        if (i + 1 < n) {
+            const double g = s[i + 1] - s[i];
+            diff[(size_t)b * stride + i] = g;
+            local += g >= d_exp_err ? 1 : 0;
+        }
+    }
+    if (local) atomicAdd(&s_cnt, local);
+    __syncthreads();
+    if (tid == 0) nsplit[b] = s_cnt;
+}
+
+void ofk_launch_d_split(hipStream_t s, const double *d, const int *counts, int batch, int stride, double d_exp_err, double *sorted,
+                        double *diff, int *nsplit)
+{
+    hipLaunchKernelGGL(k_d_split, dim3(batch), dim3(256), 0, s, d, counts, stride, d_exp_err, sorted, diff, nsplit);
+}
+
 // ------------------------------------------------------------------------------------------------ sensor association (ingest)
 // evaluate_exp.py:77-95 — for every image time the nearest IMU and range samples (np.argmin(np.abs(values - t)): the FIRST
 // minimum), then d = range, R from the IMU quaternion, normal = R e_z, omega = angular velocity, written into the pair's

@@ -539,6 +539,62 @@ extern "C" int ofk_associate_sensors(ofk_ctx *c, const double *t_img, int n_img,
     return get(c, sensors, ds, (size_t)n_img * OFK_SENSOR_DOUBLES * 8);
 }
 
+extern "C" int ofk_d_split(ofk_ctx *c, const double *d, const int *counts, int batch, int stride, double d_exp_err, double *sorted,
+                           double *diff, int *nsplit)
+{
+    if (!c || !d || !counts || !sorted || !diff || !nsplit || batch < 1 || stride < 1 || stride > 4096)
+        return ofk_fail(c, OFK_E_INVALID, "ofk_d_split: bad argument (stride 1..4096)");
+    const size_t n = (size_t)batch * stride;
+    Bump bp;
+    TRY(est_begin(c, n * 24 + (size_t)batch * 8 + 1024, bp));
+    double *dd = bp.put(d, n * 8);
+    int *dcn = (int *)bp.put(counts, (size_t)batch * 4);
+    double *ds = bp.take(n * 8), *dg = bp.take(n * 8);
+    int *dn = (int *)bp.take((size_t)batch * 4);
+    if (bp.rc) return ofk_fail(c, OFK_E_HIP, "ofk_d_split: upload failed");
+    OFK_HIP(c, hipMemsetAsync(ds, 0, n * 8, c->stream)); OFK_HIP(c, hipMemsetAsync(dg, 0, n * 8, c->stream));
+    ofk_launch_d_split(c->stream, dd, dcn, batch, stride, d_exp_err, ds, dg, dn);
+    TRY(check_launch(c, "k_d_split"));
+    TRY(get(c, sorted, ds, n * 8)); TRY(get(c, diff, dg, n * 8));
+    return get(c, nsplit, dn, (size_t)batch * 4);
+}
+
+extern "C" int ofk_feature_eval(ofk_ctx *c, const double *pos, const double *pos_err, const double *oldpos, const double *oldpos_err,
+                                const int *counts, int batch, int stride, const double *vel, const double *vel_err, double focal_len,
+                                double dummy_value, int img_w, int img_h, const double *weight, double *height, double *height_err,
+                                uint8_t *immobile, double *score, int *order, int *bad_height)
+{
+    if (!c || !pos || !pos_err || !oldpos || !oldpos_err || !counts || !vel || !vel_err || !weight || !height || !height_err || !immobile ||
+        !score || !order || batch < 1 || stride < 1)
+        return ofk_fail(c, OFK_E_INVALID, "ofk_feature_eval: bad argument");
+    const size_t n = (size_t)batch * stride;
+    Bump bp;
+    TRY(est_begin(c, n * (2 + 1 + 2 + 1 + 1 + 1 + 1 + 1) * 8 + (size_t)batch * 64 + 1024, bp));
+    double *dp = bp.put(pos, n * 16), *dpe = bp.put(pos_err, n * 8), *dop = bp.put(oldpos, n * 16), *doe = bp.put(oldpos_err, n * 8);
+    int *dcn = (int *)bp.put(counts, (size_t)batch * 4);
+    double *dv = bp.put(vel, (size_t)batch * 24), *dve = bp.put(vel_err, (size_t)batch * 24), *dw = bp.put(weight, 32);
+    double *dh = bp.take(n * 8), *dhe = bp.take(n * 8), *dsc = bp.take(n * 8);
+    uint8_t *dim = (uint8_t *)bp.take(n);
+    int *dord = (int *)bp.take(n * 4), *dfl = (int *)bp.take(16);
+    if (bp.rc) return ofk_fail(c, OFK_E_HIP, "ofk_feature_eval: upload failed");
+    OFK_HIP(c, hipMemsetAsync(dfl, 0, 16, c->stream));
+    OFK_HIP(c, hipMemsetAsync(dim, 0, n, c->stream));
+    OFK_HIP(c, hipMemsetAsync(dh, 0, n * 8, c->stream)); OFK_HIP(c, hipMemsetAsync(dhe, 0, n * 8, c->stream));
+    OFK_HIP(c, hipMemsetAsync(dsc, 0, n * 8, c->stream));
+    OFK_HIP(c, hipMemsetAsync(dord, 0xff, n * 4, c->stream));                   // slots past a set's count read -1
+    // of.pix_trans (of_library.py:31-43): d/2 if even else (d+1)/2
+    const double tx = (img_w % 2 == 0) ? img_w / 2.0 : (img_w + 1) / 2.0, ty = (img_h % 2 == 0) ? img_h / 2.0 : (img_h + 1) / 2.0;
+    ofk_launch_feature_eval(c->stream, dp, dpe, dop, doe, dcn, batch, stride, dv, dve, focal_len, dummy_value, tx, ty, dw, dh, dhe, dim, dsc,
+                            dord, dfl);
+    TRY(check_launch(c, "k_feature_eval"));
+    int fl[4] = {0, 0, 0, 0};
+    TRY(get(c, fl, dfl, 16));
+    if (bad_height) *bad_height = fl[1];
+    TRY(get(c, height, dh, n * 8)); TRY(get(c, height_err, dhe, n * 8)); TRY(get(c, score, dsc, n * 8));
+    TRY(get(c, immobile, dim, n));
+    return get(c, order, dord, n * 4);
+}
+
 extern "C" int ofk_kf_predict_update(ofk_ctx *c, int ns, int nm, int nc, const double *F, const double *Bm, const double *H,
                                      const double *Q, const double *Rm, double *x, double *P, const double *u, const double *z,
                                      int batch, int do_predict)

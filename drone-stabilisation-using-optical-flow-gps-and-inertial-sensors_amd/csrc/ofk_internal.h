@@ -132,6 +132,12 @@ void ofk_launch_kf(hipStream_t s, int ns, int nm, int nc, const double *F, const
 void ofk_launch_of_simulation(hipStream_t s, const double *truth, const double *sig, const double *pos,
                               const double *true_flow, int n, const double *z, int trials, double *v_obs,
                               double *bound);
+void ofk_launch_feature_eval(hipStream_t s, const double *pos, const double *pos_err, const double *oldpos, const double *oldpos_err,
+                             const int *counts, int batch, int stride, const double *vel, const double *vel_err, double focal,
+                             double dummy, double tx, double ty, const double *weight, double *height, double *height_err,
+                             uint8_t *immobile, double *score, int *order, int *flags);
+void ofk_launch_d_split(hipStream_t s, const double *d, const int *counts, int batch, int stride, double d_exp_err, double *sorted,
+                        double *diff, int *nsplit);
 void ofk_launch_associate(hipStream_t s, const double *t_img, int n_img, int n_imu, const double *imu_t, const double *imu_q,
                           const double *imu_w, int n_hgt, const double *hgt_t, const double *hgt_r, double *sensors, int *imu_idx,
                           int *hgt_idx);

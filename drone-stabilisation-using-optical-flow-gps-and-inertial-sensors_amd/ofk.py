@@ -25,7 +25,7 @@ SYMBOLS = (
     "ofk_version", "ofk_last_error", "ofk_device_count", "ofk_create", "ofk_destroy", "ofk_sync", "ofk_device_sync",
     "ofk_gray_bgr8", "ofk_pyr_down_u8", "ofk_scharr_s16", "ofk_mineig_response", "ofk_select_corners",
     "ofk_good_features", "ofk_lk_pyr", "ofk_flow_model", "ofk_feasibility", "ofk_velocity_solve", "ofk_imu_propagate",
-    "ofk_post_solve", "ofk_kf_predict_update", "ofk_of_simulation", "ofk_associate_sensors", "ofk_pairs_upload", "ofk_pairs_set_sensors",
+    "ofk_post_solve", "ofk_kf_predict_update", "ofk_of_simulation", "ofk_associate_sensors", "ofk_feature_eval", "ofk_d_split", "ofk_pairs_upload", "ofk_pairs_set_sensors",
     "ofk_pairs_run", "ofk_pairs_download", "ofk_pairs_export_records_f32", "ofk_stream_begin", "ofk_stream_step",
     "ofk_set_streams", "ofk_set_overlap", "ofk_mark", "ofk_mark_wait", "ofk_profile_enable", "ofk_profile_read",
 )
@@ -76,6 +76,8 @@ def load_library():
         L.ofk_imu_propagate.argtypes = [vp, vp, vp, i]
         L.ofk_post_solve.argtypes = [vp, vp, vp, vp, vp, i, vp]
         L.ofk_associate_sensors.argtypes = [vp, vp, i, vp, vp, vp, i, vp, vp, i, vp, vp, vp]
+        L.ofk_feature_eval.argtypes = [vp, vp, vp, vp, vp, vp, i, i, vp, vp, d, d, i, i, vp, vp, vp, vp, vp, vp, vp]
+        L.ofk_d_split.argtypes = [vp, vp, vp, i, i, d, vp, vp, vp]
         L.ofk_kf_predict_update.argtypes = [vp, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i]
         L.ofk_of_simulation.argtypes = [vp, vp, vp, vp, vp, i, vp, i, vp, vp]
         L.ofk_pairs_upload.argtypes = [vp, vp, vp, i, i, i]
@@ -315,6 +317,49 @@ class Context:
         with self._lock:
             self._ck(self._L.ofk_post_solve(self._h, _p(v2), _p(R), _p(ang), _p(offset), B, _p(out)))
         return out[0] if single else out
+
+    def feature_eval(self, pos, pos_err, oldpos, oldpos_err, vel, vel_err, focal_len, dummy_value, img_dim, weight, counts=None):
+        """calc_height + dynamic_immobile + eval_ft of of_library.py for a batch of track sets ([batch, n, 2] positions;
+        a single [n, 2] set is accepted).  Returns dict(height, height_err, immobile, score, order, bad_height)."""
+        pos = _arr(pos, np.float64)
+        single = pos.ndim == 2
+        pos = pos.reshape((1,) + pos.shape) if single else pos
+        B, n = pos.shape[0], pos.shape[1]
+        def per_feature(a):                                      # scalar, [n] or [B, n]
+            a = np.asarray(a, np.float64)
+            return _arr(np.broadcast_to(a if a.size == 1 else a.reshape(-1, n), (B, n)), np.float64)
+        pos_err = per_feature(pos_err)
+        oldpos = _arr(np.asarray(oldpos, np.float64).reshape(B, n, 2), np.float64)
+        oldpos_err = per_feature(oldpos_err)
+        vel = _arr(np.broadcast_to(np.asarray(vel, np.float64).reshape(-1, 3), (B, 3)), np.float64)
+        vel_err = _arr(np.broadcast_to(np.asarray(vel_err, np.float64).reshape(-1, 3), (B, 3)), np.float64)
+        cn = np.full(B, n, np.int32) if counts is None else _arr(counts, np.int32, (B,))
+        w = _arr(weight, np.float64, (4,))
+        out = dict(height=np.zeros((B, n)), height_err=np.zeros((B, n)), immobile=np.zeros((B, n), np.uint8), score=np.zeros((B, n)),
+                   order=np.zeros((B, n), np.int32))
+        bad = C.c_int(0)
+        with self._lock:
+            self._ck(self._L.ofk_feature_eval(self._h, _p(pos), _p(pos_err), _p(oldpos), _p(oldpos_err), _p(cn), B, n, _p(vel), _p(vel_err),
+                                              float(focal_len), float(dummy_value), int(img_dim[0]), int(img_dim[1]), _p(w),
+                                              _p(out["height"]), _p(out["height_err"]), _p(out["immobile"]), _p(out["score"]),
+                                              _p(out["order"]), C.byref(bad)))
+        out["bad_height"] = bool(bad.value)
+        if single:
+            out = {k: (v[0] if isinstance(v, np.ndarray) else v) for k, v in out.items()}
+        return out
+
+    def d_split(self, d, d_exp_err, counts=None):
+        """node:249-252: sorted plane distances, their consecutive differences and the number of gaps >= d_exp_err, per set
+        ([batch, n] or a single [n])."""
+        d = _arr(d, np.float64)
+        single = d.ndim == 1
+        d = d.reshape(1, -1) if single else d
+        B, n = d.shape
+        cn = np.full(B, n, np.int32) if counts is None else _arr(counts, np.int32, (B,))
+        srt = np.zeros((B, n)); dif = np.zeros((B, n)); ns = np.zeros(B, np.int32)
+        with self._lock:
+            self._ck(self._L.ofk_d_split(self._h, _p(d), _p(cn), B, n, float(d_exp_err), _p(srt), _p(dif), _p(ns)))
+        return (srt[0], dif[0, :max(n - 1, 0)], int(ns[0])) if single else (srt, dif, ns)
 
     def associate_sensors(self, t_img, imu_t, imu_quat, imu_omega, hgt_t, hgt_range, sensors=None):
         """evaluate_exp.py:68-95 on the device: nearest IMU / range sample per image time -> (sensors, imu_index, hgt_index).

@@ -122,6 +122,25 @@ int ofk_velocity_solve(ofk_ctx *ctx, int variant, const double *x, const double 
 #define OFK_IMU_MSG   15
 int ofk_imu_propagate(ofk_ctx *ctx, double *state, const double *msg, int batch);
 
+/* of_library.py:270-286 (calc_height), :53-75 + :100-114 (convert_to_of inside dynamic_immobile), :291-317 (eval_ft) — the
+ * per-feature estimators around the path, for a batch of track sets.  Per set b with counts[b] features (arrays are
+ * [batch][stride]...): observed flow = pos - oldpos; height and its variance from the pin-hole model with the set's velocity
+ * vel[b] +- vel_err[b]; immobile[i] = (observed - expected flow)^2 < var(observed) + var(expected) on both axes and neither old
+ * coordinate equals dummy_value; score = w0 (1 - height_n) + w1 height_err_n + w2 (1 - centre_dist_n) + w3 pos_err_n with the
+ * min/max normalisations of eval_ft; order = feature indices by ascending score (ties by index, NaN last; -1 past the count).
+ * *bad_height is set non-zero when a height is not positive (where the reference raises ValueError).  pos, oldpos
+ * [batch][stride][2] in pixels; pos_err, oldpos_err [batch][stride]; vel, vel_err [batch][3]; weight [4]. */
+int ofk_feature_eval(ofk_ctx *ctx, const double *pos, const double *pos_err, const double *oldpos, const double *oldpos_err,
+                     const int *counts, int batch, int stride, const double *vel, const double *vel_err, double focal_len,
+                     double dummy_value, int img_w, int img_h, const double *weight, double *height, double *height_err,
+                     uint8_t *immobile, double *score, int *order, int *bad_height);
+
+/* velocity_measurment_node:249-252 — statistics of the per-feature plane distances d_i that r_tilde returns (ofk_feasibility):
+ * sorted[b] = np.sort(d[b][:counts[b]]), diff[b][i] = sorted[i+1] - sorted[i], nsplit[b] = number of gaps >= d_exp_err (the
+ * split the node's commented line describes: several ground planes in view).  Arrays [batch][stride], stride <= 4096. */
+int ofk_d_split(ofk_ctx *ctx, const double *d, const int *counts, int batch, int stride, double d_exp_err, double *sorted,
+                double *diff, int *nsplit);
+
 /* evaluate_exp.py:68-95 — sensor association for replayed logs: for every image time t_img[k] (seconds, as the script forms
  * them: float(secs - secs0) + float(nsecs)/1e9) the nearest IMU and range samples (np.argmin(np.abs(values - t)): the first
  * minimum), then d = range, R from the IMU quaternion (x,y,z,w), normal = R e_z, omega = angular velocity.  Fills fields

@@ -244,3 +244,46 @@ def associate(t_img, imu_t, imu_q, imu_w, hgt_t, hgt_r):
     R = np.array([quat_to_rot(*imu_q[k]) for k in ii])
     normal = np.array([np.dot(Rk, np.array([0, 0, 1])) for Rk in R])
     return ii, hi, np.asarray(hgt_r, np.float64)[hi], R, normal, imu_w[ii]
+
+
+def d_split(d, d_exp_err):
+    """velocity_measurment_node:250-252 — sorted plane distances, consecutive differences, and the split count the commented
+    line :252 describes (gaps >= d_exp_err)."""
+    d_sorted = np.sort(np.asarray(d, np.float64))
+    d_diff = d_sorted[1:] - d_sorted[:-1]
+    return d_sorted, d_diff, int(np.sum(d_diff >= d_exp_err))
+
+
+def feature_eval(pos, pos_err, oldpos, oldpos_err, vel, vel_err, focal_len, dummy_value, img_dim, weight):
+    """of_library.py:270-286 (calc_height), :53-75 + :100-114 (convert_to_of inside dynamic_immobile), :291-317 (eval_ft) for ONE
+    track set, chained the way initialize_ft (:231-263) uses them.  PARITY UNPINNED: the reference's three functions carry
+    undefined names and cannot run; this restates the formulas they spell out.  pos, oldpos [n,2] px; pos_err,
+    oldpos_err [n]; vel, vel_err [3].  Returns (height, height_err, immobile, score, order)."""
+    pos = np.asarray(pos, np.float64).reshape(-1, 2); oldpos = np.asarray(oldpos, np.float64).reshape(-1, 2)
+    e = np.asarray(pos_err, np.float64).reshape(-1); oe = np.asarray(oldpos_err, np.float64).reshape(-1)
+    vx, vy, vz = [float(v) for v in vel]; vex, vey, vez = [float(v) for v in vel_err]
+    f = float(focal_len)
+    tx, ty = pix_trans(img_dim)
+    px, py = pos[:, 0], pos[:, 1]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ofx, ofy = px - oldpos[:, 0], py - oldpos[:, 1]
+        nx, ny = f * vx - px * vz, f * vy - py * vz
+        hx, hy = nx / ofx, ny / ofy
+        hxe = (f * vex / ofx) ** 2 + (nx * e / (ofx * ofx)) ** 2 + (e * vz / ofx) ** 2 + (px * vez / ofx) ** 2
+        hye = (f * vey / ofy) ** 2 + (ny * e / (ofy * ofy)) ** 2 + (e * vz / ofy) ** 2 + (py * vez / ofy) ** 2
+        h = 0.5 * (hx + hy); he = hxe + hye
+        xe = (f - (px - tx) / h) * vx / h; ye = (f - (py - ty) / h) * vy / h
+        fx, fy = f - px + tx, f - py + ty
+        xee = (e * vx / h) ** 2 + (fx * vex / h) ** 2 + (fx * vx * he / (h * h)) ** 2
+        yee = (e * vy / h) ** 2 + (fy * vey / h) ** 2 + (fy * vy * he / (h * h)) ** 2
+        obs_err = oe * oe + e * e
+        immobile = ((ofx - xe) ** 2 < obs_err + xee) & ((ofy - ye) ** 2 < obs_err + yee) & (oldpos[:, 0] != dummy_value) & \
+            (oldpos[:, 1] != dummy_value)
+
+        def norm(a):
+            rng_ = np.amax(a) - np.amin(a)
+            return (a - np.amin(a)) / rng_ if rng_ > 0 else np.zeros_like(a)
+        quad = (px - tx) ** 2 + (py - ty) ** 2
+        dn = quad / np.amax(quad) if np.amax(quad) > 0 else np.zeros_like(quad)
+        score = weight[0] * (1 - norm(h)) + weight[1] * norm(he) + weight[2] * (1 - dn) + weight[3] * norm(e)
+    return h, he, immobile, score, np.argsort(score, kind="stable")

@@ -67,6 +67,16 @@ def main():
         exec(load_lines(SRC, 79, 80), gg)
         ii.append(gg["imu_index"]); hi.append(gg["hgt_index"])
     out.update(g11b_imu_t=imu_values, g11b_hgt_t=hgt_values, g11b_q=q, g11b_imu_index=np.array(ii), g11b_hgt_index=np.array(hi))
+    # G12: velocity_measurment_node:250-251 (sorted plane distances and their consecutive differences) on the d_i that the
+    # reference's own r_tilde returns for the node's test features (G3 of reference_numpy.npz) and on seeded random sets
+    node = f"{REF}/velocity_measurment_node"
+    g3 = np.load(os.path.join(HERE, "reference_numpy.npz"))
+    sets = [np.asarray(g3["g3_d"], np.float64)] + [np.random.default_rng(120 + k).gamma(2.0, 0.7, n) for k, n in enumerate([1, 2, 37, 300])]
+    for k, dummy_d in enumerate(sets):
+        gg = {"np": np, "dummy_d": dummy_d}
+        exec(load_lines(node, 250, 251), gg)
+        out[f"g12_{k}_d"] = dummy_d; out[f"g12_{k}_sorted"] = np.asarray(gg["d_sorted"]); out[f"g12_{k}_diff"] = np.asarray(gg["d_diff"], np.float64)
+    out["g12_n"] = np.array(len(sets))
     path = os.path.join(HERE, "reference_association.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")
