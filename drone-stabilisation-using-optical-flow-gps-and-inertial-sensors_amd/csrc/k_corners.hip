@@ -1,6 +1,11 @@
 // k_corners.hip — Shi-Tomasi corner detection (cv2.goodFeaturesToTrack semantics).  gfx950.
 //
-//   k_mineig<BS,FUSED>
+//   k_mineig_pair<BS,MASK>   (block 3/5/7, row pitch a dword multiple — the pipeline's kernel)
+//       streaming response + 3x3 NMS + candidate keys: one wave per 128-column strip marching down the rows, two columns per
+//       lane, no LDS tile, no response map in HBM.  Described at its definition.
+//   k_mineig_stream<BS,MASK> (block 3/5/7/12, any width)
+//       the same march with one column per lane and 64-column strips (byte loads on border strips).
+//   k_mineig<BS,FUSED>       (any block size; the f32 map of ofk_mineig_response)
 //       One 256-thread block computes the min-eigenvalue response on a 64 x OH region:
 //         1. the gray tile (+ halo) is staged into LDS re-aligned with v_alignbyte (dword global loads);
 //         2. one thread per (row, 8-column segment) reads its gray bytes as dwords, forms the Sobel column sums

@@ -2,9 +2,11 @@
 //
 // All three are HBM-streaming integer kernels (no MFMA).  Layout: images of a batch live at
 // base + b*stride (stride 256-B aligned), rows tight (pitch = w).
-//   gray    : 16 px / thread, 3x dwordx4 loads + 1x dwordx4 store.
-//   pyrDown : 64x16 output tile / 256-thread block; source tile (136x35) staged into LDS with dword
-//             loads, separable 5-tap pass through a u16 LDS intermediate.
+//   gray    : 16 px / thread, 3x dwordx4 loads + 1x dwordx4 store, two v_dot4_u32_u8 per pixel.
+//   pyrDown : k_pyr_down_stream (widths divisible by 8): one wave per 496-column strip marching down the rows,
+//             packed-u16 5-tap filter in registers, no LDS;
+//             k_pyr_down (other widths): 64x16 output tile / 256-thread block; source tile (136x35) staged into LDS
+//             with dword loads, separable 5-tap pass through a u16 LDS intermediate.
 //   scharr  : 64x16 output tile, 68x18 source tile in LDS, int16x2 (4 B/px) coalesced stores.
 #include "ofk_internal.h"
 
