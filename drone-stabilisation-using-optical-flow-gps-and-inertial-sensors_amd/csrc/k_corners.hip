@@ -800,6 +800,11 @@ __global__ __launch_bounds__(256) OFK_PAIR_ATTR void k_mineig_pair(
     if (lane == 0 && mw > published) (void)atomicMax(maxbits + b * OFK_MAX_STRIDE, __float_as_uint(mw));
 }
 
+#undef OFK_PAIR_LOAD
+#undef OFK_PAIR_ROWS
+#undef OFK_LOAD_BLOCK
+#undef OFK_EIG_ROWS
+
 // The pair kernel takes odd boxes up to 7 on images whose rows are dword multiples and wide enough for one mirror fold.
 static bool pair_ok(int w, int block)
 {
