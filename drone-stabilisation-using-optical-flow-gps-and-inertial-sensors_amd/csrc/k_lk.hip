@@ -342,7 +342,17 @@ __global__ __launch_bounds__(64) void k_lk15(const uint8_t *__restrict__ prev, c
     __shared__ __attribute__((aligned(16))) uint8_t s_I[20 * LKF_IP];
     __shared__ __attribute__((aligned(16))) uint8_t s_J[(LKF_JW + 1) * LKF_JP];
 
-    const int b = blockIdx.y, p = blockIdx.x, lane = threadIdx.x;
+    // XCD-aware block -> (image, point) map.  Workgroups are dealt round-robin over the 8 XCDs (blocks n and n + 8 share one),
+    // each with its own L2.  The windows of an image's points overlap heavily (at the coarse levels every point reads most
+    // of the level), so all points of an image go to ONE XCD — image b to the XCD of blocks n = b (mod 8) — and its pyramid
+    // lines are fetched from HBM once instead of once per XCD.  Speed only; any placement gives the same results.
+    const int lane = threadIdx.x;
+    int b = blockIdx.y, p = blockIdx.x;
+    if ((gridDim.y & 7) == 0) {
+        const unsigned n = blockIdx.y * gridDim.x + blockIdx.x, k = n >> 3;
+        b = 8 * (int)(k / gridDim.x) + (int)(n & 7);
+        p = (int)(k % gridDim.x);
+    }
     if (p >= counts[b]) return;
     const size_t pi = (size_t)b * pts_stride + p;
     const float ptx = prev_pts[2 * pi], pty = prev_pts[2 * pi + 1];
