@@ -694,15 +694,22 @@ __global__ __launch_bounds__(256) OFK_PAIR_ATTR void k_mineig_pair(
     __shared__ unsigned long long s_buf[4][NBUF + 64];          // + 64: a flush reads one whole 64-key chunk past the count
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int sx = blockIdx.x * 4 + wave;
+    // XCD-aware block -> (image, chunk, strip block) map: workgroups are dealt round-robin over the 8 XCDs (blocks n and
+    // n + 8 share one L2); an image's strips and chunks go to ONE XCD, so the halo columns and rows they share are fetched once.
+    int bxi = blockIdx.x, byi = blockIdx.y, b = blockIdx.z;
+    if ((gridDim.z & 7) == 0) {
+        const unsigned per = gridDim.x * gridDim.y, n = blockIdx.z * per + blockIdx.y * gridDim.x + blockIdx.x, k = n >> 3, rem = k % per;
+        b = 8 * (int)(k / per) + (int)(n & 7);
+        byi = (int)(rem / gridDim.x); bxi = (int)(rem % gridDim.x);
+    }
+    const int sx = bxi * 4 + wave;
     if (sx * SW - D >= w) return;                               // whole wave
-    const int b = blockIdx.z;
-    const int ya = blockIdx.y * rows_per_strip, yb = min(h, ya + rows_per_strip);
+    const int ya = byi * rows_per_strip, yb = min(h, ya + rows_per_strip);
     const uint8_t *img = gray + (size_t)b * gray_stride;
     const uint8_t *mk = MASK ? mask + (size_t)b * mask_stride : nullptr;
     unsigned long long *buf = s_buf[wave];
 
-    const int G0 = sx * SW - PAD;                               // gray column of lane 0's even slot: a multiple of 4
+    const int G0 = sx * SW - PAD;                              // gray column of lane 0's even slot: a multiple of 4
     const int ce = G0 + 2 * lane;                               // this lane's even gray / product column (odd: ce + 1)
     const bool edge_strip = G0 < 0 || G0 + 128 > w;             // some column is mirrored (wave-uniform)
     const bool flip_e = ce < 0 || ce >= w, flip_o = ce + 1 < 0 || ce + 1 >= w;
@@ -715,7 +722,7 @@ __global__ __launch_bounds__(256) OFK_PAIR_ATTR void k_mineig_pair(
     const int Yp0 = ya - 1 - AN;                                // first product row
     const int nsteps = (yb - ya) + BS + 3;
     const int nstrips = (w + D + SW - 1) / SW;
-    const int nseg = nstrips * (int)gridDim.y, segid = (int)blockIdx.y * nstrips + sx;
+    const int nseg = nstrips * (int)gridDim.y, segid = byi * nstrips + sx;
     unsigned long long *myseg = seg + ((size_t)b * nseg + segid) * seg_cap;
     int written = 0, cnt = 0;
     int lmaxi = 0;

@@ -200,10 +200,17 @@ __global__ __launch_bounds__(256) void k_pyr_down_stream(const uint8_t *__restri
                                                          int rows, int nstrips, int nchunks)
 {
     const int lane = threadIdx.x & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));   // wave-uniform: row math stays scalar
+    // XCD-aware block -> (image, blocks of the image) map: workgroups are dealt round-robin over the 8 XCDs (blocks n and
+    // n + 8 share one L2), so an image's row chunks go to ONE XCD and the halo rows two chunks share are fetched once.
+    int bx = blockIdx.x, z = blockIdx.y;
+    if ((gridDim.y & 7) == 0) {
+        const unsigned n = blockIdx.y * gridDim.x + blockIdx.x, k = n >> 3;
+        z = 8 * (int)(k / gridDim.x) + (int)(n & 7);
+        bx = (int)(k % gridDim.x);
+    }
+    const int wid = __builtin_amdgcn_readfirstlane(bx * 4 + (threadIdx.x >> 6));   // wave-uniform: row math stays scalar
     if (wid >= nstrips * nchunks) return;                       // whole wave
     const int strip = wid % nstrips, chunk = wid / nstrips;
-    const int z = blockIdx.y;
     const uint8_t *img = z < batch ? src0 + (size_t)z * src_stride : src1 + (size_t)(z - batch) * src_stride;
     uint8_t *out = z < batch ? dst0 + (size_t)z * dst_stride : dst1 + (size_t)(z - batch) * dst_stride;
     const int c0 = strip * PDS_COLS - 8 + 8 * lane;             // first source column of this lane
