@@ -37,6 +37,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# before anything initialises the HIP runtime (torch does, below): 4 pipeline streams + torch's + RCCL's need more than the
+# runtime's default 4 hardware queues, or two of them share a queue and serialise (schedule)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 from __graft_entry__ import load_package  # noqa: E402
 
 H, W = 1080, 1920
@@ -122,7 +125,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="frame pairs per GPU per step")
-    ap.add_argument("--streams", type=int, default=1, help="concurrent slices of the batch (HIP streams) per GPU")
+    ap.add_argument("--streams", type=int, default=2, help="free-running slices of the batch (HIP streams) per GPU")
     ap.add_argument("--no-overlap", action="store_true", help="run every stage of a step serially on one stream")
     ap.add_argument("--cpu-sample", type=int, default=24, help="pairs timed on the CPU oracle (0 = skip)")
     args = ap.parse_args()
@@ -205,8 +208,9 @@ def main():
     # Outside the timed region: the same K steps once more with every stage serial on one stream, so that each kernel's
     # duration is its own (under overlap two kernels share the chip and each one's event time includes the other).
     iso = prof
-    if not args.no_overlap:
+    if not args.no_overlap or args.streams > 1:
         pipe.ctx.set_overlap(False)
+        pipe.ctx.set_streams(1)
         pipe.run_async(); pipe.sync()
         pipe.ctx.profile_enable(0x7f)
         for _ in range(args.steps):
@@ -214,7 +218,8 @@ def main():
         pipe.sync()
         iso = pipe.ctx.profile_read()
         pipe.ctx.profile_enable(0)
-        pipe.ctx.set_overlap(True)
+        pipe.ctx.set_overlap(not args.no_overlap)
+        pipe.ctx.set_streams(args.streams)
 
     if dist is not None:
         dt = sharding.max_over_ranks(dist, dt, device=f"cuda:{local}")

@@ -96,25 +96,23 @@ extern "C" int ofk_create(int device, int max_w, int max_h, int max_batch, int m
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { free(c); return ofk_fail(nullptr, OFK_E_HIP, "hipStreamCreate failed"); }
     c->nstreams = 1;
     c->streams[0] = c->stream;
-    for (int k = 1; k < OFK_MAX_STREAMS; ++k) {
-        if (hipStreamCreateWithFlags(&c->streams[k], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming) != hipSuccess) {
-            ofk_fail(nullptr, OFK_E_HIP, "hipStreamCreate (slice stream %d) failed", k);
-            ofk_destroy(c);
-            return OFK_E_HIP;
-        }
-    }
-    hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     c->overlap = 1;
-    for (int k = 0; k < OFK_MAX_STREAMS; ++k) {
-        if (hipStreamCreateWithFlags(&c->aux[k], hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&c->ev_g0[k], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&c->ev_aux[k], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&c->ev_lkdone[0][k], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&c->ev_lkdone[1][k], hipEventDisableTiming) != hipSuccess) {
-            ofk_fail(nullptr, OFK_E_HIP, "hipStreamCreate (auxiliary stream %d) failed", k);
-            ofk_destroy(c);
-            return OFK_E_HIP;
-        }
+    // Slice and auxiliary streams are created when a call first needs them (need_streams): the runtime multiplexes HIP streams
+    // onto a few hardware queues (4 by default), and two streams of one queue run in order - an idle stream would cost a real one
+    // its concurrency.
+    bool ok = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&c->ev_x, hipEventDisableTiming) == hipSuccess;
+    for (int k = 0; k < OFK_MAX_STREAMS && ok; ++k)
+        ok = hipEventCreateWithFlags(&c->ev_g0[k], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&c->ev_aux[k], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&c->ev_lkdone[0][k], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&c->ev_lkdone[1][k], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&c->ev_end[k], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&c->ev_stagger[k], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        ofk_fail(nullptr, OFK_E_HIP, "hipEventCreate failed");
+        ofk_destroy(c);
+        return OFK_E_HIP;
     }
     const size_t B = (size_t)max_batch;
     for (int k = 0; k < 2; ++k) { ALLOC(c->bgr[k], B * c->bgr_stride); ALLOC(c->pyr[k], B * c->pyr_stride); }
@@ -152,7 +150,7 @@ extern "C" int ofk_destroy(ofk_ctx *c)
     if (c->ev) { for (int i = 0; i < c->ev_cap; ++i) if (c->ev[i]) hipEventDestroy(c->ev[i]); free(c->ev); }
     free(c->ev_stage);
     free(c->h_counts);
-    for (int k = 1; k < OFK_MAX_STREAMS; ++k) { if (c->streams[k]) hipStreamDestroy(c->streams[k]); if (c->ev_join[k]) hipEventDestroy(c->ev_join[k]); }
+    for (int k = 1; k < OFK_MAX_STREAMS; ++k) if (c->streams[k]) hipStreamDestroy(c->streams[k]);
     for (int k = 0; k < OFK_MAX_STREAMS; ++k) {
         if (c->aux[k]) hipStreamDestroy(c->aux[k]);
         if (c->ev_g0[k]) hipEventDestroy(c->ev_g0[k]);
@@ -161,15 +159,55 @@ extern "C" int ofk_destroy(ofk_ctx *c)
     }
     for (int k = 0; k < 2; ++k) if (c->pyr_alt[k]) hipFree(c->pyr_alt[k]);
     for (int k = 0; k < 8; ++k) if (c->marks[k]) hipEventDestroy(c->marks[k]);
+    for (int k = 0; k < OFK_MAX_STREAMS; ++k) {
+        if (c->ev_end[k]) hipEventDestroy(c->ev_end[k]);
+        if (c->ev_stagger[k]) hipEventDestroy(c->ev_stagger[k]);
+    }
+    if (c->ev_x) hipEventDestroy(c->ev_x);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->stream) hipStreamDestroy(c->stream);
     free(c);
     return OFK_OK;
 }
 
+// Slice streams free-run across consecutive ofk_pairs_run calls.  Every other entry point works on the context's stream and
+// on buffers the slices use, so it first makes that stream wait for whatever the slices (and the export stream) still hold.
+static int need_streams(ofk_ctx *c, int slices, bool overlap)
+{
+    for (int k = 1; k < slices; ++k)
+        if (!c->streams[k]) OFK_HIP(c, hipStreamCreateWithFlags(&c->streams[k], hipStreamNonBlocking));
+    for (int k = 0; k < slices && overlap; ++k)
+        if (!c->aux[k]) OFK_HIP(c, hipStreamCreateWithFlags(&c->aux[k], hipStreamNonBlocking));
+    return OFK_OK;
+}
+
+// The last slice's stream once every other slice of the latest call has finished: where record export and marks are queued while
+// the slices are open.  The slices are offset in time and the last one finishes last, so the waits cost it nothing; a stream of
+// their own would have to share a hardware queue with one of the slices.
+static hipStream_t tail_stream(ofk_ctx *c)
+{
+    if (!c->slices_open) return c->stream;
+    hipStream_t s = c->streams[c->open_slices - 1];
+    for (int k = 0; k + 1 < c->open_slices; ++k) hipStreamWaitEvent(s, c->ev_end[k], 0);
+    return s;
+}
+
+static void join_slices(ofk_ctx *c)
+{
+    if (c->slices_open) {
+        for (int k = 1; k < c->open_slices; ++k) hipStreamWaitEvent(c->stream, c->ev_end[k], 0);
+        c->slices_open = 0;
+    }
+    if (c->x_pending) {
+        hipStreamWaitEvent(c->stream, c->ev_x, 0);
+        c->x_pending = 0;
+    }
+}
+
 extern "C" int ofk_sync(ofk_ctx *c)
 {
     if (!c) return OFK_E_INVALID;
+    join_slices(c);
     OFK_HIP(c, hipStreamSynchronize(c->stream));
     return OFK_OK;
 }
@@ -190,6 +228,7 @@ static int check_geom(ofk_ctx *c, int batch, int h, int w, const char *who)
     if (hipSetDevice(c->device) != hipSuccess) return ofk_fail(c, OFK_E_HIP, "hipSetDevice failed");
     if (batch < 1 || batch > c->max_batch || h < 1 || w < 1 || (size_t)h * w > c->P || h > 16384 || w > 16384)
         return ofk_fail(c, OFK_E_INVALID, "%s: batch %d / %dx%d exceeds the context (batch %d, %zu px)", who, batch, w, h, c->max_batch, c->P);
+    join_slices(c);
     return OFK_OK;
 }
 
@@ -433,6 +472,7 @@ static int est_begin(ofk_ctx *c, size_t bytes, Bump &bp)
 {
     if (!c) return OFK_E_INVALID;
     if (hipSetDevice(c->device) != hipSuccess) return ofk_fail(c, OFK_E_HIP, "hipSetDevice failed");
+    join_slices(c);
     TRY(ofk_need_scratch(c, bytes + 64 * 256));
     bp.c = c; bp.base = (char *)c->scratch; bp.off = 0; bp.rc = OFK_OK;
     return OFK_OK;
@@ -647,6 +687,7 @@ extern "C" int ofk_pairs_upload(ofk_ctx *c, const uint8_t *prev_bgr, const uint8
 extern "C" int ofk_pairs_set_sensors(ofk_ctx *c, const double *sensors, int batch)
 {
     if (!c || !sensors || batch < 1 || batch > c->max_batch) return ofk_fail(c, OFK_E_INVALID, "ofk_pairs_set_sensors: bad argument");
+    join_slices(c);
     OFK_HIP(c, hipMemcpyAsync(c->sensors, sensors, (size_t)batch * OFK_SENSOR_DOUBLES * 8, hipMemcpyHostToDevice, c->stream));
     OFK_HIP(c, hipStreamSynchronize(c->stream));
     return OFK_OK;
@@ -698,7 +739,12 @@ extern "C" int ofk_pairs_run(ofk_ctx *c, const ofk_params *p)
     int set = 0;
     if (overlap) { set = c->pyr_set; c->pyr_set ^= 1; }
     uint8_t *const P0 = set ? c->pyr_alt[0] : c->pyr[0], *const P1 = set ? c->pyr_alt[1] : c->pyr[1];
-    if (S > 1) {
+    // Slices are forked off the context's stream once and then free-run over consecutive calls: nothing joins them until an
+    // entry point needs the context's stream to see their results (join_slices).  On the fork the response kernels are chained
+    // slice after slice, which offsets the slices by one response kernel for as long as they run.
+    const bool fork = S > 1 && !c->slices_open;
+    TRY(need_streams(c, S, overlap));
+    if (fork) {
         hipEventRecord(c->ev_fork, c->stream);
         for (int k = 1; k < S; ++k) hipStreamWaitEvent(c->streams[k], c->ev_fork, 0);
     }
@@ -738,6 +784,7 @@ extern "C" int ofk_pairs_run(ofk_ctx *c, const ofk_params *p)
             hipEventRecord(c->ev_aux[k], sa);
             hipStreamWaitEvent(st, c->ev_g0[k], 0);              // the response kernel needs the previous frame's gray level
         }
+        if (fork && k > 0) hipStreamWaitEvent(st, c->ev_stagger[k - 1], 0);
         {
             StageTimer t(c, OFK_STAGE_EIG, st);                  // response + 3x3 NMS + candidate keys, no map in HBM
             hipMemsetAsync(maxbits, 0, (size_t)nb * OFK_MAX_STRIDE * 4, st);
@@ -746,6 +793,7 @@ extern "C" int ofk_pairs_run(ofk_ctx *c, const ofk_params *p)
                                        cand_count, cand_seg, c->seg_keys, seg_count, OFK_SEG_MAX, c->dev_flags, nb, &nseg, &segcap))
                 return ofk_fail(c, OFK_E_INVALID, "corner response: block_size %d does not fit (LDS tile / key segments)", p->block_size);
         }
+        if (fork) hipEventRecord(c->ev_stagger[k], st);
         {
             StageTimer t(c, OFK_STAGE_SELECT, st);
             ofk_launch_select(st, cand, c->cand_cap, cand_count, cand_seg, segcap, seg_count, nseg, maxbits, p->quality, w, p->max_corners,
@@ -758,16 +806,15 @@ extern "C" int ofk_pairs_run(ofk_ctx *c, const ofk_params *p)
                           pts_next, status, err, nb);
         }
         if (overlap) hipEventRecord(c->ev_lkdone[set][k], st);   // this pyramid set may be rewritten from here on
+        if (c->x_pending) hipStreamWaitEvent(st, c->ev_x, 0);    // the previous call's records are still being exported
         {
             StageTimer t(c, OFK_STAGE_SOLVE, st);
             ofk_launch_pairs_solve(st, pts_prev, pts_next, status, counts, c->max_pts, c->sensors + (size_t)b0 * OFK_SENSOR_DOUBLES,
                                    p->solve_variant, p->use_feasibility, p->feas_T, cand_count, c->records + (size_t)b0 * OFK_RECORD_DOUBLES, nb);
         }
-        if (k > 0) {                                             // join: the context's stream waits for the slice
-            hipEventRecord(c->ev_join[k], st);
-            hipStreamWaitEvent(c->stream, c->ev_join[k], 0);
-        }
+        if (S > 1) hipEventRecord(c->ev_end[k], st);             // joined lazily (join_slices), not here
     }
+    if (S > 1) { c->slices_open = 1; c->open_slices = S; }
     return check_launch(c, "ofk_pairs_run");
 }
 
@@ -779,6 +826,7 @@ extern "C" int ofk_pairs_download(ofk_ctx *c, double *records, float *prev_pts, 
     const int B = c->cur_batch;
     const size_t np = (size_t)B * c->max_pts;
     int flags[4];
+    join_slices(c);
     OFK_HIP(c, hipMemcpyAsync(flags, c->dev_flags, 16, hipMemcpyDeviceToHost, c->stream));
     if (records) OFK_HIP(c, hipMemcpyAsync(records, c->records, (size_t)B * OFK_RECORD_DOUBLES * 8, hipMemcpyDeviceToHost, c->stream));
     if (prev_pts) OFK_HIP(c, hipMemcpyAsync(prev_pts, c->pts_prev, np * 8, hipMemcpyDeviceToHost, c->stream));
@@ -800,7 +848,12 @@ extern "C" int ofk_pairs_download(ofk_ctx *c, double *records, float *prev_pts, 
 extern "C" int ofk_pairs_export_records_f32(ofk_ctx *c, void *device_dst, int batch)
 {
     if (!c || !device_dst || batch < 1 || batch > c->cur_batch) return ofk_fail(c, OFK_E_INVALID, "ofk_pairs_export_records_f32: bad argument");
-    ofk_launch_records_f32(c->stream, c->records, (float *)device_dst, batch);
+    hipStream_t s = tail_stream(c);
+    ofk_launch_records_f32(s, c->records, (float *)device_dst, batch);
+    if (c->slices_open) {                                        // the other slices' next solve must not overtake the export
+        hipEventRecord(c->ev_x, s);
+        c->x_pending = 1;
+    }
     return check_launch(c, "k_records_f32");
 }
 
@@ -883,6 +936,7 @@ extern "C" int ofk_stream_step(ofk_ctx *c, const uint8_t *next_bgr, const double
     if (!c || !next_bgr || !sensors || !p) return ofk_fail(c, OFK_E_INVALID, "ofk_stream_step: NULL argument");
     if (c->stream_batch < 1) return ofk_fail(c, OFK_E_INVALID, "ofk_stream_step: call ofk_stream_begin first");
     if (hipSetDevice(c->device) != hipSuccess) return ofk_fail(c, OFK_E_HIP, "hipSetDevice failed");
+    join_slices(c);
     const int B = c->stream_batch, h = c->stream_h, w = c->stream_w;
     TRY(check_block(c, h, w, p->block_size));
     TRY(check_select(c, p->max_corners, p->quality, p->min_distance));
@@ -921,6 +975,7 @@ extern "C" int ofk_stream_step(ofk_ctx *c, const uint8_t *next_bgr, const double
 extern "C" int ofk_set_streams(ofk_ctx *c, int nstreams)
 {
     if (!c || nstreams < 1 || nstreams > OFK_MAX_STREAMS) return ofk_fail(c, OFK_E_INVALID, "ofk_set_streams: 1..%d", OFK_MAX_STREAMS);
+    join_slices(c);
     c->nstreams = nstreams;
     return OFK_OK;
 }
@@ -937,7 +992,7 @@ extern "C" int ofk_mark(ofk_ctx *c, int slot)
     if (!c || slot < 0 || slot >= 8) return ofk_fail(c, OFK_E_INVALID, "ofk_mark: slot 0..7");
     OFK_HIP(c, hipSetDevice(c->device));
     if (!c->marks[slot]) OFK_HIP(c, hipEventCreateWithFlags(&c->marks[slot], hipEventDisableTiming));
-    OFK_HIP(c, hipEventRecord(c->marks[slot], c->stream));
+    OFK_HIP(c, hipEventRecord(c->marks[slot], tail_stream(c)));  // "everything enqueued so far" includes every slice
     return OFK_OK;
 }
 
@@ -959,6 +1014,7 @@ extern "C" int ofk_profile_enable(ofk_ctx *c, int stage_mask)
 extern "C" int ofk_profile_read(ofk_ctx *c, double *ms_total, int *launches)
 {
     if (!c || !ms_total || !launches) return OFK_E_INVALID;
+    join_slices(c);
     OFK_HIP(c, hipStreamSynchronize(c->stream));
     for (int s = 0; s < OFK_N_STAGES; ++s) { ms_total[s] = 0.0; launches[s] = 0; }
     for (int i = 0; i + 1 < c->ev_n; i += 2) {

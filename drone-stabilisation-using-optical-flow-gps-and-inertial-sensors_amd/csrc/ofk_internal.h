@@ -22,13 +22,19 @@ struct ofk_levels {
 struct ofk_ctx {
     int device;
     hipStream_t stream;                           // the context's stream (slice 0); entry points synchronise on it
-    hipStream_t streams[OFK_MAX_STREAMS]; int nstreams;   // extra slice streams, joined back into `stream` by events
-    hipEvent_t ev_fork, ev_join[OFK_MAX_STREAMS];
+    hipStream_t streams[OFK_MAX_STREAMS]; int nstreams;   // extra slice streams (created on first use), joined back into `stream` by events
+    hipEvent_t ev_fork;
     hipStream_t aux[OFK_MAX_STREAMS]; int overlap;        // per-slice auxiliary stream: next-frame gray + pyramids beside the response kernel
     hipEvent_t ev_g0[OFK_MAX_STREAMS], ev_aux[OFK_MAX_STREAMS];
     uint8_t *pyr_alt[2]; int pyr_set;                     // second pyramid set: the auxiliary stream runs one call ahead
     hipEvent_t ev_lkdone[2][OFK_MAX_STREAMS];             // LK of the call that last read a set has finished
     hipEvent_t marks[8];                                  // ofk_mark / ofk_mark_wait
+    // Slices free-run across consecutive ofk_pairs_run calls (no fork/join per call) and are offset by one response kernel, so
+    // one slice's latency-bound stages (selection, solve) always run beside another slice's response kernel or LK.
+    int slices_open, open_slices;                         // slice streams hold work the context's stream has not joined yet / how many
+    hipEvent_t ev_end[OFK_MAX_STREAMS];                   // end of a slice's chain of the latest call (slice 0 included)
+    hipEvent_t ev_stagger[OFK_MAX_STREAMS];               // response kernel of slice k launched (first call after a join)
+    hipEvent_t ev_x; int x_pending;                       // record export queued behind the last slice, not yet seen by `stream`
     int max_w, max_h, max_batch, max_pts, max_level;
     size_t P;                       // max_w * max_h
     size_t bgr_stride;              // bytes between images in bgr[], 256-B aligned

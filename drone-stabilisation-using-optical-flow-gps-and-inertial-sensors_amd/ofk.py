@@ -56,6 +56,10 @@ def load_library():
         if not os.path.exists(LIB_PATH):
             raise OfkError(E_NOGPU, f"{LIB_PATH} not built (run `make -C {os.path.join(_HERE, 'csrc')}` or "
                                     "__graft_entry__.build()); there is no CPU fallback")
+        # The resident pipeline keeps 4 HIP streams busy (2 free-running slices x {chain, auxiliary}) beside the caller's own
+        # (torch's, RCCL's).  The HIP runtime multiplexes streams onto 4 hardware queues unless told otherwise, and two streams of
+        # one queue run in order.  Only effective if the runtime is not initialised yet; a value the user set wins.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
         L = C.CDLL(LIB_PATH)
         vp, i, d = C.c_void_p, C.c_int, C.c_double
         L.ofk_version.restype = i

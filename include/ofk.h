@@ -207,7 +207,8 @@ int ofk_pairs_run(ofk_ctx *ctx, const ofk_params *p);
 int ofk_pairs_download(ofk_ctx *ctx, double *records, float *prev_pts, float *next_pts, uint8_t *status, float *err,
                        int *counts);
 /* Writes the batch's velocity records as float32 [batch][8] = {vx,vy,vz,residual,n_used,s_min,rank,corners} to a
- * DEVICE pointer owned by the caller (the buffer an RCCL all_gather sends), asynchronously on the context's stream. */
+ * DEVICE pointer owned by the caller (the buffer an RCCL all_gather sends), asynchronously behind the latest ofk_pairs_run
+ * (wait with ofk_mark + ofk_mark_wait, or ofk_sync). */
 int ofk_pairs_export_records_f32(ofk_ctx *ctx, void *device_dst, int batch);
 
 /* ------------------------------------------------- video streams: persistent tracks on the device (feature lifecycle)
@@ -227,13 +228,17 @@ int ofk_stream_step(ofk_ctx *ctx, const uint8_t *next_bgr, const double *sensors
                     int mask_radius, double *records, float *tracks, int *counts);
 
 /* Number of concurrent slices ofk_pairs_run cuts the batch into (1..8, default 1): each slice runs the whole stage chain on
- * its own HIP stream so that latency-bound stages overlap with streaming ones; results do not depend on it. */
+ * its own HIP stream so that latency-bound stages overlap with streaming ones; results do not depend on it.  With more than
+ * one slice, consecutive ofk_pairs_run calls do not join the slices: they free-run, offset by one response kernel, until any
+ * other entry point (download, sync, upload, set_sensors ...) needs their results and joins them.  ofk_pairs_export_records_f32
+ * and ofk_mark queue behind the slices without joining them.  (The schedule needs 2 x nstreams hardware queues; the HIP
+ * runtime's default is 4 in total - GPU_MAX_HW_QUEUES.) */
 int ofk_set_streams(ofk_ctx *ctx, int nstreams);
 /* ofk_pairs_run scheduling (default on): the HBM-bound gray conversions and pyramids run on an auxiliary stream into one
  * of two pyramid buffer sets, alternating per call, so that they overlap the VALU-bound response kernel and LK — of this call
  * and, when calls are queued back to back, of the previous one.  Results identical. */
 int ofk_set_overlap(ofk_ctx *ctx, int on);
-/* Completion marks on the context's stream (slots 0..7): ofk_mark records one behind everything queued so far, ofk_mark_wait
+/* Completion marks (slots 0..7): ofk_mark records one behind everything queued so far on every slice, ofk_mark_wait
  * blocks the host until it has been reached (returns at once for a slot never marked).  They let a caller hand step k's
  * records to another library (an RCCL gather) while step k+1 is already queued, without draining the stream. */
 int ofk_mark(ofk_ctx *ctx, int slot);

@@ -148,6 +148,68 @@ def test_marks(pkg, ofk):
     pipe.close()
 
 
+@pytest.mark.parametrize("streams", [2, 3])
+def test_free_running_slices_export_and_join(pkg, ofk, streams):
+    """With more than one slice stream the slices free-run over consecutive ofk_pairs_run calls; record export and marks run
+    beside them on their own stream, and any other entry point joins them first.  None of that may change a single bit."""
+    import ctypes
+    from of_amd import synth
+    from of_amd.pipeline import FlowPipeline, PipelineConfig
+    hip = ctypes.CDLL("libamdhip64.so")                        # the runtime libofk.so already loaded: plain device buffers, no torch
+    B = 6
+    nbytes = B * 8 * 4                                         # exported record: [v(3), R, used, s_min, rank, corners] as f32
+
+    def dev_fill():
+        assert hip.hipMemset(ctypes.c_void_p(ptr.value), 0xff, ctypes.c_size_t(2 * nbytes)) == 0
+
+    def dev_read(slot):
+        host = np.empty((B, 8), np.float32)
+        assert hip.hipMemcpy(host.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(ptr.value + slot * nbytes), ctypes.c_size_t(nbytes), 2) == 0
+        return host
+    prev, nxt, base = synth.make_batch(B, 240, 320, seed=31, distinct=B)
+    s_a = ofk.make_sensors(B, scaling=base[0]["scaling"], cx=base[0]["cx"], cy=base[0]["cy"])
+    s_b = ofk.make_sensors(B, scaling=base[0]["scaling"] * 1.25, cx=base[0]["cx"], cy=base[0]["cy"])
+    cfg = PipelineConfig(max_corners=80, quality=0.03, min_distance=6)
+    one = FlowPipeline(320, 240, B, cfg, streams=1)
+    one.upload(prev, nxt, s_a)
+    ref_a = one.run()
+    one.ctx.pairs_set_sensors(s_b)
+    ref_b = one.run()["records"]
+    one.close()
+    assert not np.array_equal(ref_a["records"], ref_b)
+
+    pipe = FlowPipeline(320, 240, B, cfg, streams=streams)
+    pipe.upload(prev, nxt, s_a)
+    ptr = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(ptr), ctypes.c_size_t(2 * nbytes)) == 0
+    dev_fill()
+    want = ref_a["records"][:, [0, 1, 2, 3, 11, 7, 4, 12]].astype(np.float32)
+    for k in range(5):                                         # export k overlaps run k+1; waiting on mark k-1 while k runs
+        pipe.run_async()
+        pipe.ctx.pairs_export_records_f32(ptr.value + (k % 2) * nbytes, B)
+        pipe.ctx.mark(k % 2)
+        if k:
+            pipe.ctx.mark_wait((k - 1) % 2)
+            assert np.array_equal(dev_read((k - 1) % 2).view(np.uint32), want.view(np.uint32))
+    pipe.ctx.mark_wait(0)
+    assert np.array_equal(dev_read(0).view(np.uint32), want.view(np.uint32))
+    pipe.ctx.pairs_set_sensors(s_b)                            # joins the slices, then changes what the solve reads
+    pipe.run_async()
+    pipe.run_async()
+    out = pipe.ctx.pairs_download()                            # joins again
+    assert np.array_equal(out["records"], ref_b)
+    assert np.array_equal(out["counts"], ref_a["counts"])
+    for b in range(B):
+        n = int(out["counts"][b])
+        for key in ("prev_pts", "next_pts", "status", "err"):
+            assert np.array_equal(out[key][b, :n], ref_a[key][b, :n]), key
+    pipe.ctx.set_streams(1)                                    # joins; the next call runs on the context's stream alone
+    pipe.ctx.pairs_set_sensors(s_a)
+    assert np.array_equal(pipe.run()["records"], ref_a["records"])
+    pipe.close()
+    assert hip.hipFree(ptr) == 0
+
+
 def test_profile_and_export(pkg, ofk):
     from of_amd import synth
     from of_amd.pipeline import FlowPipeline, PipelineConfig
