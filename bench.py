@@ -127,6 +127,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="frame pairs per GPU per step")
     ap.add_argument("--streams", type=int, default=2, help="free-running slices of the batch (HIP streams) per GPU")
     ap.add_argument("--no-overlap", action="store_true", help="run every stage of a step serially on one stream")
+    ap.add_argument("--no-isolated", action="store_true", help="skip the serial pass behind the timed region (profiling: the kernel "
+                    "trace then holds the timed schedule's launches only)")
     ap.add_argument("--cpu-sample", type=int, default=24, help="pairs timed on the CPU oracle (0 = skip)")
     args = ap.parse_args()
 
@@ -208,7 +210,7 @@ def main():
     # Outside the timed region: the same K steps once more with every stage serial on one stream, so that each kernel's
     # duration is its own (under overlap two kernels share the chip and each one's event time includes the other).
     iso = prof
-    if not args.no_overlap or args.streams > 1:
+    if (not args.no_overlap or args.streams > 1) and not args.no_isolated:
         pipe.ctx.set_overlap(False)
         pipe.ctx.set_streams(1)
         pipe.run_async(); pipe.sync()

@@ -1,0 +1,681 @@
+// k_jpeg.hip — baseline JPEG -> BGR8 on the device: the ingest in front of the hot path (the reference decodes
+// every sensor_msgs/CompressedImage with cv_bridge.compressed_imgmsg_to_cv2 = cv::imdecode = libjpeg,
+// velocity_measurment_node.py:112).  Output is bit-identical to libjpeg's default decompressor (ISLOW integer IDCT, "fancy"
+// triangle chroma upsampling, 16-bit fixed-point YCbCr->RGB).  The host only parses the marker segments and packs the tables;
+// entropy decoding, IDCT, upsampling and colour conversion run on the GPU.
+//
+// Huffman decoding is a serial bit-by-bit process per image.  It is parallelised by *self-synchronisation* (Klein & Wiseman 2003;
+// Weissenberger & Schmidt, "Massively parallel Huffman decoding on GPUs", ICPP 2018, and their 2021 JPEG follow-up): the entropy
+// segment is cut into chunks of JCH bytes, one decoder thread per chunk.  A decoder that starts at a wrong bit position / block
+// position produces garbage for a while but, because Huffman codes are prefix codes, falls into step with the true symbol sequence
+// after a few dozen symbols with overwhelming probability.
+//   1. k_jpeg_sync, iteration 0: every thread decodes its chunk from a guessed state (chunk start, block start) and publishes the
+//      state in which it crossed into the next chunk; iteration n > 0: every thread whose predecessor published a different state
+//      than the one it started from last time decodes its chunk again from that state.  Chunk 0 starts from the true state, so the
+//      truth advances at least one chunk per iteration; in practice all chunks agree after two iterations.  An iteration in which
+//      no thread changed its published state is a fixed point, and a fixed point that starts from the true state is the true
+//      decode (induction over the chunks) — the result never depends on the probabilistic argument, only the run time does.
+//   2. k_jpeg_scan: exclusive prefix sum of the blocks completed per chunk = index of the block a chunk starts in.
+//   3. k_jpeg_write: every thread decodes its chunk once more from its (now true) entry state and stores the coefficients.
+//   4. k_jpeg_dc: DC prediction = prefix sum of the DC differences per component in decode order.
+//   5. k_jpeg_idct: dequantisation + ISLOW IDCT, 8 lanes per block (columns, then rows through LDS) -> component planes.
+//   6. k_jpeg_color: fancy upsampling + colour conversion -> BGR8.
+// The decoder state at a symbol boundary is (byte cursor, bits left in the buffer, zigzag index, block-in-MCU); it is canonical —
+// a function of the true bit position only — because the bit buffer is refilled byte by byte to 25..32 bits before every symbol
+// and before every run of extra bits, so two decoders that agree on a symbol boundary agree on the whole state.
+#include "ofk_internal.h"
+#include <string.h>
+#include <stdlib.h>
+
+#define JCH 256                 // entropy bytes per decoder thread
+#define JB0 4                   // a symbol belongs to chunk i if the byte cursor after the refill is in [i*JCH + JB0, (i+1)*JCH + JB0)
+#define JTPB 256                // decoder threads per workgroup (chunks of ONE image: the tables live in LDS)
+#define JMAX_ITERS 64           // flag slots; more iterations than this are read back one by one
+
+struct jpeg_tab {               // per image
+    uint16_t lut[6][512];       // slot = 2*component + (AC ? 1 : 0); 9-bit lookahead: (length << 8) | symbol, 0 = longer code
+    int32_t maxcode[6][18];     // largest code of length l (-1: none), [17] = INT_MAX
+    int32_t valoff[6][18];      // vals index of the first code of length l minus that code
+    uint8_t vals[6][256];
+    uint16_t q[3][64];          // natural order
+    uint32_t ent_off, ent_len;  // entropy segment inside the batch's entropy buffer
+    int32_t nch, pad;
+};
+
+struct jpeg_geom {
+    int w, h, ncomp, hmax, vmax, mcux, mcuy, bpm, nblk;
+    int blk_comp[10];           // component of block j of an MCU
+    int comp_off[3], comp_nb[3];
+    int pw[3], ph[3];           // plane sizes (whole MCUs)
+    size_t plane_off[3], plane_stride;   // bytes between images in the plane buffer
+};
+
+__constant__ uint8_t c_zz[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+                                 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+static const uint8_t h_zz[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+                                 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+// ------------------------------------------------------------------------------------------------ device: entropy decoder
+struct jrd { const uint8_t *d; uint32_t len, pos; uint64_t buf; int nb; int k, blk; };
+
+struct jlds {
+    uint16_t lut[6][512];
+    int32_t maxcode[6][18];
+    int32_t valoff[6][18];
+    uint8_t vals[6][256];
+};
+
+__device__ inline void jload_tables(jlds &T, const jpeg_tab *t)
+{
+    const uint32_t *src = (const uint32_t *)t;
+    uint32_t *dst = (uint32_t *)&T;
+    for (int i = threadIdx.x; i < (int)(sizeof(jlds) / 4); i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+}
+
+__device__ inline void jrefill(jrd &r)
+{
+    while (r.nb <= 24) {
+        uint32_t b = 0;
+        if (r.pos < r.len) {
+            b = r.d[r.pos];
+            if (b == 0xFF && r.pos + 1 < r.len && r.d[r.pos + 1] == 0) ++r.pos;      // stuffed zero
+        }
+        ++r.pos;                                                                     // past the end: virtual zero bytes
+        r.buf = (r.buf << 8) | b;
+        r.nb += 8;
+    }
+}
+
+// the nb unread bits in front of byte cursor pos (walks back over stuffed zeros)
+__device__ inline void jrebuild(jrd &r)
+{
+    uint64_t buf = 0;
+    int got = 0;
+    uint32_t p = r.pos;
+    while (got < r.nb && p > 0) {
+        --p;
+        uint32_t b = 0;
+        if (p < r.len) {
+            b = r.d[p];
+            if (b == 0 && p > 0 && r.d[p - 1] == 0xFF) { --p; b = 0xFF; }
+        }
+        buf |= (uint64_t)b << got;
+        got += 8;
+    }
+    r.buf = buf;
+}
+
+__device__ inline uint32_t jpeek(const jrd &r, int n) { return (uint32_t)(r.buf >> (r.nb - n)) & ((1u << n) - 1u); }
+__device__ inline int jextend(int v, int s) { return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; }
+
+__device__ inline uint64_t jpack(const jrd &r) { return ((uint64_t)r.pos << 32) | ((uint64_t)r.nb << 16) | ((uint64_t)r.k << 8) | (uint64_t)r.blk; }
+__device__ inline void junpack(jrd &r, uint64_t s) { r.pos = (uint32_t)(s >> 32); r.nb = (int)((s >> 16) & 63); r.k = (int)((s >> 8) & 63); r.blk = (int)(s & 15); }
+
+// Decodes symbols from a symbol boundary (reader refilled) until the byte cursor reaches `bnext` or `max_blocks` blocks are complete.
+// emit(block_in_progress_index, natural_position_or_zigzag_k, value) is called for every coefficient (DC as its difference).
+template <class Emit>
+__device__ inline int jrun(const jlds &T, jrd &r, uint32_t bnext, const jpeg_geom &g, int max_blocks, Emit emit)
+{
+    int done = 0;
+    while (r.pos < bnext && done < max_blocks) {
+        const int comp = g.blk_comp[r.blk];
+        const int slot = comp * 2 + (r.k ? 1 : 0);
+        int len, sym;
+        const uint32_t e = T.lut[slot][jpeek(r, 9)];
+        if (e) { len = e >> 8; sym = e & 255; }
+        else {
+            const int c16 = (int)jpeek(r, 16);
+            int l = 10;
+            while (l <= 16 && (c16 >> (16 - l)) > T.maxcode[slot][l]) ++l;
+            if (l > 16) { len = 16; sym = 0; }
+            else { len = l; sym = T.vals[slot][((c16 >> (16 - l)) + T.valoff[slot][l]) & 255]; }
+        }
+        r.nb -= len;
+        if (r.k == 0) {
+            const int s = sym & 15;
+            int v = 0;
+            if (s) { jrefill(r); v = jextend((int)jpeek(r, s), s); r.nb -= s; }
+            emit(done, 0, v);
+            r.k = 1;
+        } else {
+            const int run = sym >> 4, s = sym & 15;
+            if (s) {
+                r.k += run;
+                jrefill(r);
+                const int v = jextend((int)jpeek(r, s), s);
+                r.nb -= s;
+                if (r.k < 64) emit(done, r.k, v);
+                ++r.k;
+            } else if (run == 15) r.k += 16;
+            else r.k = 64;
+        }
+        if (r.k >= 64) { r.k = 0; r.blk = r.blk + 1 == g.bpm ? 0 : r.blk + 1; ++done; }
+        jrefill(r);
+    }
+    return done;
+}
+
+__device__ inline void jstart(jrd &r, uint32_t chunk)
+{   // chunk 0: the true start of the scan; otherwise the guess "a block starts at the first byte of the chunk"
+    r.pos = chunk * JCH; r.nb = 0; r.buf = 0; r.k = 0; r.blk = 0;
+    if (chunk && r.pos < r.len && r.d[r.pos] == 0 && r.d[r.pos - 1] == 0xFF) ++r.pos;
+    jrefill(r);
+}
+
+struct jemit_none { __device__ void operator()(int, int, int) const {} };
+
+__global__ __launch_bounds__(JTPB) void k_jpeg_sync(const jpeg_tab *__restrict__ tabs, const uint8_t *__restrict__ ent, jpeg_geom g, int nch_max,
+                                                    unsigned long long *__restrict__ state, unsigned long long *__restrict__ used,
+                                                    int *__restrict__ count, int iter, int *__restrict__ flags)
+{
+    __shared__ jlds T;
+    const int b = blockIdx.y;
+    const jpeg_tab *t = tabs + b;
+    if ((int)(blockIdx.x * JTPB) >= t->nch) return;
+    jload_tables(T, t);
+    const int i = blockIdx.x * JTPB + threadIdx.x;
+    if (i >= t->nch) return;
+    const size_t o = (size_t)b * nch_max + i;
+    jrd r;
+    r.d = ent + t->ent_off; r.len = t->ent_len;
+    unsigned long long e;
+    if (iter == 0 || i == 0) {
+        if (iter) return;                                         // chunk 0 started from the truth: nothing to revise
+        jstart(r, i);
+        e = jpack(r);
+    } else {
+        e = state[o - 1];
+        if (e == used[o]) return;
+        junpack(r, e);
+        jrebuild(r);
+    }
+    used[o] = e;
+    const int n = jrun(T, r, (uint32_t)(i + 1) * JCH + JB0, g, 0x7fffffff, jemit_none());
+    count[o] = n;
+    const unsigned long long x = jpack(r);
+    if (iter == 0) state[o] = x;
+    else if (x != state[o]) { state[o] = x; flags[iter < JMAX_ITERS ? iter : JMAX_ITERS - 1] = 1; }
+}
+
+// exclusive prefix sum of count[b][0..nch) -> base[b][...]; total in base[b][nch_max]
+__global__ __launch_bounds__(1024) void k_jpeg_scan(const jpeg_tab *__restrict__ tabs, int nch_max, const int *__restrict__ count, int *__restrict__ base)
+{
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    const int b = blockIdx.x, nch = tabs[b].nch;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < nch; i0 += 1024) {
+        const int i = i0 + threadIdx.x;
+        const int v = i < nch ? count[(size_t)b * nch_max + i] : 0;
+        int s = v;
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(s, d, 64); if (lane >= d) s += t; }
+        if (lane == 63) wsum[wv] = s;
+        __syncthreads();
+        int pre = carry;
+        for (int k = 0; k < wv; ++k) pre += wsum[k];
+        if (i < nch) base[(size_t)b * (nch_max + 1) + i] = pre + s - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = pre + s;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) base[(size_t)b * (nch_max + 1) + nch_max] = carry;
+}
+
+struct jemit_store {
+    int16_t *coef; int n0, nblk;
+    __device__ void operator()(int done, int k, int v) const
+    {
+        const int n = n0 + done;
+        if (n < nblk) coef[(size_t)n * 64 + c_zz[k]] = (int16_t)v;
+    }
+};
+
+__global__ __launch_bounds__(JTPB) void k_jpeg_write(const jpeg_tab *__restrict__ tabs, const uint8_t *__restrict__ ent, jpeg_geom g, int nch_max,
+                                                     const unsigned long long *__restrict__ state, const int *__restrict__ base,
+                                                     int16_t *__restrict__ coef, int *__restrict__ endinfo)
+{
+    __shared__ jlds T;
+    const int b = blockIdx.y;
+    const jpeg_tab *t = tabs + b;
+    if ((int)(blockIdx.x * JTPB) >= t->nch) return;
+    jload_tables(T, t);
+    const int i = blockIdx.x * JTPB + threadIdx.x;
+    if (i >= t->nch) return;
+    const int n0 = base[(size_t)b * (nch_max + 1) + i];
+    if (n0 >= g.nblk) return;
+    jrd r;
+    r.d = ent + t->ent_off; r.len = t->ent_len;
+    if (i == 0) jstart(r, 0);
+    else { junpack(r, state[(size_t)b * nch_max + i - 1]); jrebuild(r); }
+    jemit_store em = {coef + (size_t)b * g.nblk * 64, n0, g.nblk};
+    const int n = jrun(T, r, (uint32_t)(i + 1) * JCH + JB0, g, g.nblk - n0, em);
+    if (n0 + n == g.nblk && n > 0) {                              // this thread finished the last block: where the scan ended
+        endinfo[b * 2] = (int)(r.pos - (uint32_t)(r.nb >> 3));
+        endinfo[b * 2 + 1] = 1;
+    }
+}
+
+// DC prediction: inclusive prefix sum of the DC differences of one component in decode order (one workgroup per image x component)
+__global__ __launch_bounds__(1024) void k_jpeg_dc(jpeg_geom g, int16_t *__restrict__ coef)
+{
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    const int b = blockIdx.x, c = blockIdx.y;
+    const int nbc = g.comp_nb[c], off = g.comp_off[c];
+    const int total = g.mcux * g.mcuy * nbc;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int16_t *cf = coef + (size_t)b * g.nblk * 64;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int j0 = 0; j0 < total; j0 += 1024) {
+        const int j = j0 + threadIdx.x;
+        size_t n = 0;
+        int v = 0;
+        if (j < total) { n = (size_t)(j / nbc) * g.bpm + off + j % nbc; v = cf[n * 64]; }
+        int s = v;
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(s, d, 64); if (lane >= d) s += t; }
+        if (lane == 63) wsum[wv] = s;
+        __syncthreads();
+        int pre = carry;
+        for (int k = 0; k < wv; ++k) pre += wsum[k];
+        if (j < total) cf[n * 64] = (int16_t)(pre + s);
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = pre + s;
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ device: IDCT, upsampling, colour
+#define JFIX_0_298631336 2446
+#define JFIX_0_390180644 3196
+#define JFIX_0_541196100 4433
+#define JFIX_0_765366865 6270
+#define JFIX_0_899976223 7373
+#define JFIX_1_175875602 9633
+#define JFIX_1_501321110 12299
+#define JFIX_1_847759065 15137
+#define JFIX_1_961570560 16069
+#define JFIX_2_053119869 16819
+#define JFIX_2_562915447 20995
+#define JFIX_3_072711026 25172
+
+// one 8-point pass of libjpeg's jidctint.c (before the descale)
+__device__ inline void jidct8(const int *in, int *o)
+{
+    int z2 = in[2], z3 = in[6];
+    int z1 = (z2 + z3) * JFIX_0_541196100;
+    int tmp2 = z1 + z3 * (-JFIX_1_847759065);
+    int tmp3 = z1 + z2 * JFIX_0_765366865;
+    z2 = in[0]; z3 = in[4];
+    int tmp0 = (int)((unsigned)(z2 + z3) << 13);
+    int tmp1 = (int)((unsigned)(z2 - z3) << 13);
+    const int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    tmp0 = in[7]; tmp1 = in[5]; tmp2 = in[3]; tmp3 = in[1];
+    z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
+    int z4 = tmp1 + tmp3;
+    const int z5 = (z3 + z4) * JFIX_1_175875602;
+    tmp0 *= JFIX_0_298631336; tmp1 *= JFIX_2_053119869; tmp2 *= JFIX_3_072711026; tmp3 *= JFIX_1_501321110;
+    z1 *= -JFIX_0_899976223; z2 *= -JFIX_2_562915447; z3 *= -JFIX_1_961570560; z4 *= -JFIX_0_390180644;
+    z3 += z5; z4 += z5;
+    tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
+    o[0] = tmp10 + tmp3; o[7] = tmp10 - tmp3;
+    o[1] = tmp11 + tmp2; o[6] = tmp11 - tmp2;
+    o[2] = tmp12 + tmp1; o[5] = tmp12 - tmp1;
+    o[3] = tmp13 + tmp0; o[4] = tmp13 - tmp0;
+}
+
+__device__ inline uint32_t jrange_limit(int x)
+{   // jdmaster.c prepare_range_limit_table, post-IDCT half, index x & 1023
+    const int i = x & 1023;
+    return (uint32_t)(i < 128 ? i + 128 : i < 512 ? 255 : i < 896 ? 0 : i - 896);
+}
+
+// 8 lanes per block, 32 blocks per workgroup
+__global__ __launch_bounds__(256) void k_jpeg_idct(const jpeg_tab *__restrict__ tabs, jpeg_geom g, const int16_t *__restrict__ coef,
+                                                   uint8_t *__restrict__ planes)
+{
+    __shared__ int ws[32][72];
+    const int b = blockIdx.y;
+    const int lb = threadIdx.x >> 3, c = threadIdx.x & 7;
+    const int n = blockIdx.x * 32 + lb;
+    const bool live = n < g.nblk;
+    int comp = 0, bx = 0, by = 0;
+    if (live) {
+        const int m = n / g.bpm, j = n % g.bpm;
+        comp = g.blk_comp[j];
+        const int jj = j - g.comp_off[comp];
+        const int hs = comp == 0 ? g.hmax : 1;
+        bx = (m % g.mcux) * hs + jj % hs;
+        by = (m / g.mcux) * (comp == 0 ? g.vmax : 1) + jj / hs;
+        const int16_t *cf = coef + ((size_t)b * g.nblk + n) * 64;
+        const uint16_t *q = tabs[b].q[comp];
+        int in[8], o[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) in[r] = (int)cf[r * 8 + c] * (int)q[r * 8 + c];
+        jidct8(in, o);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) ws[lb][r * 9 + c] = (o[r] + (1 << 10)) >> 11;
+    }
+    __syncthreads();
+    if (live) {
+        int in[8], o[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) in[k] = ws[lb][c * 9 + k];                    // this lane's row = c
+        jidct8(in, o);
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            lo |= jrange_limit((o[k] + (1 << 17)) >> 18) << (8 * k);
+            hi |= jrange_limit((o[k + 4] + (1 << 17)) >> 18) << (8 * k);
+        }
+        uint8_t *pl = planes + (size_t)b * g.plane_stride + g.plane_off[comp];
+        uint2 *dst = (uint2 *)(pl + (size_t)(by * 8 + c) * g.pw[comp] + bx * 8);
+        *dst = make_uint2(lo, hi);
+    }
+}
+
+__device__ inline int jclamp8(int x) { return x < 0 ? 0 : x > 255 ? 255 : x; }
+
+// chroma sample for output pixel (x, y) with libjpeg's fancy upsampling
+__device__ inline int jchroma(const uint8_t *__restrict__ pl, int pitch, int cw, int ch, int hmax, int vmax, int x, int y)
+{
+    if (hmax == 1) return pl[(size_t)y * pitch + x];
+    const int cx = x >> 1;
+    if (vmax == 1) {                                              // h2v1_fancy_upsample
+        const uint8_t *in = pl + (size_t)y * pitch;
+        const int v = in[cx];
+        if (x & 1) return cx == cw - 1 ? v : (v * 3 + in[cx + 1] + 2) >> 2;
+        return cx == 0 ? v : (v * 3 + in[cx - 1] + 1) >> 2;
+    }
+    const int r0 = y >> 1;                                        // h2v2_fancy_upsample
+    int r1 = (y & 1) ? r0 + 1 : r0 - 1;
+    r1 = r1 < 0 ? 0 : r1 > ch - 1 ? ch - 1 : r1;
+    const uint8_t *i0 = pl + (size_t)r0 * pitch, *i1 = pl + (size_t)r1 * pitch;
+    const int t = i0[cx] * 3 + i1[cx];
+    if (x & 1) return cx == cw - 1 ? (t * 4 + 7) >> 4 : (t * 3 + i0[cx + 1] * 3 + i1[cx + 1] + 7) >> 4;
+    return cx == 0 ? (t * 4 + 8) >> 4 : (t * 3 + i0[cx - 1] * 3 + i1[cx - 1] + 8) >> 4;
+}
+
+__global__ __launch_bounds__(256) void k_jpeg_color(jpeg_geom g, const uint8_t *__restrict__ planes, uint8_t *__restrict__ bgr, size_t bgr_stride)
+{
+    const int b = blockIdx.z;
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= g.w) return;
+    const uint8_t *pl = planes + (size_t)b * g.plane_stride;
+    uint8_t *o = bgr + (size_t)b * bgr_stride + ((size_t)y * g.w + x) * 3;
+    const int Y = pl[g.plane_off[0] + (size_t)y * g.pw[0] + x];
+    if (g.ncomp == 1) { o[0] = o[1] = o[2] = (uint8_t)Y; return; }
+    const int cw = (g.w + g.hmax - 1) / g.hmax, ch = (g.h + g.vmax - 1) / g.vmax;
+    const int cb = jchroma(pl + g.plane_off[1], g.pw[1], cw, ch, g.hmax, g.vmax, x, y) - 128;
+    const int cr = jchroma(pl + g.plane_off[2], g.pw[2], cw, ch, g.hmax, g.vmax, x, y) - 128;
+    // jdcolor.c build_ycc_rgb_table: SCALEBITS 16, FIX(1.40200) = 91881, FIX(1.77200) = 116130, FIX(0.71414) = 46802, FIX(0.34414) = 22554
+    o[0] = (uint8_t)jclamp8(Y + ((116130 * cb + 32768) >> 16));
+    o[1] = (uint8_t)jclamp8(Y + ((-22554 * cb + 32768 - 46802 * cr) >> 16));
+    o[2] = (uint8_t)jclamp8(Y + ((91881 * cr + 32768) >> 16));
+}
+
+// ------------------------------------------------------------------------------------------------ host: marker segments
+struct jhost {
+    int w, h, ncomp, hs[3], vs[3], tq[3], td[3], ta[3];
+    uint16_t q[4][64]; int qok[4];
+    uint8_t bits[2][4][17], vals[2][4][256]; int hok[2][4];
+    const uint8_t *ent; size_t ent_len;
+};
+
+static const char *jparse(const uint8_t *d, size_t n, jhost *j)
+{
+    memset(j, 0, sizeof *j);
+    if (!d || n < 4 || d[0] != 0xFF || d[1] != 0xD8) return "not a JPEG stream (no SOI)";
+    size_t i = 2;
+    bool sof = false;
+    while (i + 4 <= n) {
+        if (d[i] != 0xFF) return "marker expected";
+        while (i < n && d[i] == 0xFF) ++i;
+        if (i >= n) break;
+        const int m = d[i++];
+        if (m == 0xD8 || (m >= 0xD0 && m <= 0xD7) || m == 0x01) continue;
+        if (m == 0xD9) return "EOI before the scan";
+        if (i + 2 > n) break;
+        const size_t L = ((size_t)d[i] << 8) | d[i + 1];
+        if (L < 2 || i + L > n) return "truncated marker segment";
+        const uint8_t *s = d + i + 2;
+        const size_t sl = L - 2;
+        if (m == 0xDB) {
+            size_t k = 0;
+            while (k < sl) {
+                const int pq = s[k] >> 4, tq = s[k] & 15;
+                ++k;
+                if (tq > 3 || pq > 1 || k + (pq ? 128 : 64) > sl) return "bad DQT";
+                for (int z = 0; z < 64; ++z) { j->q[tq][h_zz[z]] = pq ? (uint16_t)((s[k] << 8) | s[k + 1]) : s[k]; k += pq ? 2 : 1; }
+                j->qok[tq] = 1;
+            }
+        } else if (m == 0xC4) {
+            size_t k = 0;
+            while (k + 17 <= sl) {
+                const int tc = s[k] >> 4, th = s[k] & 15;
+                ++k;
+                if (tc > 1 || th > 3) return "bad DHT";
+                int cnt = 0;
+                j->bits[tc][th][0] = 0;
+                for (int l = 1; l <= 16; ++l) { j->bits[tc][th][l] = s[k++]; cnt += j->bits[tc][th][l]; }
+                if (cnt > 256 || k + cnt > sl) return "bad DHT";
+                memcpy(j->vals[tc][th], s + k, cnt);
+                k += cnt;
+                j->hok[tc][th] = 1;
+            }
+        } else if (m == 0xC0 || m == 0xC1) {
+            if (sl < 6 || s[0] != 8) return "only 8-bit samples are supported";
+            j->h = (s[1] << 8) | s[2]; j->w = (s[3] << 8) | s[4]; j->ncomp = s[5];
+            if ((j->ncomp != 1 && j->ncomp != 3) || sl < 6 + 3 * (size_t)j->ncomp || j->h < 1 || j->w < 1) return "unsupported frame header";
+            for (int c = 0; c < j->ncomp; ++c) {
+                j->hs[c] = s[7 + 3 * c] >> 4; j->vs[c] = s[7 + 3 * c] & 15; j->tq[c] = s[8 + 3 * c];
+                if (j->tq[c] > 3) return "bad quantisation table index";
+            }
+            sof = true;
+        } else if (m >= 0xC2 && m <= 0xCF && m != 0xC8 && m != 0xCC) {
+            return "only baseline / extended-sequential Huffman JPEG is supported (progressive, lossless and arithmetic coding are not)";
+        } else if (m == 0xDD) {
+            if (sl < 2 || ((s[0] << 8) | s[1]) != 0) return "restart intervals are not supported";
+        } else if (m == 0xDA) {
+            if (!sof || sl < 1 || s[0] != j->ncomp || sl < 4 + 2 * (size_t)j->ncomp) return "unsupported scan header (one interleaved scan expected)";
+            for (int c = 0; c < j->ncomp; ++c) {
+                j->td[c] = s[2 + 2 * c] >> 4; j->ta[c] = s[2 + 2 * c] & 15;
+                if (j->td[c] > 3 || j->ta[c] > 3) return "bad Huffman table index";
+            }
+            const size_t e0 = i + L;
+            size_t e = e0;
+            while (e < n) {                                       // up to the next marker (FF followed by anything but a stuffed zero)
+                const uint8_t *f = (const uint8_t *)memchr(d + e, 0xFF, n - e);
+                if (!f) { e = n; break; }
+                e = (size_t)(f - d);
+                if (e + 1 >= n) { e = n; break; }
+                if (d[e + 1] != 0x00) break;
+                e += 2;
+            }
+            j->ent = d + e0; j->ent_len = e - e0;
+            break;
+        }
+        i += L;
+    }
+    if (!j->ent) return "no scan found";
+    if (j->ncomp == 1) j->hs[0] = j->vs[0] = 1;
+    else {
+        if (j->hs[1] != 1 || j->vs[1] != 1 || j->hs[2] != 1 || j->vs[2] != 1) return "unsupported chroma sampling";
+        if (!((j->hs[0] == 1 && j->vs[0] == 1) || (j->hs[0] == 2 && j->vs[0] == 1) || (j->hs[0] == 2 && j->vs[0] == 2)))
+            return "unsupported luma sampling (4:4:4, 4:2:2 and 4:2:0 are supported)";
+    }
+    for (int c = 0; c < j->ncomp; ++c)
+        if (!j->qok[j->tq[c]] || !j->hok[0][j->td[c]] || !j->hok[1][j->ta[c]]) return "a table the scan refers to is missing";
+    if (j->ent_len >= (1ull << 31)) return "entropy segment too long";
+    return nullptr;
+}
+
+static void jbuild_slot(jpeg_tab *t, int slot, const uint8_t *bits, const uint8_t *vals)
+{   // T.81 Annex C code assignment; 9-bit lookahead like jdhuff.c's (there: 8 bits)
+    memset(t->lut[slot], 0, sizeof t->lut[slot]);
+    memcpy(t->vals[slot], vals, 256);
+    int code = 0, p = 0;
+    for (int l = 1; l <= 16; ++l) {
+        t->valoff[slot][l] = p - code;
+        for (int k = 0; k < bits[l]; ++k, ++p, ++code)
+            if (l <= 9) {
+                const int lo = code << (9 - l);
+                for (int f = 0; f < (1 << (9 - l)) && lo + f < 512; ++f) t->lut[slot][lo + f] = (uint16_t)((l << 8) | vals[p & 255]);
+            }
+        t->maxcode[slot][l] = bits[l] ? code - 1 : -1;
+        code <<= 1;
+    }
+    t->maxcode[slot][0] = -1; t->maxcode[slot][17] = 0x7fffffff;
+    t->valoff[slot][0] = t->valoff[slot][17] = 0;
+}
+
+static jpeg_geom jgeom(const jhost &j)
+{
+    jpeg_geom g;
+    memset(&g, 0, sizeof g);
+    g.w = j.w; g.h = j.h; g.ncomp = j.ncomp; g.hmax = j.hs[0]; g.vmax = j.vs[0];
+    g.mcux = (j.w + 8 * g.hmax - 1) / (8 * g.hmax); g.mcuy = (j.h + 8 * g.vmax - 1) / (8 * g.vmax);
+    int off = 0;
+    size_t po = 0;
+    for (int c = 0; c < j.ncomp; ++c) {
+        g.comp_off[c] = off; g.comp_nb[c] = j.hs[c] * j.vs[c];
+        for (int k = 0; k < g.comp_nb[c]; ++k) g.blk_comp[off + k] = c;
+        off += g.comp_nb[c];
+        g.pw[c] = g.mcux * j.hs[c] * 8; g.ph[c] = g.mcuy * j.vs[c] * 8;
+        g.plane_off[c] = po;
+        po += ((size_t)g.pw[c] * g.ph[c] + 255) & ~(size_t)255;
+    }
+    g.bpm = off; g.nblk = g.mcux * g.mcuy * g.bpm;
+    g.plane_stride = po;
+    return g;
+}
+
+extern "C" int ofk_jpeg_info(const uint8_t *jpeg, size_t nbytes, int *h, int *w, int *components)
+{
+    jhost j;
+    if (jparse(jpeg, nbytes, &j)) return OFK_E_INVALID;
+    if (h) *h = j.h;
+    if (w) *w = j.w;
+    if (components) *components = j.ncomp;
+    return OFK_OK;
+}
+
+static size_t jup(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Decodes `batch` streams of one geometry into dst (device, [batch][dst_stride] BGR8), or, with dst == NULL, into the context's
+// scratch (*out / *out_stride tell where).  Synchronous on the context's stream.
+int ofk_jpeg_decode_device(ofk_ctx *c, const uint8_t *const *jpeg, const size_t *nbytes, int batch, uint8_t *dst, size_t dst_stride,
+                           size_t dst_capacity_px, int *h_out, int *w_out, uint8_t **out, size_t *out_stride)
+{
+    if (!jpeg || !nbytes || batch < 1) return ofk_fail(c, OFK_E_INVALID, "ofk_jpeg: bad argument");
+    jhost *jh = (jhost *)malloc(sizeof(jhost) * (size_t)batch);
+    if (!jh) return ofk_fail(c, OFK_E_INVALID, "ofk_jpeg: out of host memory");
+    size_t ent_total = 0;
+    int nch_max = 1;
+    for (int b = 0; b < batch; ++b) {
+        const char *err = jparse(jpeg[b], nbytes[b], &jh[b]);
+        if (err) { const int rc = ofk_fail(c, OFK_E_INVALID, "ofk_jpeg: stream %d: %s", b, err); free(jh); return rc; }
+        if (b && (jh[b].w != jh[0].w || jh[b].h != jh[0].h || jh[b].ncomp != jh[0].ncomp || jh[b].hs[0] != jh[0].hs[0] || jh[b].vs[0] != jh[0].vs[0])) {
+            const int rc = ofk_fail(c, OFK_E_INVALID, "ofk_jpeg: stream %d differs in size or sampling from stream 0 (one geometry per batch)", b);
+            free(jh); return rc;
+        }
+        ent_total += jup(jh[b].ent_len + 16, JCH);
+        const int nch = (int)((jh[b].ent_len + JB0) / JCH) + 1;
+        if (nch > nch_max) nch_max = nch;
+    }
+    const jpeg_geom g = jgeom(jh[0]);
+    if (dst && (size_t)g.w * g.h > dst_capacity_px) { const int rc = ofk_fail(c, OFK_E_INVALID, "ofk_jpeg: %dx%d frames exceed the destination", g.w, g.h); free(jh); return rc; }
+    // pinned staging: tables + entropy segments, one H2D copy
+    const size_t tab_bytes = jup(sizeof(jpeg_tab) * (size_t)batch, 256);
+    const size_t stage = tab_bytes + ent_total;
+    if (c->hstage_bytes < stage) {
+        if (c->hstage) { hipHostFree(c->hstage); c->hstage = nullptr; c->hstage_bytes = 0; }
+        if (hipHostMalloc(&c->hstage, jup(stage, 1 << 20), hipHostMallocDefault) != hipSuccess) { free(jh); return ofk_fail(c, OFK_E_HIP, "ofk_jpeg: pinned staging allocation failed"); }
+        c->hstage_bytes = jup(stage, 1 << 20);
+    }
+    jpeg_tab *ht = (jpeg_tab *)c->hstage;
+    uint8_t *hent = (uint8_t *)c->hstage + tab_bytes;
+    size_t eo = 0;
+    for (int b = 0; b < batch; ++b) {
+        const jhost &j = jh[b];
+        jpeg_tab *t = ht + b;
+        for (int cc = 0; cc < 3; ++cc) {
+            const int cs = cc < j.ncomp ? cc : 0;
+            jbuild_slot(t, 2 * cc, j.bits[0][j.td[cs]], j.vals[0][j.td[cs]]);
+            jbuild_slot(t, 2 * cc + 1, j.bits[1][j.ta[cs]], j.vals[1][j.ta[cs]]);
+            memcpy(t->q[cc], j.q[j.tq[cs]], 128);
+        }
+        t->ent_off = (uint32_t)eo; t->ent_len = (uint32_t)j.ent_len;
+        t->nch = (int)((j.ent_len + JB0) / JCH) + 1; t->pad = 0;
+        memcpy(hent + eo, j.ent, j.ent_len);
+        const size_t padded = jup(j.ent_len + 16, JCH);
+        memset(hent + eo + j.ent_len, 0, padded - j.ent_len);
+        eo += padded;
+    }
+    free(jh);
+    if (ent_total >= (1ull << 32)) return ofk_fail(c, OFK_E_INVALID, "ofk_jpeg: more than 4 GiB of entropy data in one batch");
+    // device scratch
+    const size_t B = (size_t)batch;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += jup(bytes, 256); return o; };
+    const size_t o_stage = take(stage), o_state = take(B * nch_max * 8), o_used = take(B * nch_max * 8), o_count = take(B * nch_max * 4),
+                 o_base = take(B * (nch_max + 1) * 4), o_flags = take(JMAX_ITERS * 4 + B * 8), o_coef = take(B * g.nblk * 128),
+                 o_planes = take(B * g.plane_stride);
+    const size_t own_stride = jup((size_t)g.w * g.h * 3, 256);
+    const size_t o_out = dst ? 0 : take(B * own_stride);
+    const int rc = ofk_need_scratch(c, off);
+    if (rc != OFK_OK) return rc;
+    char *S = (char *)c->scratch;
+    if (!dst) { dst = (uint8_t *)(S + o_out); dst_stride = own_stride; }
+    if (out) *out = dst;
+    if (out_stride) *out_stride = dst_stride;
+    const jpeg_tab *dt = (const jpeg_tab *)(S + o_stage);
+    const uint8_t *dent = (const uint8_t *)(S + o_stage + tab_bytes);
+    unsigned long long *state = (unsigned long long *)(S + o_state), *used = (unsigned long long *)(S + o_used);
+    int *count = (int *)(S + o_count), *base = (int *)(S + o_base), *flags = (int *)(S + o_flags), *endinfo = flags + JMAX_ITERS;
+    int16_t *coef = (int16_t *)(S + o_coef);
+    uint8_t *planes = (uint8_t *)(S + o_planes);
+    hipStream_t st = c->stream;
+    OFK_HIP(c, hipMemcpyAsync(S + o_stage, c->hstage, stage, hipMemcpyHostToDevice, st));
+    OFK_HIP(c, hipMemsetAsync(flags, 0, JMAX_ITERS * 4 + B * 8, st));
+    OFK_HIP(c, hipMemsetAsync(coef, 0, B * g.nblk * 128, st));
+    const dim3 dgrid((nch_max + JTPB - 1) / JTPB, batch);
+    int hflags[JMAX_ITERS];
+    int iter = 0;
+    hipLaunchKernelGGL(k_jpeg_sync, dgrid, dim3(JTPB), 0, st, dt, dent, g, nch_max, state, used, count, iter, flags);
+    bool converged = nch_max == 1;
+    while (!converged) {
+        const int first = iter + 1;
+        const int burst = iter == 0 ? 3 : 1;                      // two iterations settle almost every stream, the third proves it
+        for (int k = 0; k < burst; ++k) {
+            ++iter;
+            if (iter >= JMAX_ITERS) OFK_HIP(c, hipMemsetAsync(flags + JMAX_ITERS - 1, 0, 4, st));
+            hipLaunchKernelGGL(k_jpeg_sync, dgrid, dim3(JTPB), 0, st, dt, dent, g, nch_max, state, used, count, iter, flags);
+        }
+        OFK_HIP(c, hipMemcpyAsync(hflags, flags, sizeof hflags, hipMemcpyDeviceToHost, st));
+        OFK_HIP(c, hipStreamSynchronize(st));
+        for (int k = first; k <= iter; ++k)
+            if (!hflags[k < JMAX_ITERS ? k : JMAX_ITERS - 1]) converged = true;
+        if (!converged && iter > nch_max + 2) return ofk_fail(c, OFK_E_INVALID, "ofk_jpeg: entropy decoders did not converge");
+    }
+    hipLaunchKernelGGL(k_jpeg_scan, dim3(batch), dim3(1024), 0, st, dt, nch_max, count, base);
+    hipLaunchKernelGGL(k_jpeg_write, dgrid, dim3(JTPB), 0, st, dt, dent, g, nch_max, state, base, coef, endinfo);
+    hipLaunchKernelGGL(k_jpeg_dc, dim3(batch, g.ncomp), dim3(1024), 0, st, g, coef);
+    hipLaunchKernelGGL(k_jpeg_idct, dim3((g.nblk + 31) / 32, batch), dim3(256), 0, st, dt, g, coef, planes);
+    hipLaunchKernelGGL(k_jpeg_color, dim3((g.w + 255) / 256, g.h, batch), dim3(256), 0, st, g, planes, dst, dst_stride);
+    int *hend = (int *)malloc(B * 8);
+    if (!hend) return ofk_fail(c, OFK_E_INVALID, "ofk_jpeg: out of host memory");
+    hipError_t e = hipMemcpyAsync(hend, endinfo, B * 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) { free(hend); return ofk_fail(c, OFK_E_HIP, "ofk_jpeg: %s", hipGetErrorString(e)); }
+    for (int b = 0; b < batch; ++b)
+        if (!hend[2 * b + 1]) { free(hend); return ofk_fail(c, OFK_E_INVALID, "ofk_jpeg: stream %d: entropy data ends before the last block (truncated or corrupt)", b); }
+    free(hend);
+    if (h_out) *h_out = g.h;
+    if (w_out) *w_out = g.w;
+    return OFK_OK;
+}

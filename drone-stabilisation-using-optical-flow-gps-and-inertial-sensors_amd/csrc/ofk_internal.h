@@ -82,6 +82,9 @@ int ofk_fail(ofk_ctx *ctx, int code, const char *fmt, ...);
     } while (0)
 ofk_levels ofk_make_levels(int h, int w, int win, int max_level);   // win <= 0: ignore the winSize stop rule
 int ofk_need_scratch(ofk_ctx *ctx, size_t bytes);
+void ofk_join_slices(ofk_ctx *ctx);                                   // before touching the context's stream / shared buffers
+int ofk_jpeg_decode_device(ofk_ctx *c, const uint8_t *const *jpeg, const size_t *nbytes, int batch, uint8_t *dst, size_t dst_stride,
+                           size_t dst_capacity_px, int *h_out, int *w_out, uint8_t **out, size_t *out_stride);   // k_jpeg.hip
 
 // --- launchers (all asynchronous on `s`; pointers are device pointers)
 void ofk_launch_gray(hipStream_t s, const uint8_t *bgr, size_t bgr_stride, uint8_t *gray, size_t gray_stride, int batch,

@@ -29,6 +29,24 @@ def cvtColor(src, code):
     return ofk.default_context(w, h).gray_bgr8(src)
 
 
+IMREAD_UNCHANGED, IMREAD_GRAYSCALE, IMREAD_COLOR = -1, 0, 1
+
+
+def imdecode(buf, flags=IMREAD_COLOR):
+    """cv2.imdecode for baseline JPEG streams (what cv_bridge.compressed_imgmsg_to_cv2 calls for the reference's CompressedImage
+    callback, velocity_measurment_node.py:112), decoded on the GPU.  IMREAD_COLOR: HxWx3 BGR; IMREAD_UNCHANGED: HxW for gray
+    streams, HxWx3 otherwise.  Returns None - like OpenCV - if the buffer is not a stream the decoder supports."""
+    if flags not in (IMREAD_COLOR, IMREAD_UNCHANGED):
+        raise NotImplementedError("imdecode: IMREAD_COLOR and IMREAD_UNCHANGED only (gray conversion is cvtColor's job on this path)")
+    data = np.asarray(buf, dtype=np.uint8).tobytes() if not isinstance(buf, (bytes, bytearray, memoryview)) else bytes(buf)
+    try:
+        h, w, ncomp = ofk.jpeg_info(data)
+    except ofk.OfkError:
+        return None
+    img = ofk.default_context(w, h).jpeg_decode([data])[0]
+    return np.ascontiguousarray(img[:, :, 0]) if (ncomp == 1 and flags == IMREAD_UNCHANGED) else img
+
+
 def goodFeaturesToTrack(image, maxCorners, qualityLevel, minDistance, corners=None, mask=None, blockSize=3,
                         useHarrisDetector=False, k=0.04):
     if useHarrisDetector:

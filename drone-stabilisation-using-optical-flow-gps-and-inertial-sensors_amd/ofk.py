@@ -25,7 +25,7 @@ SYMBOLS = (
     "ofk_version", "ofk_last_error", "ofk_device_count", "ofk_create", "ofk_destroy", "ofk_sync", "ofk_device_sync",
     "ofk_gray_bgr8", "ofk_pyr_down_u8", "ofk_scharr_s16", "ofk_mineig_response", "ofk_select_corners",
     "ofk_good_features", "ofk_lk_pyr", "ofk_flow_model", "ofk_feasibility", "ofk_velocity_solve", "ofk_imu_propagate",
-    "ofk_post_solve", "ofk_kf_predict_update", "ofk_of_simulation", "ofk_associate_sensors", "ofk_feature_eval", "ofk_d_split", "ofk_pairs_upload", "ofk_pairs_set_sensors",
+    "ofk_post_solve", "ofk_kf_predict_update", "ofk_of_simulation", "ofk_associate_sensors", "ofk_feature_eval", "ofk_d_split", "ofk_pairs_upload", "ofk_pairs_upload_jpeg", "ofk_jpeg_info", "ofk_jpeg_decode_bgr8", "ofk_pairs_set_sensors",
     "ofk_pairs_run", "ofk_pairs_download", "ofk_pairs_export_records_f32", "ofk_stream_begin", "ofk_stream_step",
     "ofk_set_streams", "ofk_set_overlap", "ofk_mark", "ofk_mark_wait", "ofk_profile_enable", "ofk_profile_read",
 )
@@ -45,6 +45,17 @@ class Params(C.Structure):
 
 _lib = None
 _lib_lock = threading.Lock()
+
+
+def jpeg_info(stream):
+    """(h, w, components) of a JPEG stream the device decoder accepts; OfkError otherwise (host-side header parse)."""
+    data = bytes(stream)
+    h, w, n = C.c_int(), C.c_int(), C.c_int()
+    rc = load_library().ofk_jpeg_info(data, len(data), C.byref(h), C.byref(w), C.byref(n))
+    if rc != 0:
+        raise OfkError(rc, "not a JPEG stream the decoder supports (8-bit baseline Huffman, gray or YCbCr 4:4:4/4:2:2/4:2:0, "
+                           "no restart intervals)")
+    return h.value, w.value, n.value
 
 
 def load_library():
@@ -85,6 +96,9 @@ def load_library():
         L.ofk_kf_predict_update.argtypes = [vp, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i]
         L.ofk_of_simulation.argtypes = [vp, vp, vp, vp, vp, i, vp, i, vp, vp]
         L.ofk_pairs_upload.argtypes = [vp, vp, vp, i, i, i]
+        L.ofk_pairs_upload_jpeg.argtypes = [vp, vp, vp, vp, vp, i]
+        L.ofk_jpeg_info.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
+        L.ofk_jpeg_decode_bgr8.argtypes = [vp, vp, vp, i, vp]
         L.ofk_pairs_set_sensors.argtypes = [vp, vp, i]
         L.ofk_pairs_run.argtypes = [vp, C.POINTER(Params)]
         L.ofk_pairs_download.argtypes = [vp, vp, vp, vp, vp, vp, vp]
@@ -417,6 +431,35 @@ class Context:
         with self._lock:
             self._ck(self._L.ofk_pairs_upload(self._h, _p(prev_bgr), _p(next_bgr), B, h, w))
         self._resident = (B, h, w)
+
+    @staticmethod
+    def _jpeg_args(streams):
+        bufs = [bytes(s) for s in streams]
+        ptrs = (C.c_char_p * len(bufs))(*bufs)
+        sizes = (C.c_size_t * len(bufs))(*[len(b) for b in bufs])
+        return bufs, ptrs, sizes
+
+    def pairs_upload_jpeg(self, prev_streams, next_streams):
+        """Resident frame pairs from baseline JPEG streams (CompressedImage payloads), decoded on the device."""
+        if len(prev_streams) != len(next_streams) or not len(prev_streams):
+            raise ValueError("expected two equally long, non-empty lists of JPEG streams")
+        h, w, _ = jpeg_info(prev_streams[0])
+        keep0, p0, s0 = self._jpeg_args(prev_streams)
+        keep1, p1, s1 = self._jpeg_args(next_streams)
+        with self._lock:
+            self._ck(self._L.ofk_pairs_upload_jpeg(self._h, p0, s0, p1, s1, len(keep0)))
+        self._resident = (len(keep0), h, w)
+
+    def jpeg_decode(self, streams):
+        """[B,h,w,3] BGR uint8 from B baseline JPEG streams of one size and sampling (cv2.imdecode, batched)."""
+        if not len(streams):
+            raise ValueError("no streams")
+        h, w, _ = jpeg_info(streams[0])
+        keep, ptrs, sizes = self._jpeg_args(streams)
+        out = np.empty((len(keep), h, w, 3), np.uint8)
+        with self._lock:
+            self._ck(self._L.ofk_jpeg_decode_bgr8(self._h, ptrs, sizes, len(keep), _p(out)))
+        return out
 
     def pairs_set_sensors(self, sensors):
         s = _arr(sensors, np.float64).reshape(-1, SENSOR_DOUBLES)

@@ -92,6 +92,11 @@ class FlowPipeline:
         self.ctx.pairs_upload(prev_bgr, next_bgr)
         self.ctx.pairs_set_sensors(sensors)
 
+    def upload_jpeg(self, prev_streams, next_streams, sensors):
+        """The same from baseline JPEG streams (CompressedImage payloads): decoded on the device, 15-20x less PCIe traffic."""
+        self.ctx.pairs_upload_jpeg(prev_streams, next_streams)
+        self.ctx.pairs_set_sensors(sensors)
+
     def run_async(self):
         self.ctx.pairs_run(self._params)
 

@@ -25,6 +25,7 @@
 #ifndef OFK_H
 #define OFK_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -198,6 +199,12 @@ typedef struct ofk_params {
 
 /* Copies a batch of BGR frame pairs into the context's device buffers (host -> HBM). */
 int ofk_pairs_upload(ofk_ctx *ctx, const uint8_t *prev_bgr, const uint8_t *next_bgr, int batch, int h, int w);
+/* The same from compressed frames: jpeg[i] / nbytes[i] = one baseline JPEG stream per frame (the payload of a
+ * sensor_msgs/CompressedImage; the reference decodes it with cv_bridge.compressed_imgmsg_to_cv2 = cv::imdecode,
+ * velocity_measurment_node.py:112).  All frames of a call must share size and chroma sampling.  Decoded on the device straight
+ * into the resident buffers; pixels identical to libjpeg's default decompressor (see ofk_jpeg_decode_bgr8). */
+int ofk_pairs_upload_jpeg(ofk_ctx *ctx, const uint8_t *const *prev_jpeg, const size_t *prev_bytes, const uint8_t *const *next_jpeg,
+                          const size_t *next_bytes, int batch);
 int ofk_pairs_set_sensors(ofk_ctx *ctx, const double *sensors, int batch);
 /* Runs gray -> pyramids -> corners -> LK -> centre/scale -> (feasibility) -> solve -> post-solve for every resident
  * pair.  Asynchronous on the context's stream; call ofk_sync / ofk_pairs_download to wait. */
@@ -226,6 +233,17 @@ int ofk_stream_begin(ofk_ctx *ctx, const uint8_t *first_bgr, int batch, int h, i
                      int *counts);
 int ofk_stream_step(ofk_ctx *ctx, const uint8_t *next_bgr, const double *sensors, const ofk_params *p, int min_features,
                     int mask_radius, double *records, float *tracks, int *counts);
+
+/* ---- compressed-image ingest (cv2.imdecode of the reference's CompressedImage callback, velocity_measurment_node.py:112) ----
+ * ofk_jpeg_info: header fields of a JPEG stream (host only; no context, no GPU).  OFK_E_INVALID if the stream is not one the decoder
+ * accepts: 8-bit baseline / extended-sequential Huffman, one interleaved scan, gray or YCbCr 4:4:4 / 4:2:2 / 4:2:0, no restart
+ * intervals.
+ * ofk_jpeg_decode_bgr8: decodes `batch` streams of equal size and sampling on the device into bgr [batch][h][w][3] (host; gray
+ * streams are replicated over the three channels like cv2.IMREAD_COLOR).  Bit-identical to libjpeg's default decompressor (ISLOW
+ * IDCT, fancy upsampling) - what cv::imdecode returns.  Entropy decoding runs on the GPU too (self-synchronising chunked Huffman
+ * decoders); truncated or corrupt entropy data is an error, not a partially grey picture. */
+int ofk_jpeg_info(const uint8_t *jpeg, size_t nbytes, int *h, int *w, int *components);
+int ofk_jpeg_decode_bgr8(ofk_ctx *ctx, const uint8_t *const *jpeg, const size_t *nbytes, int batch, uint8_t *bgr);
 
 /* Number of concurrent slices ofk_pairs_run cuts the batch into (1..8, default 1): each slice runs the whole stage chain on
  * its own HIP stream so that latency-bound stages overlap with streaming ones; results do not depend on it.  With more than

@@ -19,8 +19,8 @@ i16p = np.ctypeslib.ndpointer(np.int16, flags="C_CONTIGUOUS")
 
 
 def build():
-    src = os.path.join(_HERE, "image_oracle.c")
-    if not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("image_oracle.c", "jpeg_oracle.c")]
+    if not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
 

@@ -1,0 +1,132 @@
+"""Compressed-image ingest (reference: cv_bridge.compressed_imgmsg_to_cv2 = cv::imdecode = libjpeg,
+velocity_measurment_node.py:112).  The golden fixture holds JPEG streams with the pixels libjpeg-turbo's default decompressor
+returned for them (tests/golden/make_golden_jpeg.py); the oracle restatement and the device decoder must both reproduce them bit
+for bit.  Larger streams are encoded with Pillow when it is importable (an encoder is not part of this repo) and checked against
+the oracle."""
+import io
+import os
+
+import numpy as np
+import pytest
+
+from oracle import jpeg_oracle as jo
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jpeg_golden.npz")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD)
+
+
+def names(gold):
+    return [str(n) for n in gold["names"]]
+
+
+# ------------------------------------------------------------------------------------------------ CPU: oracle, host parser
+def test_oracle_reproduces_libjpeg_pixels(gold):
+    for n in names(gold):
+        got = jo.decode(gold[f"jpg_{n}"].tobytes())
+        assert np.array_equal(got, gold[f"bgr_{n}"]), n
+
+
+def test_oracle_refuses_progressive(gold):
+    with pytest.raises(ValueError):
+        jo.decode(gold["jpg_progressive"].tobytes())
+
+
+def test_host_header_parser_matches_oracle(pkg, ofk, gold):
+    """ofk_jpeg_info is host-only: it runs without a GPU."""
+    for n in names(gold):
+        data = gold[f"jpg_{n}"].tobytes()
+        i = jo.info(data)
+        assert ofk.jpeg_info(data) == (i["h"], i["w"], i["ncomp"])
+        assert gold[f"bgr_{n}"].shape == (i["h"], i["w"], 3)
+    for bad in (b"", b"\xff\xd8", b"not a jpeg at all", gold["jpg_progressive"].tobytes(), gold["jpg_c444"].tobytes()[:300]):
+        with pytest.raises(ofk.OfkError):
+            ofk.jpeg_info(bad)
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+def test_device_decoder_reproduces_libjpeg_pixels(gpu_ctx, gold):
+    for n in names(gold):
+        data = gold[f"jpg_{n}"].tobytes()
+        out = gpu_ctx.jpeg_decode([data])
+        assert out.shape == (1,) + gold[f"bgr_{n}"].shape
+        assert np.array_equal(out[0], gold[f"bgr_{n}"]), n
+    # a batch: the same stream three times and twice more after a different one of the same geometry (tables differ per image)
+    a, b = gold["jpg_c420_ros"].tobytes(), gold["jpg_c420_ros"].tobytes()
+    out = gpu_ctx.jpeg_decode([a, b, a])
+    for k in range(3):
+        assert np.array_equal(out[k], gold["bgr_c420_ros"])
+
+
+@pytest.mark.gpu
+def test_device_decoder_errors(gpu_ctx, ofk, gold):
+    with pytest.raises(ofk.OfkError):
+        gpu_ctx.jpeg_decode([gold["jpg_progressive"].tobytes()])
+    with pytest.raises(ofk.OfkError, match="differs"):
+        gpu_ctx.jpeg_decode([gold["jpg_c420_ros"].tobytes(), gold["jpg_c420_odd"].tobytes()])
+    data = gold["jpg_c420_ros"].tobytes()
+    with pytest.raises(ofk.OfkError, match="truncated|corrupt"):
+        gpu_ctx.jpeg_decode([data[: len(data) // 2] + b"\xff\xd9"])
+    # still usable afterwards
+    assert np.array_equal(gpu_ctx.jpeg_decode([data])[0], gold["bgr_c420_ros"])
+
+
+@pytest.mark.gpu
+def test_imdecode_facade(pkg, gold):
+    from of_amd import cv2_hip as cv2
+    img = cv2.imdecode(gold["jpg_c420_ros"], cv2.IMREAD_COLOR)
+    assert np.array_equal(img, gold["bgr_c420_ros"])
+    g = cv2.imdecode(gold["jpg_gray"], cv2.IMREAD_UNCHANGED)
+    assert g.ndim == 2 and np.array_equal(g, gold["bgr_gray"][:, :, 0])
+    assert cv2.imdecode(np.frombuffer(b"garbage", np.uint8), cv2.IMREAD_COLOR) is None
+
+
+def _encode(img, quality, subsampling=None):
+    Image = pytest.importorskip("PIL.Image")
+    buf = io.BytesIO()
+    kw = {} if subsampling is None else {"subsampling": subsampling}
+    Image.fromarray(img).save(buf, "JPEG", quality=quality, **kw)
+    return buf.getvalue()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h,w,ss,q", [(1080, 1920, 2, 80), (1080, 1920, 2, 97), (721, 1283, 1, 60), (333, 517, 0, 90), (1080, 1920, None, 80)])
+def test_device_decoder_vs_oracle_large(pkg, ofk, h, w, ss, q):
+    """Thousands of decoder threads per image (1080p at quality 80 is ~1500 chunks): the self-synchronisation must end in the
+    oracle's coefficients whatever the chunk boundaries hit."""
+    from of_amd import synth
+    frames = [synth.render_pair(h, w, 700 + k)["prev"] for k in range(3)]
+    if ss is None:
+        frames = [np.ascontiguousarray(f[:, :, 1]) for f in frames]
+    streams = [_encode(f, q, ss) for f in frames]
+    ctx = ofk.Context(0, w, h, 3, 64, 1)
+    out = ctx.jpeg_decode(streams)
+    for k in range(3):
+        assert np.array_equal(out[k], jo.decode(streams[k])), k
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_pairs_upload_jpeg_feeds_the_pipeline(pkg, ofk):
+    """Compressed ingest -> resident pairs -> the whole path: identical to uploading the frames the oracle decodes."""
+    from of_amd import synth
+    from of_amd.pipeline import FlowPipeline, PipelineConfig
+    B, h, w = 3, 480, 640
+    pairs = [synth.render_pair(h, w, 40 + b) for b in range(B)]
+    sp = [_encode(p["prev"], 90, 2) for p in pairs]
+    sn = [_encode(p["next"], 90, 2) for p in pairs]
+    sensors = ofk.make_sensors(B, scaling=pairs[0]["scaling"], cx=pairs[0]["cx"], cy=pairs[0]["cy"])
+    cfg = PipelineConfig(max_corners=150, quality=0.03, min_distance=7)
+    pipe = FlowPipeline(w, h, B, cfg)
+    pipe.upload(np.stack([jo.decode(s) for s in sp]), np.stack([jo.decode(s) for s in sn]), sensors)
+    ref = pipe.run()
+    pipe.ctx.pairs_upload_jpeg(sp, sn)
+    out = pipe.run()
+    for k in ("counts", "prev_pts", "next_pts", "status", "records"):
+        assert np.array_equal(out[k], ref[k]), k
+    assert int(out["counts"].min()) > 20
+    pipe.close()
