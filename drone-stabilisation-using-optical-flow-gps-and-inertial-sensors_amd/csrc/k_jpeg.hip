@@ -26,9 +26,12 @@
 #include "ofk_internal.h"
 #include <string.h>
 #include <stdlib.h>
+#include <thread>
+#include <vector>
 
 #define JCH 256                 // entropy bytes per decoder thread
 #define JB0 4                   // a symbol belongs to chunk i if the byte cursor after the refill is in [i*JCH + JB0, (i+1)*JCH + JB0)
+                                // (the guess of chunk i starts with the cursor at i*JCH + 4 after its first refill)
 #define JTPB 256                // decoder threads per workgroup (chunks of ONE image: the tables live in LDS)
 #define JMAX_ITERS 64           // flag slots; more iterations than this are read back one by one
 
@@ -50,13 +53,17 @@ struct jpeg_geom {
     size_t plane_off[3], plane_stride;   // bytes between images in the plane buffer
 };
 
-__constant__ uint8_t c_zz[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
-                                 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+__constant__ uint8_t c_izz[64] = {0, 1, 5, 6, 14, 15, 27, 28, 2, 4, 7, 13, 16, 26, 29, 42, 3, 8, 12, 17, 25, 30, 41, 43, 9, 11, 18, 24, 31, 40, 44, 53, 10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38, 46, 51, 55, 60, 21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63};      // natural position -> zigzag index
 static const uint8_t h_zz[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
                                  35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
 // ------------------------------------------------------------------------------------------------ device: entropy decoder
-struct jrd { const uint8_t *d; uint32_t len, pos; uint64_t buf; int nb; int k, blk; };
+// Reads go to global memory (L1/L2 hits: a workgroup's chunks are contiguous).  Staging the chunks in LDS was measured and bought
+// nothing: with 8 waves per SIMD the loop is bound by instruction issue (~250 instructions per symbol with the divergence between
+// lanes), not by the latency of the byte reads, and the 42 KB of LDS cost two thirds of the occupancy.
+// The host pads every entropy segment with zeros up to JPAD(len): the reader needs no bounds checks.
+#define JPAD(len) (((size_t)(len) + 2 * JCH + 19) / JCH * JCH)
+struct jrd { const uint8_t *d; uint32_t pos; uint64_t buf; int nb; int k, blk; };
 
 struct jlds {
     uint16_t lut[6][512];
@@ -73,15 +80,13 @@ __device__ inline void jload_tables(jlds &T, const jpeg_tab *t)
     __syncthreads();
 }
 
+// Canonical refill: byte by byte until 32..39 bits are buffered - enough for the longest code (16) plus the longest run of extra
+// bits (15), so a symbol needs one refill.  The state after it depends on the bit position only.
 __device__ inline void jrefill(jrd &r)
 {
-    while (r.nb <= 24) {
-        uint32_t b = 0;
-        if (r.pos < r.len) {
-            b = r.d[r.pos];
-            if (b == 0xFF && r.pos + 1 < r.len && r.d[r.pos + 1] == 0) ++r.pos;      // stuffed zero
-        }
-        ++r.pos;                                                                     // past the end: virtual zero bytes
+    while (r.nb <= 31) {
+        const uint32_t b = r.d[r.pos++];
+        if (b == 0xFF && r.d[r.pos] == 0) ++r.pos;                // stuffed zero (an FF in front of the zero padding counts as one too)
         r.buf = (r.buf << 8) | b;
         r.nb += 8;
     }
@@ -95,11 +100,8 @@ __device__ inline void jrebuild(jrd &r)
     uint32_t p = r.pos;
     while (got < r.nb && p > 0) {
         --p;
-        uint32_t b = 0;
-        if (p < r.len) {
-            b = r.d[p];
-            if (b == 0 && p > 0 && r.d[p - 1] == 0xFF) { --p; b = 0xFF; }
-        }
+        uint32_t b = r.d[p];
+        if (b == 0 && p > 0 && r.d[p - 1] == 0xFF) { --p; b = 0xFF; }
         buf |= (uint64_t)b << got;
         got += 8;
     }
@@ -113,13 +115,15 @@ __device__ inline uint64_t jpack(const jrd &r) { return ((uint64_t)r.pos << 32) 
 __device__ inline void junpack(jrd &r, uint64_t s) { r.pos = (uint32_t)(s >> 32); r.nb = (int)((s >> 16) & 63); r.k = (int)((s >> 8) & 63); r.blk = (int)(s & 15); }
 
 // Decodes symbols from a symbol boundary (reader refilled) until the byte cursor reaches `bnext` or `max_blocks` blocks are complete.
-// emit(block_in_progress_index, natural_position_or_zigzag_k, value) is called for every coefficient (DC as its difference).
+// emit.coef(zigzag index, value) is called for every non-zero coefficient of the block in progress (DC as its difference),
+// emit.block(i) when the i-th block of this run is complete.
 template <class Emit>
-__device__ inline int jrun(const jlds &T, jrd &r, uint32_t bnext, const jpeg_geom &g, int max_blocks, Emit emit)
+__device__ inline int jrun(const jlds &T, jrd &r, uint32_t bnext, const jpeg_geom &g, int max_blocks, Emit &emit)
 {
     int done = 0;
+    const int ny = g.comp_nb[0];
     while (r.pos < bnext && done < max_blocks) {
-        const int comp = g.blk_comp[r.blk];
+        const int comp = r.blk < ny ? 0 : r.blk - ny + 1;
         const int slot = comp * 2 + (r.k ? 1 : 0);
         int len, sym;
         const uint32_t e = T.lut[slot][jpeek(r, 9)];
@@ -132,25 +136,17 @@ __device__ inline int jrun(const jlds &T, jrd &r, uint32_t bnext, const jpeg_geo
             else { len = l; sym = T.vals[slot][((c16 >> (16 - l)) + T.valoff[slot][l]) & 255]; }
         }
         r.nb -= len;
-        if (r.k == 0) {
-            const int s = sym & 15;
-            int v = 0;
-            if (s) { jrefill(r); v = jextend((int)jpeek(r, s), s); r.nb -= s; }
-            emit(done, 0, v);
-            r.k = 1;
-        } else {
-            const int run = sym >> 4, s = sym & 15;
-            if (s) {
-                r.k += run;
-                jrefill(r);
-                const int v = jextend((int)jpeek(r, s), s);
-                r.nb -= s;
-                if (r.k < 64) emit(done, r.k, v);
-                ++r.k;
-            } else if (run == 15) r.k += 16;
-            else r.k = 64;
-        }
-        if (r.k >= 64) { r.k = 0; r.blk = r.blk + 1 == g.bpm ? 0 : r.blk + 1; ++done; }
+        const int run = r.k ? sym >> 4 : 0, s = sym & 15;
+        if (s) {
+            r.k += run;
+            const int v = jextend((int)jpeek(r, s), s);
+            r.nb -= s;
+            if (r.k < 64) emit.coef(r.k, v);
+            ++r.k;
+        } else if (r.k == 0) r.k = 1;                             // DC difference 0
+        else if (run == 15) r.k += 16;                            // ZRL
+        else r.k = 64;                                            // EOB
+        if (r.k >= 64) { r.k = 0; r.blk = r.blk + 1 == g.bpm ? 0 : r.blk + 1; emit.block(done); ++done; }
         jrefill(r);
     }
     return done;
@@ -159,11 +155,11 @@ __device__ inline int jrun(const jlds &T, jrd &r, uint32_t bnext, const jpeg_geo
 __device__ inline void jstart(jrd &r, uint32_t chunk)
 {   // chunk 0: the true start of the scan; otherwise the guess "a block starts at the first byte of the chunk"
     r.pos = chunk * JCH; r.nb = 0; r.buf = 0; r.k = 0; r.blk = 0;
-    if (chunk && r.pos < r.len && r.d[r.pos] == 0 && r.d[r.pos - 1] == 0xFF) ++r.pos;
+    if (chunk && r.d[r.pos] == 0 && r.d[r.pos - 1] == 0xFF) ++r.pos;
     jrefill(r);
 }
 
-struct jemit_none { __device__ void operator()(int, int, int) const {} };
+struct jemit_none { __device__ void coef(int, int) const {} __device__ void block(int) const {} };
 
 __global__ __launch_bounds__(JTPB) void k_jpeg_sync(const jpeg_tab *__restrict__ tabs, const uint8_t *__restrict__ ent, jpeg_geom g, int nch_max,
                                                     unsigned long long *__restrict__ state, unsigned long long *__restrict__ used,
@@ -173,25 +169,31 @@ __global__ __launch_bounds__(JTPB) void k_jpeg_sync(const jpeg_tab *__restrict__
     const int b = blockIdx.y;
     const jpeg_tab *t = tabs + b;
     if ((int)(blockIdx.x * JTPB) >= t->nch) return;
-    jload_tables(T, t);
     const int i = blockIdx.x * JTPB + threadIdx.x;
-    if (i >= t->nch) return;
     const size_t o = (size_t)b * nch_max + i;
+    // who has work?  iteration 0: everybody; later: the chunks whose predecessor published a state they have not started from yet
+    // (chunk 0 started from the truth and never has).  A workgroup without work leaves before it loads the tables.
+    unsigned long long e = 0;
+    bool work = i < t->nch;
+    if (work && iter) {
+        work = i > 0;
+        if (work) { e = state[o - 1]; work = e != used[o]; }
+    }
+    if (!__syncthreads_or(work)) return;
+    jload_tables(T, t);
+    if (!work) return;
     jrd r;
-    r.d = ent + t->ent_off; r.len = t->ent_len;
-    unsigned long long e;
-    if (iter == 0 || i == 0) {
-        if (iter) return;                                         // chunk 0 started from the truth: nothing to revise
+    r.d = ent + t->ent_off;
+    if (iter == 0) {
         jstart(r, i);
         e = jpack(r);
     } else {
-        e = state[o - 1];
-        if (e == used[o]) return;
         junpack(r, e);
         jrebuild(r);
     }
     used[o] = e;
-    const int n = jrun(T, r, (uint32_t)(i + 1) * JCH + JB0, g, 0x7fffffff, jemit_none());
+    jemit_none em;
+    const int n = jrun(T, r, (uint32_t)(i + 1) * JCH + JB0, g, 0x7fffffff, em);
     count[o] = n;
     const unsigned long long x = jpack(r);
     if (iter == 0) state[o] = x;
@@ -224,12 +226,30 @@ __global__ __launch_bounds__(1024) void k_jpeg_scan(const jpeg_tab *__restrict__
     if (threadIdx.x == 0) base[(size_t)b * (nch_max + 1) + nch_max] = carry;
 }
 
+// Coefficients of the block in progress are collected in the thread's LDS row and leave as one 128-byte store when the block is
+// complete (2-byte stores scattered over HBM made this kernel 3x slower than the counting pass).  A block that straddles a chunk
+// boundary is shared with the neighbouring thread: its parts are scattered element-wise onto the zeroed background instead.
+#define JBLK_PITCH 66                                             // int16 per LDS row: 33 dwords, lanes spread over the banks
 struct jemit_store {
-    int16_t *coef; int n0, nblk;
-    __device__ void operator()(int done, int k, int v) const
+    int16_t *row;                                                 // this thread's LDS row (zigzag order, zero between blocks)
+    int16_t *out; int n0, nblk; bool head_partial;
+    __device__ void coef(int k, int v) { row[k] = (int16_t)v; }
+    __device__ void scatter(int n)
+    {
+        int16_t *dst = out + (size_t)n * 64;
+        for (int k = 0; k < 64; ++k) { const int16_t v = row[k]; if (v) { dst[k] = v; row[k] = 0; } }
+    }
+    __device__ void block(int done)
     {
         const int n = n0 + done;
-        if (n < nblk) coef[(size_t)n * 64 + c_zz[k]] = (int16_t)v;
+        if (n >= nblk) return;
+        if (done == 0 && head_partial) { scatter(n); return; }
+        const uint32_t *src = (const uint32_t *)row;
+        uint4 *dst = (uint4 *)(out + (size_t)n * 64);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) dst[q] = make_uint4(src[4 * q], src[4 * q + 1], src[4 * q + 2], src[4 * q + 3]);
+#pragma unroll
+        for (int q = 0; q < 32; ++q) ((uint32_t *)row)[q] = 0;
     }
 };
 
@@ -238,6 +258,7 @@ __global__ __launch_bounds__(JTPB) void k_jpeg_write(const jpeg_tab *__restrict_
                                                      int16_t *__restrict__ coef, int *__restrict__ endinfo)
 {
     __shared__ jlds T;
+    __shared__ int16_t rows[JTPB][JBLK_PITCH];
     const int b = blockIdx.y;
     const jpeg_tab *t = tabs + b;
     if ((int)(blockIdx.x * JTPB) >= t->nch) return;
@@ -247,11 +268,13 @@ __global__ __launch_bounds__(JTPB) void k_jpeg_write(const jpeg_tab *__restrict_
     const int n0 = base[(size_t)b * (nch_max + 1) + i];
     if (n0 >= g.nblk) return;
     jrd r;
-    r.d = ent + t->ent_off; r.len = t->ent_len;
+    r.d = ent + t->ent_off;
     if (i == 0) jstart(r, 0);
     else { junpack(r, state[(size_t)b * nch_max + i - 1]); jrebuild(r); }
-    jemit_store em = {coef + (size_t)b * g.nblk * 64, n0, g.nblk};
+    for (int q = 0; q < JBLK_PITCH / 2; ++q) ((uint32_t *)rows[threadIdx.x])[q] = 0;
+    jemit_store em = {rows[threadIdx.x], coef + (size_t)b * g.nblk * 64, n0, g.nblk, r.k != 0};
     const int n = jrun(T, r, (uint32_t)(i + 1) * JCH + JB0, g, g.nblk - n0, em);
+    if (r.k != 0 && n0 + n < g.nblk) em.scatter(n0 + n);          // the block still in progress continues in the next chunk
     if (n0 + n == g.nblk && n > 0) {                              // this thread finished the last block: where the scan ended
         endinfo[b * 2] = (int)(r.pos - (uint32_t)(r.nb >> 3));
         endinfo[b * 2 + 1] = 1;
@@ -354,7 +377,7 @@ __global__ __launch_bounds__(256) void k_jpeg_idct(const jpeg_tab *__restrict__ 
         const uint16_t *q = tabs[b].q[comp];
         int in[8], o[8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) in[r] = (int)cf[r * 8 + c] * (int)q[r * 8 + c];
+        for (int r = 0; r < 8; ++r) in[r] = (int)cf[c_izz[r * 8 + c]] * (int)q[r * 8 + c];         // blocks are stored in zigzag order
         jidct8(in, o);
 #pragma unroll
         for (int r = 0; r < 8; ++r) ws[lb][r * 9 + c] = (o[r] + (1 << 10)) >> 11;
@@ -379,42 +402,85 @@ __global__ __launch_bounds__(256) void k_jpeg_idct(const jpeg_tab *__restrict__ 
 
 __device__ inline int jclamp8(int x) { return x < 0 ? 0 : x > 255 ? 255 : x; }
 
-// chroma sample for output pixel (x, y) with libjpeg's fancy upsampling
-__device__ inline int jchroma(const uint8_t *__restrict__ pl, int pitch, int cw, int ch, int hmax, int vmax, int x, int y)
+// Chroma of the 8 output pixels x0 .. x0+7 (x0 a multiple of 8) of row y with libjpeg's "fancy" upsampling
+// (jdsample.c h2v1_fancy_upsample / h2v2_fancy_upsample; context rows replicated at the top and bottom edge as jdmainct.c does).
+// The four chroma columns under the pixels come in as one dword per row, their two neighbours as bytes.
+__device__ inline void jchroma8(const uint8_t *__restrict__ pl, int pitch, int cw, int ch, int hmax, int vmax, int x0, int y, int *out)
 {
-    if (hmax == 1) return pl[(size_t)y * pitch + x];
-    const int cx = x >> 1;
-    if (vmax == 1) {                                              // h2v1_fancy_upsample
-        const uint8_t *in = pl + (size_t)y * pitch;
-        const int v = in[cx];
-        if (x & 1) return cx == cw - 1 ? v : (v * 3 + in[cx + 1] + 2) >> 2;
-        return cx == 0 ? v : (v * 3 + in[cx - 1] + 1) >> 2;
+    if (hmax == 1) {
+        const uint2 v = *(const uint2 *)(pl + (size_t)y * pitch + x0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { out[k] = (v.x >> (8 * k)) & 255; out[k + 4] = (v.y >> (8 * k)) & 255; }
+        return;
     }
-    const int r0 = y >> 1;                                        // h2v2_fancy_upsample
+    const int cx0 = x0 >> 1;
+    const int cl = cx0 > 0 ? cx0 - 1 : 0, cr = cx0 + 4 < cw ? cx0 + 4 : cw - 1;
+    int t[6];
+    if (vmax == 1) {
+        const uint8_t *in = pl + (size_t)y * pitch;
+        const uint32_t m = *(const uint32_t *)(in + cx0);
+        t[0] = in[cl]; t[5] = in[cr];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k + 1] = (m >> (8 * k)) & 255;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int cx = cx0 + k, v = t[k + 1];
+            out[2 * k] = cx == 0 ? v : (v * 3 + t[k] + 1) >> 2;
+            out[2 * k + 1] = cx == cw - 1 ? v : (v * 3 + t[k + 2] + 2) >> 2;
+        }
+        return;
+    }
+    const int r0 = y >> 1;
     int r1 = (y & 1) ? r0 + 1 : r0 - 1;
     r1 = r1 < 0 ? 0 : r1 > ch - 1 ? ch - 1 : r1;
     const uint8_t *i0 = pl + (size_t)r0 * pitch, *i1 = pl + (size_t)r1 * pitch;
-    const int t = i0[cx] * 3 + i1[cx];
-    if (x & 1) return cx == cw - 1 ? (t * 4 + 7) >> 4 : (t * 3 + i0[cx + 1] * 3 + i1[cx + 1] + 7) >> 4;
-    return cx == 0 ? (t * 4 + 8) >> 4 : (t * 3 + i0[cx - 1] * 3 + i1[cx - 1] + 8) >> 4;
+    const uint32_t m0 = *(const uint32_t *)(i0 + cx0), m1 = *(const uint32_t *)(i1 + cx0);
+    t[0] = i0[cl] * 3 + i1[cl]; t[5] = i0[cr] * 3 + i1[cr];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t[k + 1] = (int)((m0 >> (8 * k)) & 255) * 3 + (int)((m1 >> (8 * k)) & 255);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int cx = cx0 + k, v = t[k + 1];
+        out[2 * k] = cx == 0 ? (v * 4 + 8) >> 4 : (v * 3 + t[k] + 8) >> 4;
+        out[2 * k + 1] = cx == cw - 1 ? (v * 4 + 7) >> 4 : (v * 3 + t[k + 2] + 7) >> 4;
+    }
 }
 
+// eight pixels per thread: 8 bytes of luma in, 24 bytes of BGR out as dwords (bytes when the row pitch is not a dword multiple)
 __global__ __launch_bounds__(256) void k_jpeg_color(jpeg_geom g, const uint8_t *__restrict__ planes, uint8_t *__restrict__ bgr, size_t bgr_stride)
 {
     const int b = blockIdx.z;
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    if (x >= g.w) return;
+    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 8, y = blockIdx.y * 4 + threadIdx.y;
+    if (x0 >= g.w || y >= g.h) return;
     const uint8_t *pl = planes + (size_t)b * g.plane_stride;
-    uint8_t *o = bgr + (size_t)b * bgr_stride + ((size_t)y * g.w + x) * 3;
-    const int Y = pl[g.plane_off[0] + (size_t)y * g.pw[0] + x];
-    if (g.ncomp == 1) { o[0] = o[1] = o[2] = (uint8_t)Y; return; }
-    const int cw = (g.w + g.hmax - 1) / g.hmax, ch = (g.h + g.vmax - 1) / g.vmax;
-    const int cb = jchroma(pl + g.plane_off[1], g.pw[1], cw, ch, g.hmax, g.vmax, x, y) - 128;
-    const int cr = jchroma(pl + g.plane_off[2], g.pw[2], cw, ch, g.hmax, g.vmax, x, y) - 128;
-    // jdcolor.c build_ycc_rgb_table: SCALEBITS 16, FIX(1.40200) = 91881, FIX(1.77200) = 116130, FIX(0.71414) = 46802, FIX(0.34414) = 22554
-    o[0] = (uint8_t)jclamp8(Y + ((116130 * cb + 32768) >> 16));
-    o[1] = (uint8_t)jclamp8(Y + ((-22554 * cb + 32768 - 46802 * cr) >> 16));
-    o[2] = (uint8_t)jclamp8(Y + ((91881 * cr + 32768) >> 16));
+    uint8_t *o = bgr + (size_t)b * bgr_stride + ((size_t)y * g.w + x0) * 3;
+    const uint2 y8 = *(const uint2 *)(pl + g.plane_off[0] + (size_t)y * g.pw[0] + x0);              // pw is a multiple of 8
+    uint8_t px[24];
+    if (g.ncomp == 1) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) px[3 * k] = px[3 * k + 1] = px[3 * k + 2] = (uint8_t)(((k < 4 ? y8.x : y8.y) >> (8 * (k & 3))) & 255);
+    } else {
+        const int cw = (g.w + g.hmax - 1) / g.hmax, ch = (g.h + g.vmax - 1) / g.vmax;
+        int cb[8], cr[8];
+        jchroma8(pl + g.plane_off[1], g.pw[1], cw, ch, g.hmax, g.vmax, x0, y, cb);
+        jchroma8(pl + g.plane_off[2], g.pw[2], cw, ch, g.hmax, g.vmax, x0, y, cr);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int Y = ((k < 4 ? y8.x : y8.y) >> (8 * (k & 3))) & 255, u = cb[k] - 128, v = cr[k] - 128;
+            // jdcolor.c build_ycc_rgb_table: SCALEBITS 16, FIX(1.40200) = 91881, FIX(1.77200) = 116130, FIX(0.71414) = 46802, FIX(0.34414) = 22554
+            px[3 * k] = (uint8_t)jclamp8(Y + ((116130 * u + 32768) >> 16));
+            px[3 * k + 1] = (uint8_t)jclamp8(Y + ((-22554 * u + 32768 - 46802 * v) >> 16));
+            px[3 * k + 2] = (uint8_t)jclamp8(Y + ((91881 * v + 32768) >> 16));
+        }
+    }
+    if ((g.w & 7) == 0 && (bgr_stride & 3) == 0) {
+        uint32_t *o4 = (uint32_t *)o;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) o4[k] = px[4 * k] | (px[4 * k + 1] << 8) | (px[4 * k + 2] << 16) | ((uint32_t)px[4 * k + 3] << 24);
+    } else {
+        const int n = (g.w - x0 < 8 ? g.w - x0 : 8) * 3;
+        for (int k = 0; k < n; ++k) o[k] = px[k];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ host: marker segments
@@ -487,7 +553,8 @@ static const char *jparse(const uint8_t *d, size_t n, jhost *j)
             }
             const size_t e0 = i + L;
             size_t e = e0;
-            while (e < n) {                                       // up to the next marker (FF followed by anything but a stuffed zero)
+            if (n >= e0 + 2 && d[n - 2] == 0xFF && d[n - 1] == 0xD9) e = n - 2;   // ends in EOI (every encoder's output): no need to read it all
+            else while (e < n) {                                       // up to the next marker (FF followed by anything but a stuffed zero)
                 const uint8_t *f = (const uint8_t *)memchr(d + e, 0xFF, n - e);
                 if (!f) { e = n; break; }
                 e = (size_t)(f - d);
@@ -582,7 +649,7 @@ int ofk_jpeg_decode_device(ofk_ctx *c, const uint8_t *const *jpeg, const size_t 
             const int rc = ofk_fail(c, OFK_E_INVALID, "ofk_jpeg: stream %d differs in size or sampling from stream 0 (one geometry per batch)", b);
             free(jh); return rc;
         }
-        ent_total += jup(jh[b].ent_len + 16, JCH);
+        ent_total += JPAD(jh[b].ent_len);
         const int nch = (int)((jh[b].ent_len + JB0) / JCH) + 1;
         if (nch > nch_max) nch_max = nch;
     }
@@ -598,23 +665,39 @@ int ofk_jpeg_decode_device(ofk_ctx *c, const uint8_t *const *jpeg, const size_t 
     }
     jpeg_tab *ht = (jpeg_tab *)c->hstage;
     uint8_t *hent = (uint8_t *)c->hstage + tab_bytes;
+    // tables and entropy segments into the staging buffer: a plain copy of ~0.4 MB per 1080p frame, spread over a few host threads
+    // (one thread moves ~10 GB/s, which would make this copy the slowest stage of the ingest)
+    size_t *eoff = (size_t *)malloc(sizeof(size_t) * (size_t)batch);
+    if (!eoff) { free(jh); return ofk_fail(c, OFK_E_INVALID, "ofk_jpeg: out of host memory"); }
     size_t eo = 0;
-    for (int b = 0; b < batch; ++b) {
-        const jhost &j = jh[b];
-        jpeg_tab *t = ht + b;
-        for (int cc = 0; cc < 3; ++cc) {
-            const int cs = cc < j.ncomp ? cc : 0;
-            jbuild_slot(t, 2 * cc, j.bits[0][j.td[cs]], j.vals[0][j.td[cs]]);
-            jbuild_slot(t, 2 * cc + 1, j.bits[1][j.ta[cs]], j.vals[1][j.ta[cs]]);
-            memcpy(t->q[cc], j.q[j.tq[cs]], 128);
+    for (int b = 0; b < batch; ++b) { eoff[b] = eo; eo += JPAD(jh[b].ent_len); }
+    auto stage_range = [&](int b0, int step) {
+        for (int b = b0; b < batch; b += step) {
+            const jhost &j = jh[b];
+            jpeg_tab *t = ht + b;
+            for (int cc = 0; cc < 3; ++cc) {
+                const int cs = cc < j.ncomp ? cc : 0;
+                jbuild_slot(t, 2 * cc, j.bits[0][j.td[cs]], j.vals[0][j.td[cs]]);
+                jbuild_slot(t, 2 * cc + 1, j.bits[1][j.ta[cs]], j.vals[1][j.ta[cs]]);
+                memcpy(t->q[cc], j.q[j.tq[cs]], 128);
+            }
+            t->ent_off = (uint32_t)eoff[b]; t->ent_len = (uint32_t)j.ent_len;
+            t->nch = (int)((j.ent_len + JB0) / JCH) + 1; t->pad = 0;
+            memcpy(hent + eoff[b], j.ent, j.ent_len);
+            memset(hent + eoff[b] + j.ent_len, 0, JPAD(j.ent_len) - j.ent_len);
         }
-        t->ent_off = (uint32_t)eo; t->ent_len = (uint32_t)j.ent_len;
-        t->nch = (int)((j.ent_len + JB0) / JCH) + 1; t->pad = 0;
-        memcpy(hent + eo, j.ent, j.ent_len);
-        const size_t padded = jup(j.ent_len + 16, JCH);
-        memset(hent + eo + j.ent_len, 0, padded - j.ent_len);
-        eo += padded;
+    };
+    unsigned nthr = std::thread::hardware_concurrency() / 2;
+    nthr = nthr < 1 ? 1 : nthr > 8 ? 8 : nthr;
+    if ((unsigned)batch < nthr) nthr = (unsigned)batch;
+    if (ent_total < (4u << 20) || nthr == 1) stage_range(0, 1);
+    else {
+        std::vector<std::thread> pool;
+        for (unsigned k = 1; k < nthr; ++k) pool.emplace_back(stage_range, (int)k, (int)nthr);
+        stage_range(0, (int)nthr);
+        for (auto &th : pool) th.join();
     }
+    free(eoff);
     free(jh);
     if (ent_total >= (1ull << 32)) return ofk_fail(c, OFK_E_INVALID, "ofk_jpeg: more than 4 GiB of entropy data in one batch");
     // device scratch
@@ -665,7 +748,7 @@ int ofk_jpeg_decode_device(ofk_ctx *c, const uint8_t *const *jpeg, const size_t 
     hipLaunchKernelGGL(k_jpeg_write, dgrid, dim3(JTPB), 0, st, dt, dent, g, nch_max, state, base, coef, endinfo);
     hipLaunchKernelGGL(k_jpeg_dc, dim3(batch, g.ncomp), dim3(1024), 0, st, g, coef);
     hipLaunchKernelGGL(k_jpeg_idct, dim3((g.nblk + 31) / 32, batch), dim3(256), 0, st, dt, g, coef, planes);
-    hipLaunchKernelGGL(k_jpeg_color, dim3((g.w + 255) / 256, g.h, batch), dim3(256), 0, st, g, planes, dst, dst_stride);
+    hipLaunchKernelGGL(k_jpeg_color, dim3((g.w + 511) / 512, (g.h + 3) / 4, batch), dim3(64, 4), 0, st, g, planes, dst, dst_stride);
     int *hend = (int *)malloc(B * 8);
     if (!hend) return ofk_fail(c, OFK_E_INVALID, "ofk_jpeg: out of host memory");
     hipError_t e = hipMemcpyAsync(hend, endinfo, B * 8, hipMemcpyDeviceToHost, st);

@@ -43,8 +43,8 @@ def main():
 
     sp4 = [enc(p["prev"]) for p in distinct]
     sn4 = [enc(p["next"]) for p in distinct]
-    sp = [sp4[b % 4] for b in range(B)]
-    sn = [sn4[b % 4] for b in range(B)]
+    sp = [bytes(bytearray(sp4[b % 4])) for b in range(B)]           # every frame in its own host buffer, as a subscriber sees them
+    sn = [bytes(bytearray(sn4[b % 4])) for b in range(B)]
     mean_bytes = float(np.mean([len(s) for s in sp + sn]))
     ctx = ofk.Context(0, W, H, B, 512, 3)
     ctx.pairs_upload_jpeg(sp, sn)                                 # warm-up: scratch + staging allocation
