@@ -100,10 +100,18 @@ class optical_fusion:
             self.got_ang_vel_ = True
 
     def _decode(self, image_raw):
+        """node:112 (cv_bridge.compressed_imgmsg_to_cv2(image_raw, 'bgr8')).  A sensor_msgs/CompressedImage - anything with a
+        `.data` byte payload - or a bare JPEG byte string is decoded on the GPU (cv2_hip.imdecode = what cv_bridge calls);
+        cv_bridge only takes over for payloads the device decoder does not handle (png, progressive JPEG)."""
         if isinstance(image_raw, np.ndarray):
             return image_raw
+        data = image_raw if isinstance(image_raw, (bytes, bytearray, memoryview)) else getattr(image_raw, "data", None)
+        if data is not None:
+            img = cv2.imdecode(np.frombuffer(bytes(data), np.uint8), cv2.IMREAD_COLOR)
+            if img is not None:
+                return img
         if CvBridge is None:
-            raise RuntimeError("cv_bridge is not available: pass BGR numpy frames to call_optical")
+            raise RuntimeError("call_optical: not a baseline JPEG payload and cv_bridge is not available - pass BGR numpy frames")
         return CvBridge().compressed_imgmsg_to_cv2(image_raw, 'bgr8')
 
     def call_optical(self, image_raw):

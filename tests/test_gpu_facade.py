@@ -127,6 +127,33 @@ def test_node_restored_pipeline_tracks_rendered_motion(mods, pkg):
     assert v_obs is not None and n.last_rank == 3
 
 
+def test_node_takes_compressed_image_messages(mods, pkg):
+    """node:112 — the image callback receives sensor_msgs/CompressedImage; the JPEG payload is decoded on the GPU and the node
+    ends in exactly the state it reaches when handed the frames libjpeg would have produced."""
+    Image = pytest.importorskip("PIL.Image")
+    import io
+    from types import SimpleNamespace
+    from oracle import jpeg_oracle as jo
+    from of_amd import synth
+    node = mods.node
+    p = synth.render_pair(480, 640, 33, v=(0.01, -0.008, 0.004), omega=(0, 0, 0), d=0.75, scaling=0.01)
+    msgs = []
+    for key in ("prev", "next"):
+        buf = io.BytesIO()
+        Image.fromarray(p[key]).save(buf, "JPEG", quality=90)
+        msgs.append(SimpleNamespace(format="jpeg", data=buf.getvalue()))
+    outs = []
+    for frames in (msgs, [jo.decode(m.data) for m in msgs]):
+        n = node.optical_fusion(spin=False, synthetic_test=False)
+        n.feature_params = dict(qualityLevel=0.05, minDistance=10, blockSize=12)
+        n.T = 2.0
+        n.call_optical(frames[0]); n.call_optical(frames[1])
+        outs.append((np.array(n.feat), np.array(n.flow), n.step()))
+    assert len(outs[0][0]) >= 20
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)
+
+
 def test_simulation_module(mods, golden):
     g, sim = golden, mods.sim
     flow = sim.generate_test_data(g["g1_points"], g["g1_v"], g["g1_omega"], 1, g["g1_n"], g["g1_t"])
