@@ -17,6 +17,9 @@ exchange and uses hipDeviceSynchronize through the library, so torch is not impo
 Under torchrun the gather is pipelined one step behind the compute (ofk_mark / ofk_mark_wait): step k's records
 travel while step k+1 runs; K steps issue K gathers inside the timed region.
 
+Schedule (default): the batch runs as two free-running slices (--streams 2): each slice has its own stage chain
+and auxiliary stream, the slices are offset by one response kernel and are not joined between steps.
+
 The JSON line also carries
   roofline     : the longest stage on the step's critical path, from HIP events recorded inside the timed region on the
                  stream the stage is launched on; achieved = SURVEY.md §8(d) algorithmic bytes per pair x B / mean stage
