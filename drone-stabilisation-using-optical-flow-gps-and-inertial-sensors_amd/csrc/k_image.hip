@@ -260,6 +260,181 @@ __global__ __launch_bounds__(256) void k_pyr_down_stream(const uint8_t *__restri
     }
 }
 
+// ------------------------------------------------------------------------------------------------ three pyramid levels in one pass
+// k_pyr3_stream: levels 1, 2 and 3 from one read of level 0 (widths divisible by 16, heights by 8).  The per-level kernels read
+// level 1 and level 2 back from HBM (1.3 of the 6.8 MB per pair); here a wave marches down a strip of level 0 once and every
+// level's rows are built from the rows of the level above while those are still in registers.
+//   lane = 16 source columns (one dwordx4 load per row) = 8 / 4 / 2 columns of levels 1 / 2 / 3.  Every level's horizontal
+//   [1 4 6 4 1] needs one value pair from each neighbouring lane (DPP wave shifts), so three lanes on either side of a strip
+//   only feed their neighbours: 58 payload lanes between strips, 61 in a strip that touches an image border (the mirrored
+//   columns come from the lane itself).  1920 columns = 120 lanes = two strips.
+//   Vertically, step t consumes level-0 rows 2t+1, 2t+2 and yields level-1 row t; at even t level-2 row (t-2)/2 follows from
+//   the last five horizontally filtered level-1 rows, at t = 2 (mod 4) level-3 row (t-6)/4 from the last five level-2 rows.
+//   A chunk of steps starts 12 steps early (its windows fill with the rows of the chunk above - or, at the top of the image,
+//   with rows of negative index, which equal their mirror images at every level because filter and extension are symmetric);
+//   at the bottom (even heights at every level) row n of a level mirrors row n-2, the centre row of the last window.
+//   Arithmetic per level is exactly that of k_pyr_down_stream: packed u16 pairs, (sum + 128) >> 8.
+#define P3_M 0x00ff00ffu
+#define P3_SHR(x) ((unsigned)__builtin_amdgcn_update_dpp(0, (int)(x), 0x138, 0xF, 0xF, true))   // value of lane-1
+#define P3_SHL(x) ((unsigned)__builtin_amdgcn_update_dpp(0, (int)(x), 0x130, 0xF, 0xF, true))   // value of lane+1
+#define P3_AB(hi, lo) __builtin_amdgcn_alignbit((hi), (lo), 16)                                   // (lo.hi16, hi.lo16)
+#define P3_EVEN(t1, t0) __builtin_amdgcn_perm((t1), (t0), 0x05040100u)                            // (t0.lo16, t1.lo16)
+#define P3_ODD(t1, t0) __builtin_amdgcn_perm((t1), (t0), 0x07060302u)                             // (t0.hi16, t1.hi16)
+#define P3_BYTES(v1, v0) __builtin_amdgcn_perm((v1), (v0), 0x07050301u)                           // (v >> 8) of the four u16 halves
+
+__device__ __forceinline__ unsigned p3_vert(unsigned a, unsigned b, unsigned c, unsigned d, unsigned e)
+{
+    return ((b + d + c) << 2) + a + ((c << 1) + e) + 0x00800080u;       // a + e + 4(b + d) + 6c + 128 in both halves
+}
+
+// 16 bytes of a level-0 row -> the four pairs of horizontal sums centred on bytes (0,2) (4,6) (8,10) (12,14)
+__device__ __forceinline__ void p3_h16(uint4 d, bool first, bool last, unsigned *h)
+{
+    const unsigned E0 = d.x & P3_M, O0 = (d.x >> 8) & P3_M, E1 = d.y & P3_M, O1 = (d.y >> 8) & P3_M;
+    const unsigned E2 = d.z & P3_M, O2 = (d.z >> 8) & P3_M, E3 = d.w & P3_M, O3 = (d.w >> 8) & P3_M;
+    unsigned pE = P3_SHR(E3), pO = P3_SHR(O3), nE = P3_SHL(E0);
+    if (first) { pE = E0; pO = O0 << 16; }                      // columns -2,-1 mirror 2,1
+    if (last) nE = E3 >> 16;                                    // column w mirrors w-2
+    const unsigned l20 = P3_AB(E0, pE), l21 = P3_AB(E1, E0), l22 = P3_AB(E2, E1), l23 = P3_AB(E3, E2), l24 = P3_AB(nE, E3);
+    const unsigned l10 = P3_AB(O0, pO), l11 = P3_AB(O1, O0), l12 = P3_AB(O2, O1), l13 = P3_AB(O3, O2);
+    h[0] = 6u * E0 + 4u * (l10 + O0) + l20 + l21;
+    h[1] = 6u * E1 + 4u * (l11 + O1) + l21 + l22;
+    h[2] = 6u * E2 + 4u * (l12 + O2) + l22 + l23;
+    h[3] = 6u * E3 + 4u * (l13 + O3) + l23 + l24;
+}
+
+// 8 values of a level-1 row as even/odd pairs (E0 = (o0,o2), O0 = (o1,o3), E1 = (o4,o6), O1 = (o5,o7)) -> two pairs of sums
+__device__ __forceinline__ void p3_h8(unsigned E0, unsigned O0, unsigned E1, unsigned O1, bool first, bool last, unsigned &g0, unsigned &g1)
+{
+    unsigned pE = P3_SHR(E1), pO = P3_SHR(O1), nE = P3_SHL(E0);
+    if (first) { pE = E0; pO = O0 << 16; }
+    if (last) nE = E1 >> 16;
+    const unsigned l20 = P3_AB(E0, pE), l21 = P3_AB(E1, E0), l22 = P3_AB(nE, E1), l10 = P3_AB(O0, pO), l11 = P3_AB(O1, O0);
+    g0 = 6u * E0 + 4u * (l10 + O0) + l20 + l21;
+    g1 = 6u * E1 + 4u * (l11 + O1) + l21 + l22;
+}
+
+// 4 values of a level-2 row (E = (t0,t2), O = (t1,t3)) -> one pair of sums
+__device__ __forceinline__ unsigned p3_h4(unsigned E, unsigned O, bool first, bool last)
+{
+    unsigned pE = P3_SHR(E), pO = P3_SHR(O), nE = P3_SHL(E);
+    if (first) { pE = E; pO = O << 16; }
+    if (last) nE = E >> 16;
+    return 6u * E + 4u * (P3_AB(O, pO) + O) + P3_AB(E, pE) + P3_AB(nE, E);
+}
+
+struct p3_args {
+    const uint8_t *base0, *base1;       // pyramid slabs of the two frame sets (level 0 at offset 0)
+    size_t stride, off1, off2, off3;    // bytes between images; offsets of levels 1..3 inside a slab
+    int h, w, batch, steps, nstrips, nchunks;
+};
+
+__global__ __launch_bounds__(256) void k_pyr3_stream(p3_args A)
+{
+    const int lane = threadIdx.x & 63;
+    int bx = blockIdx.x, z = blockIdx.y;
+    if ((gridDim.y & 7) == 0) {                                 // XCD-aware: an image's chunks on one XCD (see k_pyr_down_stream)
+        const unsigned n = blockIdx.y * gridDim.x + blockIdx.x, k = n >> 3;
+        z = 8 * (int)(k / gridDim.x) + (int)(n & 7);
+        bx = (int)(k % gridDim.x);
+    }
+    const int wid = __builtin_amdgcn_readfirstlane(bx * 4 + (threadIdx.x >> 6));
+    if (wid >= A.nstrips * A.nchunks) return;
+    const int strip = wid % A.nstrips, chunk = wid / A.nstrips;
+    const int h = A.h, w = A.w, n1 = h >> 1, n2 = h >> 2, n3 = h >> 3, w1 = w >> 1, w2 = w >> 2, w3 = w >> 3;
+    const uint8_t *img = (z < A.batch ? A.base0 + (size_t)z * A.stride : A.base1 + (size_t)(z - A.batch) * A.stride);
+    uint8_t *slab = const_cast<uint8_t *>(img);
+    const int hl = strip == 0 ? 0 : 3, hr = strip == A.nstrips - 1 ? 0 : 3;
+    const int cs = strip == 0 ? 0 : 16 * (61 + 58 * (strip - 1));           // first payload column of the strip
+    const int c0 = cs - 16 * hl + 16 * lane;
+    const int sc = min(max(c0, 0), w - 16);
+    const bool first = c0 == 0, last = c0 == w - 16;
+    const bool st = lane >= hl && lane <= 63 - hr && c0 < w;
+    const int T0 = chunk * A.steps, T1 = T0 + A.steps;
+    auto ld = [&](int sy) -> uint4 {
+        sy = sy < 0 ? -sy : sy;
+        sy = sy >= h ? 2 * (h - 1) - sy : sy;
+        const uint8_t *rowp = img + (size_t)__builtin_amdgcn_readfirstlane(max(sy, 0)) * (unsigned)w;
+        return *reinterpret_cast<const uint4 *>(rowp + (unsigned)sc);
+    };
+    const int ts = T0 - 12;
+    unsigned a[4], b[4], c[4];
+    p3_h16(ld(2 * ts - 2), first, last, a);
+    p3_h16(ld(2 * ts - 1), first, last, b);
+    p3_h16(ld(2 * ts), first, last, c);
+    uint4 q[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) q[k] = ld(2 * ts + 1 + k);
+    unsigned r1x[5] = {0, 0, 0, 0, 0}, r1y[5] = {0, 0, 0, 0, 0}, r2[5] = {0, 0, 0, 0, 0};
+    for (int t = ts; t < T1; t += 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int tt = t + k;
+            const bool own = tt >= T0;                          // warm-up steps store nothing
+            unsigned d[4], e[4], v[4];
+            p3_h16(q[2 * k], first, last, d);
+            p3_h16(q[2 * k + 1], first, last, e);
+            q[2 * k] = ld(2 * tt + 9);
+            q[2 * k + 1] = ld(2 * tt + 10);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] = p3_vert(a[j], b[j], c[j], d[j], e[j]); a[j] = c[j]; b[j] = d[j]; c[j] = e[j]; }
+            if (st && own && tt < n1)
+                *reinterpret_cast<uint2 *>(slab + A.off1 + (size_t)tt * w1 + (c0 >> 1)) = make_uint2(P3_BYTES(v[1], v[0]), P3_BYTES(v[3], v[2]));
+            // level 1 -> horizontally filtered row of level 1
+            const unsigned t0 = (v[0] >> 8) & P3_M, t1 = (v[1] >> 8) & P3_M, t2 = (v[2] >> 8) & P3_M, t3 = (v[3] >> 8) & P3_M;
+            unsigned g0, g1;
+            p3_h8(P3_EVEN(t1, t0), P3_ODD(t1, t0), P3_EVEN(t3, t2), P3_ODD(t3, t2), first, last, g0, g1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { r1x[j] = r1x[j + 1]; r1y[j] = r1y[j + 1]; }
+            r1x[4] = g0; r1y[4] = g1;
+            if ((k & 1) == 0) {                                 // even step: level-2 row (tt - 2) / 2 from level-1 rows tt-4 .. tt
+                const bool m1 = tt == n1;                       // row n1 mirrors row n1 - 2, the centre of this window
+                const unsigned w0 = p3_vert(r1x[0], r1x[1], r1x[2], r1x[3], m1 ? r1x[2] : r1x[4]);
+                const unsigned w1v = p3_vert(r1y[0], r1y[1], r1y[2], r1y[3], m1 ? r1y[2] : r1y[4]);
+                const int qrow = (tt - 2) >> 1;
+                if (st && own && tt >= 2 && qrow < n2)
+                    *reinterpret_cast<unsigned *>(slab + A.off2 + (size_t)qrow * w2 + (c0 >> 2)) = P3_BYTES(w1v, w0);
+                const unsigned s0 = (w0 >> 8) & P3_M, s1 = (w1v >> 8) & P3_M;
+                const unsigned k2 = p3_h4(P3_EVEN(s1, s0), P3_ODD(s1, s0), first, last);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) r2[j] = r2[j + 1];
+                r2[4] = k2;
+                if (k == 2) {                                   // step 2 (mod 4): level-3 row (tt - 6) / 4 from level-2 rows q-4 .. q
+                    const unsigned zv = p3_vert(r2[0], r2[1], r2[2], r2[3], qrow == n2 ? r2[2] : r2[4]);
+                    const int rrow = (tt - 6) >> 2;
+                    if (st && own && tt >= 6 && rrow < n3)
+                        *reinterpret_cast<unsigned short *>(slab + A.off3 + (size_t)rrow * w3 + (c0 >> 3)) =
+                            (unsigned short)(((zv >> 8) & 0xffu) | ((zv >> 16) & 0xff00u));
+                }
+            }
+        }
+    }
+}
+
+static bool pyr3_ok(int h, int w) { return (w & 15) == 0 && (h & 7) == 0 && w >= 64 && h >= 32 && getenv("OFK_NO_PYR3") == nullptr; }
+
+// levels 1..3 of both frame sets from level 0; false if the geometry does not fit (the caller then goes level by level)
+bool ofk_launch_pyr3(hipStream_t s, uint8_t *pyr0, uint8_t *pyr1, size_t stride, const ofk_levels &lv, int batch, int images)
+{
+    const int h = lv.h[0], w = lv.w[0];
+    if (lv.n < 3 || !pyr3_ok(h, w)) return false;
+    const int lanes = w / 16;
+    int nstrips = 1;
+    if (lanes > 64) { nstrips = 2; while (61 * 2 + 58 * (nstrips - 2) < lanes) ++nstrips; }
+    const int total = ((h >> 1) + 3 + 3) / 4 * 4;               // steps 0 .. n1 + 2, rounded up to whole groups of four
+    int nchunks = (2048 + images * nstrips - 1) / (images * nstrips);      // >= 2048 waves x 8 KB of loads in flight covers the HBM latency;
+                                                                           // more chunks only add warm-up rows (measured: 2 chunks 71 %, 4 chunks 69 %, 8 chunks 61 % of the HBM roof)
+    const int maxchunks = total / 32 > 1 ? total / 32 : 1;                 // chunks of at least 32 steps (12 warm-up steps each)
+    nchunks = nchunks < 1 ? 1 : nchunks > maxchunks ? maxchunks : nchunks;
+    if (const char *e = getenv("OFK_PYR3_CHUNKS")) { const int v = atoi(e); if (v >= 1 && v <= maxchunks) nchunks = v; }   // tuning knob
+    int steps = ((total + nchunks - 1) / nchunks + 3) / 4 * 4;
+    nchunks = (total + steps - 1) / steps;
+    p3_args A = {pyr0, pyr1 ? pyr1 : pyr0, stride, lv.off[1], lv.off[2], lv.off[3], h, w, batch, steps, nstrips, nchunks};
+    dim3 grid((nstrips * nchunks + 3) / 4, images);
+    hipLaunchKernelGGL(k_pyr3_stream, grid, dim3(256), 0, s, A);
+    return true;
+}
+
 static bool pyr_stream_ok(int h, int w) { return (w & 7) == 0 && w >= 16 && h >= 4; }
 
 static void launch_pyr_stream(hipStream_t s, const uint8_t *src0, const uint8_t *src1, size_t src_stride, int h, int w,

@@ -413,7 +413,10 @@ static int check_lk(ofk_ctx *c, int h, int w, int win, int max_level)
 // builds levels 1..L of both resident pyramids
 static void build_pyramids(ofk_ctx *c, const ofk_levels &lv, int batch, int which_mask)
 {
-    for (int l = 1; l <= lv.n; ++l) {
+    int l0 = 1;                                                  // levels 1..3 in one pass where the geometry allows it
+    if (which_mask == 3 ? ofk_launch_pyr3(c->stream, c->pyr[0], c->pyr[1], c->pyr_stride, lv, batch, 2 * batch)
+                        : ofk_launch_pyr3(c->stream, c->pyr[which_mask == 1 ? 0 : 1], nullptr, c->pyr_stride, lv, batch, batch)) l0 = 4;
+    for (int l = l0; l <= lv.n; ++l) {
         if (which_mask == 3)
             ofk_launch_pyr_down2(c->stream, c->pyr[0] + lv.off[l - 1], c->pyr[1] + lv.off[l - 1], c->pyr_stride, lv.h[l - 1], lv.w[l - 1],
                                  c->pyr[0] + lv.off[l], c->pyr[1] + lv.off[l], c->pyr_stride, batch);
@@ -449,6 +452,29 @@ extern "C" int ofk_lk_pyr(ofk_ctx *c, const uint8_t *prev, const uint8_t *next, 
                                 hipMemcpyDeviceToHost, c->stream));
     OFK_HIP(c, hipMemcpy2DAsync(status, pts_stride, c->status, c->max_pts, pts_stride, batch, hipMemcpyDeviceToHost, c->stream));
     return d2h(c, err, c->err, (size_t)c->max_pts * 4, (size_t)pts_stride * 4, batch);
+}
+
+// levels 1..L of a batch of gray images, built exactly as ofk_lk_pyr / ofk_pairs_run build them (three levels per pass where the
+// geometry allows it); out = per image the levels 1..L back to back, tightly packed
+extern "C" int ofk_pyramid_u8(ofk_ctx *c, const uint8_t *gray, int batch, int h, int w, int max_level, uint8_t *out, int *levels_built)
+{
+    TRY(check_geom(c, batch, h, w, "ofk_pyramid_u8"));
+    if (!gray || !out) return ofk_fail(c, OFK_E_INVALID, "ofk_pyramid_u8: NULL buffer");
+    if (max_level < 0 || max_level > c->max_level) return ofk_fail(c, OFK_E_INVALID, "max_level %d outside 0..%d", max_level, c->max_level);
+    const ofk_levels lv = ofk_make_levels(h, w, 0, max_level);
+    TRY(h2d(c, c->pyr[0], c->pyr_stride, gray, (size_t)h * w, batch));
+    build_pyramids(c, lv, batch, 1);
+    TRY(check_launch(c, "pyramid"));
+    size_t total = 0, o = 0;
+    for (int l = 1; l <= lv.n; ++l) total += (size_t)lv.h[l] * lv.w[l];
+    for (int l = 1; l <= lv.n; ++l) {
+        const size_t px = (size_t)lv.h[l] * lv.w[l];
+        OFK_HIP(c, hipMemcpy2DAsync(out + o, total, c->pyr[0] + lv.off[l], c->pyr_stride, px, batch, hipMemcpyDeviceToHost, c->stream));
+        o += px;
+    }
+    OFK_HIP(c, hipStreamSynchronize(c->stream));
+    if (levels_built) *levels_built = lv.n;
+    return OFK_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ estimation entry points
@@ -809,7 +835,7 @@ extern "C" int ofk_pairs_run(ofk_ctx *c, const ofk_params *p)
         }
         {
             StageTimer t(c, OFK_STAGE_PYR, sa);
-            for (int l = 1; l <= lv.n; ++l)
+            for (int l = ofk_launch_pyr3(sa, pyr0, pyr1, c->pyr_stride, lv, nb, 2 * nb) ? 4 : 1; l <= lv.n; ++l)
                 ofk_launch_pyr_down2(sa, pyr0 + lv.off[l - 1], pyr1 + lv.off[l - 1], c->pyr_stride, lv.h[l - 1], lv.w[l - 1], pyr0 + lv.off[l],
                                      pyr1 + lv.off[l], c->pyr_stride, nb);
         }
@@ -906,7 +932,7 @@ static int stream_ingest(ofk_ctx *c, int k, const uint8_t *bgr, int batch, int h
 {
     TRY(h2d(c, c->bgr[k], c->bgr_stride, bgr, (size_t)h * w * 3, batch));
     ofk_launch_gray(c->stream, c->bgr[k], c->bgr_stride, c->pyr[k], c->pyr_stride, batch, h, w);
-    for (int l = 1; l <= lv.n; ++l)
+    for (int l = ofk_launch_pyr3(c->stream, c->pyr[k], nullptr, c->pyr_stride, lv, batch, batch) ? 4 : 1; l <= lv.n; ++l)
         ofk_launch_pyr_down(c->stream, c->pyr[k] + lv.off[l - 1], c->pyr_stride, lv.h[l - 1], lv.w[l - 1], c->pyr[k] + lv.off[l],
                             c->pyr_stride, batch);
     return OFK_OK;

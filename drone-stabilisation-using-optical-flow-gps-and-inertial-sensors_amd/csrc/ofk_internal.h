@@ -93,6 +93,7 @@ void ofk_launch_pyr_down(hipStream_t s, const uint8_t *src, size_t src_stride, i
                          size_t dst_stride, int batch);
 void ofk_launch_pyr_down2(hipStream_t s, const uint8_t *src0, const uint8_t *src1, size_t src_stride, int h, int w,
                           uint8_t *dst0, uint8_t *dst1, size_t dst_stride, int batch);
+bool ofk_launch_pyr3(hipStream_t s, uint8_t *pyr0, uint8_t *pyr1, size_t stride, const ofk_levels &lv, int batch, int images);
 void ofk_launch_scharr(hipStream_t s, const uint8_t *src, size_t src_stride, int h, int w, int16_t *dxdy,
                        size_t dst_stride_elems, int batch);
 int  ofk_launch_mineig(hipStream_t s, const uint8_t *gray, size_t gray_stride, int h, int w, int block, float *eig,

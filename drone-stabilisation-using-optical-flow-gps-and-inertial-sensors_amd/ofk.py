@@ -23,7 +23,7 @@ STAGES = ("gray", "pyr", "eig", "nms", "select", "lk", "solve")
 # every entry point include/ofk.h declares (tests/test_abi.py checks the library exports them all)
 SYMBOLS = (
     "ofk_version", "ofk_last_error", "ofk_device_count", "ofk_create", "ofk_destroy", "ofk_sync", "ofk_device_sync",
-    "ofk_gray_bgr8", "ofk_pyr_down_u8", "ofk_scharr_s16", "ofk_mineig_response", "ofk_select_corners",
+    "ofk_gray_bgr8", "ofk_pyr_down_u8", "ofk_pyramid_u8", "ofk_scharr_s16", "ofk_mineig_response", "ofk_select_corners",
     "ofk_good_features", "ofk_lk_pyr", "ofk_flow_model", "ofk_feasibility", "ofk_velocity_solve", "ofk_imu_propagate",
     "ofk_post_solve", "ofk_kf_predict_update", "ofk_of_simulation", "ofk_associate_sensors", "ofk_feature_eval", "ofk_d_split", "ofk_pairs_upload", "ofk_pairs_upload_jpeg", "ofk_jpeg_info", "ofk_jpeg_decode_bgr8", "ofk_pairs_set_sensors",
     "ofk_pairs_run", "ofk_pairs_download", "ofk_pairs_export_records_f32", "ofk_stream_begin", "ofk_stream_step",
@@ -80,6 +80,7 @@ def load_library():
         L.ofk_destroy.argtypes = [vp]; L.ofk_sync.argtypes = [vp]
         L.ofk_gray_bgr8.argtypes = [vp, vp, i, i, i, vp]
         L.ofk_pyr_down_u8.argtypes = [vp, vp, i, i, i, vp]
+        L.ofk_pyramid_u8.argtypes = [vp, vp, i, i, i, i, vp, C.POINTER(i)]
         L.ofk_scharr_s16.argtypes = [vp, vp, i, i, i, vp]
         L.ofk_mineig_response.argtypes = [vp, vp, i, i, i, i, vp]
         L.ofk_select_corners.argtypes = [vp, vp, vp, i, i, i, i, d, d, vp, vp]
@@ -198,6 +199,29 @@ class Context:
         with self._lock:
             self._ck(self._L.ofk_pyr_down_u8(self._h, _p(src), B, h, w, _p(out)))
         return out[0] if single else out
+
+    def pyramid(self, gray, max_level):
+        """Levels 1..L of the pyramid calcOpticalFlowPyrLK builds: list of [B,h_l,w_l] uint8 arrays (a list of 2-D arrays for one image)."""
+        gray, single = self._batched(gray, 2)
+        gray = _arr(gray, np.uint8)
+        B, h, w = gray.shape
+        shapes, hh, ww = [], h, w
+        for _ in range(int(max_level)):
+            hh, ww = (hh + 1) // 2, (ww + 1) // 2
+            shapes.append((hh, ww))
+        total = sum(a * b for a, b in shapes)
+        out = np.empty((B, max(total, 1)), np.uint8)
+        built = C.c_int()
+        with self._lock:
+            self._ck(self._L.ofk_pyramid_u8(self._h, _p(gray), B, h, w, int(max_level), _p(out), C.byref(built)))
+        levels, o = [], 0
+        stride = sum(a * b for a, b in shapes[:built.value])
+        flat = out.reshape(-1)[:B * stride].reshape(B, stride) if stride else out[:, :0]
+        for (a, b) in shapes[:built.value]:
+            lvl = flat[:, o:o + a * b].reshape(B, a, b)
+            levels.append(lvl[0] if single else lvl)
+            o += a * b
+        return levels
 
     def scharr(self, gray):
         gray, single = self._batched(gray, 2)

@@ -63,6 +63,11 @@ int ofk_gray_bgr8(ofk_ctx *ctx, const uint8_t *bgr, int batch, int h, int w, uin
  * separable [1 4 6 4 1]/16, REFLECT_101, dst = ((h+1)/2, (w+1)/2). */
 int ofk_pyr_down_u8(ofk_ctx *ctx, const uint8_t *src, int batch, int h, int w, uint8_t *dst);
 
+/* Gaussian pyramid (cv2.buildOpticalFlowPyramid without the derivative planes; what calcOpticalFlowPyrLK builds internally,
+ * of_module.py:88): levels 1..max_level of every image by repeated pyrDown, stopping early when a level would be empty.
+ * out: per image the levels back to back, tightly packed ((h+1)/2 x (w+1)/2, ...); *levels_built = number of levels written. */
+int ofk_pyramid_u8(ofk_ctx *ctx, const uint8_t *gray, int batch, int h, int w, int max_level, uint8_t *out, int *levels_built);
+
 /* Scharr derivatives of one pyramid level as calcOpticalFlowPyrLK computes them (same call sites):
  * dxdy [batch][h][w][2] int16 = (dx, dy), REFLECT_101 at the image border. */
 int ofk_scharr_s16(ofk_ctx *ctx, const uint8_t *gray, int batch, int h, int w, int16_t *dxdy);

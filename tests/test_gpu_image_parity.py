@@ -46,6 +46,28 @@ def test_pyr_down(gpu_ctx, shape):
     assert np.all(gpu_ctx.pyr_down(np.full(shape, 77, np.uint8)) == 77)
 
 
+# fused three-level pass (widths % 16 == 0, heights % 8 == 0, >= 64 x 32): one strip, two strips (1920), three and more strips,
+# chunk boundaries at several heights; other shapes take the level-by-level kernels through the same entry point
+PYR3_SHAPES = [(32, 64), (40, 976), (48, 992), (56, 1936), (1080, 1920), (64, 2000), (264, 4000), (544, 1024), (136, 80), (30, 64), (32, 72)]
+
+
+@pytest.mark.parametrize("shape", PYR3_SHAPES)
+def test_pyramid_levels(ofk, shape):
+    h, w = shape
+    levels = 4 if min(h, w) >= 64 else 3
+    src = rand_u8((3, h, w), 11)
+    src[1] = 255; src[2, ::2] = 0                              # saturated and striped images: rounding and mirrored borders
+    ctx = ofk.Context(0, w, h, 3, 16, levels)
+    got = ctx.pyramid(src, levels)
+    assert len(got) == levels
+    for b in range(3):
+        ref = src[b]
+        for l in range(levels):
+            ref = io.pyr_down(ref)
+            assert np.array_equal(got[l][b], ref), (b, l)
+    ctx.close()
+
+
 @pytest.mark.parametrize("shape", SHAPES + [(2, 2), (5, 130)])
 def test_scharr(gpu_ctx, shape):
     src = rand_u8((2,) + shape, 3)

@@ -13,7 +13,7 @@ import glob
 import json
 import sys
 
-STAGE_OF = [("k_gray_bgr8", "gray"), ("k_pyr_down", "pyr"), ("k_mineig", "eig"), ("k_select", "select"), ("k_lk", "lk"),
+STAGE_OF = [("k_gray_bgr8", "gray"), ("k_pyr_down", "pyr"), ("k_pyr3", "pyr"), ("k_mineig", "eig"), ("k_select", "select"), ("k_lk", "lk"),
             ("k_pairs_solve", "solve")]
 
 
