@@ -279,6 +279,13 @@ def main():
                                     "algorithmic_GBps": round(ab[s] * B / (iso[s][0] / args.steps * 1e-3) / 1e9, 2) if iso[s][0] > 0 else None,
                                     "hbm_frac": round(ab[s] * B / (iso[s][0] / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if iso[s][0] > 0 else None}
                                 for s in ofk.STAGES},
+            # BASELINE.json's target names the pyramid construction: its roofline from this run's serial pass (alone on the chip)
+            "north_star_kernel": {"kernel": "k_pyr3_stream (pyramid levels 1-3 of both frames, one launch)", "bound": "hbm",
+                                  "achieved": round(ab["pyr"] * B * args.steps / (iso["pyr"][0] * 1e-3) / 1e9, 1) if iso["pyr"][0] > 0 else None,
+                                  "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": round(ab["pyr"] * B * args.steps / (iso["pyr"][0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if iso["pyr"][0] > 0 else None,
+                                  "avg_ms": round(iso["pyr"][0] / max(1, iso["pyr"][1]), 4),
+                                  "traffic": pmc_traffic("pyr", B * args.steps / max(1, iso["pyr"][1]))},
             "velocity_sample": [round(float(x), 6) for x in rec[0, :3]],
             "velocity_truth": list(truth["v"]),
         }
