@@ -270,7 +270,7 @@ def main():
                          "algorithmic_bytes_per_launch": int(ab[dom] * B / slices), "avg_ms": round(dom_ms, 4),
                          # the response and LK kernels are bound by VALU issue, not by HBM: their real roof, from the
                          # committed SQ_INSTS_VALU counts (profiles/r01_valu_pmc.json) and this run's isolated kernel time
-                         "valu": valu_roof(dom, B / slices, iso[dom][0] / max(1, iso[dom][1]))},
+                         "valu": valu_roof(dom, B * args.steps / max(1, iso[dom][1]), iso[dom][0] / max(1, iso[dom][1]))},
             "pipeline_algorithmic_GBps": round(sum(ab.values()) * world * B * args.steps / dt / 1e9, 1),
             "stages": stages,
             # every stage alone on the chip (serial pass outside the timed region) and the HBM-bound group BASELINE.json's
