@@ -29,7 +29,8 @@
 #include <thread>
 #include <vector>
 
-#define JCH 256                 // entropy bytes per decoder thread
+#define JCH 256                 // entropy bytes per decoder thread when there is enough data; halved down to JCH_MIN for small
+#define JCH_MIN 64              // batches (a single 1080p frame: 7000 threads of 64 bytes), where latency counts, not throughput
 #define JB0 4                   // a symbol belongs to chunk i if the byte cursor after the refill is in [i*JCH + JB0, (i+1)*JCH + JB0)
                                 // (the guess of chunk i starts with the cursor at i*JCH + 4 after its first refill)
 #define JTPB 256                // decoder threads per workgroup (chunks of ONE image: the tables live in LDS)
@@ -46,7 +47,7 @@ struct jpeg_tab {               // per image
 };
 
 struct jpeg_geom {
-    int w, h, ncomp, hmax, vmax, mcux, mcuy, bpm, nblk;
+    int w, h, ncomp, hmax, vmax, mcux, mcuy, bpm, nblk, jch;  // jch: bytes per decoder thread of this batch
     int blk_comp[10];           // component of block j of an MCU
     int comp_off[3], comp_nb[3];
     int pw[3], ph[3];           // plane sizes (whole MCUs)
@@ -152,9 +153,9 @@ __device__ inline int jrun(const jlds &T, jrd &r, uint32_t bnext, const jpeg_geo
     return done;
 }
 
-__device__ inline void jstart(jrd &r, uint32_t chunk)
+__device__ inline void jstart(jrd &r, uint32_t chunk, int jch)
 {   // chunk 0: the true start of the scan; otherwise the guess "a block starts at the first byte of the chunk"
-    r.pos = chunk * JCH; r.nb = 0; r.buf = 0; r.k = 0; r.blk = 0;
+    r.pos = chunk * (uint32_t)jch; r.nb = 0; r.buf = 0; r.k = 0; r.blk = 0;
     if (chunk && r.d[r.pos] == 0 && r.d[r.pos - 1] == 0xFF) ++r.pos;
     jrefill(r);
 }
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(JTPB) void k_jpeg_sync(const jpeg_tab *__restrict__
     jrd r;
     r.d = ent + t->ent_off;
     if (iter == 0) {
-        jstart(r, i);
+        jstart(r, i, g.jch);
         e = jpack(r);
     } else {
         junpack(r, e);
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(JTPB) void k_jpeg_sync(const jpeg_tab *__restrict__
     }
     used[o] = e;
     jemit_none em;
-    const int n = jrun(T, r, (uint32_t)(i + 1) * JCH + JB0, g, 0x7fffffff, em);
+    const int n = jrun(T, r, (uint32_t)(i + 1) * (uint32_t)g.jch + JB0, g, 0x7fffffff, em);
     count[o] = n;
     const unsigned long long x = jpack(r);
     if (iter == 0) state[o] = x;
@@ -269,11 +270,11 @@ __global__ __launch_bounds__(JTPB) void k_jpeg_write(const jpeg_tab *__restrict_
     if (n0 >= g.nblk) return;
     jrd r;
     r.d = ent + t->ent_off;
-    if (i == 0) jstart(r, 0);
+    if (i == 0) jstart(r, 0, g.jch);
     else { junpack(r, state[(size_t)b * nch_max + i - 1]); jrebuild(r); }
     for (int q = 0; q < JBLK_PITCH / 2; ++q) ((uint32_t *)rows[threadIdx.x])[q] = 0;
     jemit_store em = {rows[threadIdx.x], coef + (size_t)b * g.nblk * 64, n0, g.nblk, r.k != 0};
-    const int n = jrun(T, r, (uint32_t)(i + 1) * JCH + JB0, g, g.nblk - n0, em);
+    const int n = jrun(T, r, (uint32_t)(i + 1) * (uint32_t)g.jch + JB0, g, g.nblk - n0, em);
     if (r.k != 0 && n0 + n < g.nblk) em.scatter(n0 + n);          // the block still in progress continues in the next chunk
     if (n0 + n == g.nblk && n > 0) {                              // this thread finished the last block: where the scan ended
         endinfo[b * 2] = (int)(r.pos - (uint32_t)(r.nb >> 3));
@@ -650,10 +651,15 @@ int ofk_jpeg_decode_device(ofk_ctx *c, const uint8_t *const *jpeg, const size_t 
             free(jh); return rc;
         }
         ent_total += JPAD(jh[b].ent_len);
-        const int nch = (int)((jh[b].ent_len + JB0) / JCH) + 1;
+    }
+    jpeg_geom g = jgeom(jh[0]);
+    g.jch = JCH;
+    while (g.jch > JCH_MIN && ent_total / (size_t)g.jch < 131072) g.jch >>= 1;   // keep >= 128 k decoder threads if the data allows
+    if (const char *e = getenv("OFK_JPEG_CHUNK")) { const int v = atoi(e); if (v == 64 || v == 128 || v == 256) g.jch = v; }   // tuning knob
+    for (int b = 0; b < batch; ++b) {
+        const int nch = (int)((jh[b].ent_len + JB0) / (size_t)g.jch) + 1;
         if (nch > nch_max) nch_max = nch;
     }
-    const jpeg_geom g = jgeom(jh[0]);
     if (dst && (size_t)g.w * g.h > dst_capacity_px) { const int rc = ofk_fail(c, OFK_E_INVALID, "ofk_jpeg: %dx%d frames exceed the destination", g.w, g.h); free(jh); return rc; }
     // pinned staging: tables + entropy segments, one H2D copy
     const size_t tab_bytes = jup(sizeof(jpeg_tab) * (size_t)batch, 256);
@@ -682,7 +688,7 @@ int ofk_jpeg_decode_device(ofk_ctx *c, const uint8_t *const *jpeg, const size_t 
                 memcpy(t->q[cc], j.q[j.tq[cs]], 128);
             }
             t->ent_off = (uint32_t)eoff[b]; t->ent_len = (uint32_t)j.ent_len;
-            t->nch = (int)((j.ent_len + JB0) / JCH) + 1; t->pad = 0;
+            t->nch = (int)((j.ent_len + JB0) / (size_t)g.jch) + 1; t->pad = 0;
             memcpy(hent + eoff[b], j.ent, j.ent_len);
             memset(hent + eoff[b] + j.ent_len, 0, JPAD(j.ent_len) - j.ent_len);
         }
@@ -732,7 +738,8 @@ int ofk_jpeg_decode_device(ofk_ctx *c, const uint8_t *const *jpeg, const size_t 
     bool converged = nch_max == 1;
     while (!converged) {
         const int first = iter + 1;
-        const int burst = iter == 0 ? 3 : 1;                      // two iterations settle almost every stream, the third proves it
+        const int burst = iter == 0 ? 3 : 4;                      // two iterations settle most chunks, later ones the stragglers; an iteration
+                                                                  // past the fixed point costs ~10 us (its workgroups leave at once), a host round trip more
         for (int k = 0; k < burst; ++k) {
             ++iter;
             if (iter >= JMAX_ITERS) OFK_HIP(c, hipMemsetAsync(flags + JMAX_ITERS - 1, 0, 4, st));
