@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Throughput of the resident pair pipeline on the other BASELINE.json configurations (not the bench contract's line):
-C3 = 1024 x 640x480 pairs (+ a 6-state Kalman update per pair), C5 = 3840x2160 pairs, 2000 corners, 5-level pyramid.
-  python tools/bench_configs.py [c3] [c5]
+C3 = 1024 x 640x480 pairs (+ a 6-state Kalman update per pair), C4 = 1080p camera streams frame by frame (FlowStream),
+C5 = 3840x2160 pairs, 2000 corners, 5-level pyramid.
+  python tools/bench_configs.py [c3] [c4] [c5]
 """
 import os
 import sys
@@ -49,12 +50,37 @@ def run(name, w, h, batch, cfg, steps, kf=False):
     pipe.close()
 
 
+def run_stream(name, w, h, streams, cfg, frames):
+    """C4: `streams` camera streams, one new frame per stream and step (host BGR in, PCIe included): LK from the resident tracks,
+    velocity, status filter, masked re-detection, frame swap - pipeline.FlowStream / ofk_stream_step."""
+    import of_amd.ofk as ofk
+    from of_amd import synth
+    from of_amd.pipeline import FlowStream
+    pairs = [synth.render_pair(h, w, 500 + k) for k in range(streams)]
+    f0 = np.stack([p["prev"] for p in pairs]); f1 = np.stack([p["next"] for p in pairs])
+    sensors = np.concatenate([ofk.make_sensors(1, scaling=p["scaling"], cx=p["cx"], cy=p["cy"]) for p in pairs])
+    fs = FlowStream(w, h, batch=streams, cfg=cfg, min_features=cfg.max_corners // 2, mask_radius=10)
+    fs.begin(f0)
+    fs.step(f1, sensors)
+    t0 = time.perf_counter()
+    for k in range(frames):
+        rec, tracks, counts = fs.step(f0 if k & 1 else f1, sensors)
+    dt = (time.perf_counter() - t0) / frames
+    print(f"{name}: {streams} stream(s) {w}x{h}: {dt * 1e3:.3f} ms per step = {streams / dt:.0f} frames/s, tracks per stream {np.mean(counts):.0f} "
+          f"(a 30 fps camera leaves {1e3 / 30:.1f} ms per frame)", flush=True)
+    fs.close()
+
+
 def main():
     load_package()
     from of_amd.pipeline import PipelineConfig
-    which = sys.argv[1:] or ["c3", "c5"]
+    which = sys.argv[1:] or ["c3", "c4", "c5"]
     if "c3" in which:
         run("C3", 640, 480, 1024, PipelineConfig(max_corners=500, quality=0.01, min_distance=10, block_size=7, win=15, max_level=3), 10, kf=True)
+    if "c4" in which:
+        cfg4 = PipelineConfig(max_corners=500, quality=0.01, min_distance=10, block_size=7, win=15, max_level=3)
+        run_stream("C4", 1920, 1080, 1, cfg4, 60)
+        run_stream("C4x8", 1920, 1080, 8, cfg4, 30)
     if "c5" in which:
         run("C5", 3840, 2160, 32, PipelineConfig(max_corners=2000, quality=0.01, min_distance=10, block_size=7, win=15, max_level=5), 10)
 
