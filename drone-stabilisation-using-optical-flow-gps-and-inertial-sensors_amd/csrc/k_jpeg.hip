@@ -43,7 +43,7 @@ struct jpeg_tab {               // per image
     uint8_t vals[6][256];
     uint16_t q[3][64];          // natural order
     uint32_t ent_off, ent_len;  // entropy segment inside the batch's entropy buffer
-    int32_t nch, pad;
+    int32_t nch, ri;            // chunks of this image; restart interval in MCUs (0 = none)
 };
 
 struct jpeg_geom {
@@ -64,7 +64,7 @@ static const uint8_t h_zz[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 1
 // lanes), not by the latency of the byte reads, and the 42 KB of LDS cost two thirds of the occupancy.
 // The host pads every entropy segment with zeros up to JPAD(len): the reader needs no bounds checks.
 #define JPAD(len) (((size_t)(len) + 2 * JCH + 19) / JCH * JCH)
-struct jrd { const uint8_t *d; uint32_t pos; uint64_t buf; int nb; int k, blk; };
+struct jrd { const uint8_t *d; uint32_t pos; uint64_t buf; int nb, fake; int k, blk; };   // fake: virtual zero bits buffered while parked at RSTn
 
 struct jlds {
     uint16_t lut[6][512];
@@ -86,34 +86,45 @@ __device__ inline void jload_tables(jlds &T, const jpeg_tab *t)
 __device__ inline void jrefill(jrd &r)
 {
     while (r.nb <= 31) {
-        const uint32_t b = r.d[r.pos++];
-        if (b == 0xFF && r.d[r.pos] == 0) ++r.pos;                // stuffed zero (an FF in front of the zero padding counts as one too)
+        uint32_t b = 0;
+        if (r.fake) r.fake += 8;                                  // parked in front of a restart marker: zero bits, like libjpeg
+        else {
+            b = r.d[r.pos];
+            if (b != 0xFF) ++r.pos;
+            else {
+                const uint32_t n = r.d[r.pos + 1];
+                if (n == 0) r.pos += 2;                           // stuffed zero (an FF in front of the zero padding counts as one too)
+                else if ((n & 0xF8u) == 0xD0u) { b = 0; r.fake = 8; }      // RSTn: stay in front of it until the interval's bits are used up
+                else ++r.pos;
+            }
+        }
         r.buf = (r.buf << 8) | b;
         r.nb += 8;
     }
 }
 
-// the nb unread bits in front of byte cursor pos (walks back over stuffed zeros)
+// the nb unread bits in front of byte cursor pos: nb - fake real ones (walking back over stuffed zeros), then the virtual zeros
 __device__ inline void jrebuild(jrd &r)
 {
     uint64_t buf = 0;
     int got = 0;
+    const int real = r.nb - r.fake;
     uint32_t p = r.pos;
-    while (got < r.nb && p > 0) {
+    while (got < real && p > 0) {
         --p;
         uint32_t b = r.d[p];
         if (b == 0 && p > 0 && r.d[p - 1] == 0xFF) { --p; b = 0xFF; }
         buf |= (uint64_t)b << got;
         got += 8;
     }
-    r.buf = buf;
+    r.buf = buf << r.fake;
 }
 
 __device__ inline uint32_t jpeek(const jrd &r, int n) { return (uint32_t)(r.buf >> (r.nb - n)) & ((1u << n) - 1u); }
 __device__ inline int jextend(int v, int s) { return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; }
 
-__device__ inline uint64_t jpack(const jrd &r) { return ((uint64_t)r.pos << 32) | ((uint64_t)r.nb << 16) | ((uint64_t)r.k << 8) | (uint64_t)r.blk; }
-__device__ inline void junpack(jrd &r, uint64_t s) { r.pos = (uint32_t)(s >> 32); r.nb = (int)((s >> 16) & 63); r.k = (int)((s >> 8) & 63); r.blk = (int)(s & 15); }
+__device__ inline uint64_t jpack(const jrd &r) { return ((uint64_t)r.pos << 32) | ((uint64_t)(r.fake & 63) << 24) | ((uint64_t)r.nb << 16) | ((uint64_t)r.k << 8) | (uint64_t)r.blk; }
+__device__ inline void junpack(jrd &r, uint64_t s) { r.pos = (uint32_t)(s >> 32); r.fake = (int)((s >> 24) & 63); r.nb = (int)((s >> 16) & 63); r.k = (int)((s >> 8) & 63); r.blk = (int)(s & 15); }
 
 // Decodes symbols from a symbol boundary (reader refilled) until the byte cursor reaches `bnext` or `max_blocks` blocks are complete.
 // emit.coef(zigzag index, value) is called for every non-zero coefficient of the block in progress (DC as its difference),
@@ -136,6 +147,15 @@ __device__ inline int jrun(const jlds &T, jrd &r, uint32_t bnext, const jpeg_geo
             if (l > 16) { len = 16; sym = 0; }
             else { len = l; sym = T.vals[slot][((c16 >> (16 - l)) + T.valoff[slot][l]) & 255]; }
         }
+        if (r.fake && len > r.nb - r.fake) {
+            // Parked at a restart marker and the code would run into the virtual bits: what is left of the interval is its padding
+            // (1-bits, which are a proper prefix of every table's longest codes, never a code - T.81 Annex C), so the interval is
+            // complete (jdhuff.c process_restart): drop the padding, step over the marker, start the next MCU.  A decoder in
+            // step is at k = 0, blk = 0 here anyway; one that is out of step is in step from here on.
+            r.pos += 2; r.nb = 0; r.fake = 0; r.buf = 0; r.k = 0; r.blk = 0;
+            jrefill(r);
+            continue;
+        }
         r.nb -= len;
         const int run = r.k ? sym >> 4 : 0, s = sym & 15;
         if (s) {
@@ -155,8 +175,8 @@ __device__ inline int jrun(const jlds &T, jrd &r, uint32_t bnext, const jpeg_geo
 
 __device__ inline void jstart(jrd &r, uint32_t chunk, int jch)
 {   // chunk 0: the true start of the scan; otherwise the guess "a block starts at the first byte of the chunk"
-    r.pos = chunk * (uint32_t)jch; r.nb = 0; r.buf = 0; r.k = 0; r.blk = 0;
-    if (chunk && r.d[r.pos] == 0 && r.d[r.pos - 1] == 0xFF) ++r.pos;
+    r.pos = chunk * (uint32_t)jch; r.nb = 0; r.fake = 0; r.buf = 0; r.k = 0; r.blk = 0;
+    if (chunk && r.d[r.pos - 1] == 0xFF && (r.d[r.pos] == 0 || (r.d[r.pos] & 0xF8u) == 0xD0u)) ++r.pos;   // second byte of FF00 / RSTn
     jrefill(r);
 }
 
@@ -282,14 +302,16 @@ __global__ __launch_bounds__(JTPB) void k_jpeg_write(const jpeg_tab *__restrict_
     }
 }
 
-// DC prediction: inclusive prefix sum of the DC differences of one component in decode order (one workgroup per image x component)
-__global__ __launch_bounds__(1024) void k_jpeg_dc(jpeg_geom g, int16_t *__restrict__ coef)
+// DC prediction: inclusive prefix sum of the DC differences of one component in decode order (one workgroup per image x component),
+// restarted at every restart interval (segmented scan: flag = first block of an interval)
+__global__ __launch_bounds__(1024) void k_jpeg_dc(const jpeg_tab *__restrict__ tabs, jpeg_geom g, int16_t *__restrict__ coef)
 {
-    __shared__ int wsum[16];
+    __shared__ int wsum[16], wflag[16];
     __shared__ int carry;
     const int b = blockIdx.x, c = blockIdx.y;
     const int nbc = g.comp_nb[c], off = g.comp_off[c];
     const int total = g.mcux * g.mcuy * nbc;
+    const int seg = tabs[b].ri * nbc;                           // blocks of this component per restart interval (0: one interval)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int16_t *cf = coef + (size_t)b * g.nblk * 64;
     if (threadIdx.x == 0) carry = 0;
@@ -299,15 +321,19 @@ __global__ __launch_bounds__(1024) void k_jpeg_dc(jpeg_geom g, int16_t *__restri
         size_t n = 0;
         int v = 0;
         if (j < total) { n = (size_t)(j / nbc) * g.bpm + off + j % nbc; v = cf[n * 64]; }
-        int s = v;
-        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(s, d, 64); if (lane >= d) s += t; }
-        if (lane == 63) wsum[wv] = s;
+        int s = v, f = seg > 0 && j % seg == 0;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int ts = __shfl_up(s, d, 64), tf = __shfl_up(f, d, 64);
+            if (lane >= d) { if (!f) s += ts; f |= tf; }
+        }
+        if (lane == 63) { wsum[wv] = s; wflag[wv] = f; }
         __syncthreads();
-        int pre = carry;
-        for (int k = 0; k < wv; ++k) pre += wsum[k];
-        if (j < total) cf[n * 64] = (int16_t)(pre + s);
+        int pre = carry;                                        // sum since the last interval start in front of this wave
+        for (int k = 0; k < wv; ++k) pre = wflag[k] ? wsum[k] : pre + wsum[k];
+        const int r = f ? s : pre + s;
+        if (j < total) cf[n * 64] = (int16_t)r;
         __syncthreads();
-        if (threadIdx.x == 1023) carry = pre + s;
+        if (threadIdx.x == 1023) carry = r;
         __syncthreads();
     }
 }
@@ -486,7 +512,7 @@ __global__ __launch_bounds__(256) void k_jpeg_color(jpeg_geom g, const uint8_t *
 
 // ------------------------------------------------------------------------------------------------ host: marker segments
 struct jhost {
-    int w, h, ncomp, hs[3], vs[3], tq[3], td[3], ta[3];
+    int w, h, ncomp, hs[3], vs[3], tq[3], td[3], ta[3], ri;
     uint16_t q[4][64]; int qok[4];
     uint8_t bits[2][4][17], vals[2][4][256]; int hok[2][4];
     const uint8_t *ent; size_t ent_len;
@@ -545,7 +571,8 @@ static const char *jparse(const uint8_t *d, size_t n, jhost *j)
         } else if (m >= 0xC2 && m <= 0xCF && m != 0xC8 && m != 0xCC) {
             return "only baseline / extended-sequential Huffman JPEG is supported (progressive, lossless and arithmetic coding are not)";
         } else if (m == 0xDD) {
-            if (sl < 2 || ((s[0] << 8) | s[1]) != 0) return "restart intervals are not supported";
+            if (sl < 2) return "bad DRI";
+            j->ri = (s[0] << 8) | s[1];
         } else if (m == 0xDA) {
             if (!sof || sl < 1 || s[0] != j->ncomp || sl < 4 + 2 * (size_t)j->ncomp) return "unsupported scan header (one interleaved scan expected)";
             for (int c = 0; c < j->ncomp; ++c) {
@@ -560,7 +587,7 @@ static const char *jparse(const uint8_t *d, size_t n, jhost *j)
                 if (!f) { e = n; break; }
                 e = (size_t)(f - d);
                 if (e + 1 >= n) { e = n; break; }
-                if (d[e + 1] != 0x00) break;
+                if (d[e + 1] != 0x00 && !(j->ri && (d[e + 1] & 0xF8) == 0xD0)) break;    // RSTn markers belong to the scan
                 e += 2;
             }
             j->ent = d + e0; j->ent_len = e - e0;
@@ -688,7 +715,7 @@ int ofk_jpeg_decode_device(ofk_ctx *c, const uint8_t *const *jpeg, const size_t 
                 memcpy(t->q[cc], j.q[j.tq[cs]], 128);
             }
             t->ent_off = (uint32_t)eoff[b]; t->ent_len = (uint32_t)j.ent_len;
-            t->nch = (int)((j.ent_len + JB0) / (size_t)g.jch) + 1; t->pad = 0;
+            t->nch = (int)((j.ent_len + JB0) / (size_t)g.jch) + 1; t->ri = j.ri;
             memcpy(hent + eoff[b], j.ent, j.ent_len);
             memset(hent + eoff[b] + j.ent_len, 0, JPAD(j.ent_len) - j.ent_len);
         }
@@ -753,7 +780,7 @@ int ofk_jpeg_decode_device(ofk_ctx *c, const uint8_t *const *jpeg, const size_t 
     }
     hipLaunchKernelGGL(k_jpeg_scan, dim3(batch), dim3(1024), 0, st, dt, nch_max, count, base);
     hipLaunchKernelGGL(k_jpeg_write, dgrid, dim3(JTPB), 0, st, dt, dent, g, nch_max, state, base, coef, endinfo);
-    hipLaunchKernelGGL(k_jpeg_dc, dim3(batch, g.ncomp), dim3(1024), 0, st, g, coef);
+    hipLaunchKernelGGL(k_jpeg_dc, dim3(batch, g.ncomp), dim3(1024), 0, st, dt, g, coef);
     hipLaunchKernelGGL(k_jpeg_idct, dim3((g.nblk + 31) / 32, batch), dim3(256), 0, st, dt, g, coef, planes);
     hipLaunchKernelGGL(k_jpeg_color, dim3((g.w + 511) / 512, (g.h + 3) / 4, batch), dim3(64, 4), 0, st, g, planes, dst, dst_stride);
     int *hend = (int *)malloc(B * 8);

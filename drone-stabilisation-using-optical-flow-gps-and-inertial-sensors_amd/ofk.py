@@ -53,8 +53,8 @@ def jpeg_info(stream):
     h, w, n = C.c_int(), C.c_int(), C.c_int()
     rc = load_library().ofk_jpeg_info(data, len(data), C.byref(h), C.byref(w), C.byref(n))
     if rc != 0:
-        raise OfkError(rc, "not a JPEG stream the decoder supports (8-bit baseline Huffman, gray or YCbCr 4:4:4/4:2:2/4:2:0, "
-                           "no restart intervals)")
+        raise OfkError(rc, "not a JPEG stream the decoder supports (8-bit baseline Huffman, one interleaved scan, gray or YCbCr "
+                           "4:4:4/4:2:2/4:2:0)")
     return h.value, w.value, n.value
 
 

@@ -241,8 +241,8 @@ int ofk_stream_step(ofk_ctx *ctx, const uint8_t *next_bgr, const double *sensors
 
 /* ---- compressed-image ingest (cv2.imdecode of the reference's CompressedImage callback, velocity_measurment_node.py:112) ----
  * ofk_jpeg_info: header fields of a JPEG stream (host only; no context, no GPU).  OFK_E_INVALID if the stream is not one the decoder
- * accepts: 8-bit baseline / extended-sequential Huffman, one interleaved scan, gray or YCbCr 4:4:4 / 4:2:2 / 4:2:0, no restart
- * intervals.
+ * accepts: 8-bit baseline / extended-sequential Huffman, one interleaved scan, gray or YCbCr 4:4:4 / 4:2:2 / 4:2:0, with or
+ * without restart intervals.
  * ofk_jpeg_decode_bgr8: decodes `batch` streams of equal size and sampling on the device into bgr [batch][h][w][3] (host; gray
  * streams are replicated over the three channels like cv2.IMREAD_COLOR).  Bit-identical to libjpeg's default decompressor (ISLOW
  * IDCT, fancy upsampling) - what cv::imdecode returns.  Entropy decoding runs on the GPU too (self-synchronising chunked Huffman

@@ -14,7 +14,8 @@
  *
  * Scope (everything else is refused with a negative return code): 8-bit baseline / extended-sequential Huffman (SOF0, SOF1), one
  * interleaved scan, 1 component (gray) or 3 components YCbCr with luma sampling 1x1 (4:4:4), 2x1 (4:2:2) or 2x2 (4:2:0) and 1x1
- * chroma, no restart intervals. */
+ * chroma.  Restart intervals (DRI / RSTn, T.81 F.2.2.4 + E.2.4; jdhuff.c process_restart): the bit buffer is dropped, the marker
+ * skipped and the DC predictors reset every `ri` MCUs. */
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -29,6 +30,7 @@ typedef struct {
     int w, h, ncomp;
     int hs[3], vs[3], tq[3], td[3], ta[3];
     int hmax, vmax, mcux, mcuy, bpm;            /* MCUs per row / column, blocks per MCU */
+    int ri;                                     /* restart interval in MCUs (0 = none) */
     uint16_t q[4][64];                          /* natural order */
     int qok[4];
     orc_htab dc[4], ac[4];
@@ -99,13 +101,14 @@ static int parse(const uint8_t *d, size_t n, orc_jpeg *j)
         } else if (m >= 0xC2 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
             return -7;                                          /* progressive, lossless, arithmetic ... */
         } else if (m == 0xDD) {
-            if (sl < 2 || ((s[0] << 8) | s[1]) != 0) return -8; /* restart intervals */
+            if (sl < 2) return -8;
+            j->ri = (s[0] << 8) | s[1];
         } else if (m == 0xDA) {                                 /* SOS */
             if (!sof || sl < 1 || s[0] != j->ncomp || sl < 4 + 2 * (size_t)j->ncomp) return -9;
             for (int c = 0; c < j->ncomp; ++c) { j->td[c] = s[2 + 2 * c] >> 4; j->ta[c] = s[2 + 2 * c] & 15; if (j->td[c] > 3 || j->ta[c] > 3) return -9; }
             j->ent = d + i + L;
             size_t e = i + L;
-            while (e + 1 < n && !(d[e] == 0xFF && d[e + 1] != 0x00)) ++e;       /* up to the next marker */
+            while (e + 1 < n && !(d[e] == 0xFF && d[e + 1] != 0x00 && !(d[e + 1] >= 0xD0 && d[e + 1] <= 0xD7))) ++e;   /* up to the next marker that is not RSTn */
             if (e + 1 >= n) e = n;
             j->ent_len = e - (i + L);
             break;
@@ -162,7 +165,12 @@ static int entropy(const orc_jpeg *j, int16_t *coef)
     const size_t nmcu = (size_t)j->mcux * j->mcuy;
     memset(coef, 0, nmcu * j->bpm * 64 * sizeof(int16_t));
     int16_t *blk = coef;
-    for (size_t m = 0; m < nmcu; ++m)
+    for (size_t m = 0; m < nmcu; ++m) {
+        if (j->ri && m && m % (size_t)j->ri == 0) {             /* process_restart */
+            b.nb = 0; b.buf = 0;
+            if (b.hit_marker && b.pos < b.n && b.p[b.pos] >= 0xD0 && b.p[b.pos] <= 0xD7) { ++b.pos; b.hit_marker = 0; }
+            pred[0] = pred[1] = pred[2] = 0;
+        }
         for (int c = 0; c < j->ncomp; ++c)
             for (int k2 = 0; k2 < j->hs[c] * j->vs[c]; ++k2, blk += 64) {
                 int s = decode(&b, &j->dc[j->td[c]]);
@@ -182,6 +190,7 @@ static int entropy(const orc_jpeg *j, int16_t *coef)
                     }
                 }
             }
+    }
     return 0;
 }
 

@@ -25,7 +25,7 @@ def scene(h, w, seed):
     return np.clip(img, 0, 255).astype(np.uint8)
 
 
-CASES = [  # name, h, w, mode, subsampling (0 = 4:4:4, 1 = 4:2:2, 2 = 4:2:0), quality
+CASES = [  # name, h, w, mode, subsampling (0 = 4:4:4, 1 = 4:2:2, 2 = 4:2:0), quality[, extra encoder options]
     ("c420_odd", 61, 97, "RGB", 2, 80),
     ("c420_ros", 240, 320, "RGB", 2, 80),          # compressed_image_transport's default quality
     ("c420_q100", 128, 160, "RGB", 2, 100),        # long Huffman codes, almost no zero runs
@@ -34,17 +34,23 @@ CASES = [  # name, h, w, mode, subsampling (0 = 4:4:4, 1 = 4:2:2, 2 = 4:2:0), qu
     ("c444", 40, 64, "RGB", 0, 90),
     ("gray", 70, 50, "L", None, 85),
     ("gray_ros", 240, 320, "L", None, 80),
+    ("c420_rst_rows", 240, 320, "RGB", 2, 80, {"restart_marker_rows": 1}),       # restart intervals: DRI + RSTn every MCU row
+    ("c420_rst_blocks", 61, 97, "RGB", 2, 85, {"restart_marker_blocks": 3}),     # ... every 3 MCUs (RST0..7 wrap around)
+    ("c444_rst_blocks", 40, 64, "RGB", 0, 90, {"restart_marker_blocks": 1}),
+    ("gray_rst_blocks", 70, 50, "L", None, 85, {"restart_marker_blocks": 5}),
 ]
 
 
 def main():
     out = {"libjpeg": np.array(f"libjpeg-turbo {features.version('libjpeg_turbo')} via Pillow"), "names": np.array([c[0] for c in CASES])}
-    for i, (name, h, w, mode, ss, q) in enumerate(CASES):
+    for i, case in enumerate(CASES):
+        name, h, w, mode, ss, q = case[:6]
         img = scene(h, w, 100 + i)
         if mode == "L":
             img = img[:, :, 1]
         buf = io.BytesIO()
         kw = {} if ss is None else {"subsampling": ss}
+        kw.update(case[6] if len(case) > 6 else {})
         Image.fromarray(img, mode).save(buf, "JPEG", quality=q, **kw)
         data = buf.getvalue()
         dec = np.asarray(Image.open(io.BytesIO(data)).convert("RGB" if mode == "RGB" else "L"))

@@ -85,10 +85,11 @@ def test_imdecode_facade(pkg, gold):
     assert cv2.imdecode(np.frombuffer(b"garbage", np.uint8), cv2.IMREAD_COLOR) is None
 
 
-def _encode(img, quality, subsampling=None):
+def _encode(img, quality, subsampling=None, **extra):
     Image = pytest.importorskip("PIL.Image")
     buf = io.BytesIO()
     kw = {} if subsampling is None else {"subsampling": subsampling}
+    kw.update(extra)
     Image.fromarray(img).save(buf, "JPEG", quality=quality, **kw)
     return buf.getvalue()
 
@@ -103,6 +104,24 @@ def test_device_decoder_vs_oracle_large(pkg, ofk, h, w, ss, q):
     if ss is None:
         frames = [np.ascontiguousarray(f[:, :, 1]) for f in frames]
     streams = [_encode(f, q, ss) for f in frames]
+    ctx = ofk.Context(0, w, h, 3, 64, 1)
+    out = ctx.jpeg_decode(streams)
+    for k in range(3):
+        assert np.array_equal(out[k], jo.decode(streams[k])), k
+    ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h,w,ss,opts", [(1080, 1920, 2, {"restart_marker_rows": 1}), (720, 1280, 2, {"restart_marker_blocks": 7}),
+                                         (480, 640, 1, {"restart_marker_blocks": 1}), (1080, 1920, None, {"restart_marker_rows": 4})])
+def test_device_decoder_restart_intervals(pkg, ofk, h, w, ss, opts):
+    """DRI / RSTn streams: every decoder thread that runs into a marker is in step from there on; DC prediction restarts per
+    interval (segmented scan).  Mixed with a stream without markers in one batch (the interval is a per-image property)."""
+    from of_amd import synth
+    frames = [synth.render_pair(h, w, 800 + k)["prev"] for k in range(3)]
+    if ss is None:
+        frames = [np.ascontiguousarray(f[:, :, 1]) for f in frames]
+    streams = [_encode(frames[0], 80, ss, **opts), _encode(frames[1], 80, ss), _encode(frames[2], 92, ss, **opts)]
     ctx = ofk.Context(0, w, h, 3, 64, 1)
     out = ctx.jpeg_decode(streams)
     for k in range(3):
