@@ -176,21 +176,8 @@ static int need_streams(ofk_ctx *c, int slices, bool overlap)
 {
     for (int k = 1; k < slices; ++k)
         if (!c->streams[k]) OFK_HIP(c, hipStreamCreateWithFlags(&c->streams[k], hipStreamNonBlocking));
-    // EXPERIMENT (env OFK_AUX_CUS=N, OFK_AUX_PATTERN=0|1): pin the auxiliary (HBM-bound) streams to N compute units
-    static const int aux_cus = getenv("OFK_AUX_CUS") ? atoi(getenv("OFK_AUX_CUS")) : 0;
-    static const int aux_pat = getenv("OFK_AUX_PATTERN") ? atoi(getenv("OFK_AUX_PATTERN")) : 0;
     for (int k = 0; k < slices && overlap; ++k)
-        if (!c->aux[k]) {
-            if (aux_cus <= 0) OFK_HIP(c, hipStreamCreateWithFlags(&c->aux[k], hipStreamNonBlocking));
-            else {
-                uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                for (int i = 0; i < aux_cus && i < 256; ++i) {
-                    const int bit = aux_pat == 0 ? i : (i * (256 / aux_cus)) % 256;
-                    mask[bit >> 5] |= 1u << (bit & 31);
-                }
-                OFK_HIP(c, hipExtStreamCreateWithCUMask(&c->aux[k], 8, mask));
-            }
-        }
+        if (!c->aux[k]) OFK_HIP(c, hipStreamCreateWithFlags(&c->aux[k], hipStreamNonBlocking));
     return OFK_OK;
 }
 
