@@ -129,7 +129,8 @@ extern "C" int ofk_create(int device, int max_w, int max_h, int max_batch, int m
     hipMemsetAsync(c->dev_flags, 0, 16, c->stream);
     hipMemsetAsync(c->counts, 0, B * 4, c->stream);
     hipMemsetAsync(c->sensors, 0, B * OFK_SENSOR_DOUBLES * 8, c->stream);
-    c->ev_cap = 4096;
+    c->ev_cap = 32768;                                           // stage timers between two ofk_profile_read calls (28 per step with two slices);
+                                                                 // the events themselves are created on first use
     c->ev = (hipEvent_t *)calloc(c->ev_cap, sizeof(hipEvent_t));
     c->ev_stage = (int *)calloc(c->ev_cap / 2, sizeof(int));
     hipStreamSynchronize(c->stream);
