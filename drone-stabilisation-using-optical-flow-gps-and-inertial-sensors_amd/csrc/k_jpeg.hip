@@ -388,23 +388,28 @@ __global__ __launch_bounds__(256) void k_jpeg_idct(const jpeg_tab *__restrict__ 
                                                    uint8_t *__restrict__ planes)
 {
     __shared__ int ws[32][72];
+    __shared__ int16_t cz[32][72];                                // the blocks as stored (zigzag order), one 16-byte load per lane
+    __shared__ uint16_t qs[3][64];
+    __shared__ uint8_t izz[64];
     const int b = blockIdx.y;
     const int lb = threadIdx.x >> 3, c = threadIdx.x & 7;
     const int n = blockIdx.x * 32 + lb;
     const bool live = n < g.nblk;
     int comp = 0, bx = 0, by = 0;
+    if (threadIdx.x < 192) qs[threadIdx.x >> 6][threadIdx.x & 63] = tabs[b].q[threadIdx.x >> 6][threadIdx.x & 63];
+    else izz[threadIdx.x - 192] = c_izz[threadIdx.x - 192];
+    if (live) *reinterpret_cast<uint4 *>(&cz[lb][8 * c]) = reinterpret_cast<const uint4 *>(coef + ((size_t)b * g.nblk + n) * 64)[c];
+    __syncthreads();
     if (live) {
-        const int m = n / g.bpm, j = n % g.bpm;
-        comp = g.blk_comp[j];
-        const int jj = j - g.comp_off[comp];
+        const int m = n / g.bpm, j = n % g.bpm, ny = g.comp_nb[0];
+        comp = j < ny ? 0 : j - ny + 1;
+        const int jj = comp == 0 ? j : 0;
         const int hs = comp == 0 ? g.hmax : 1;
         bx = (m % g.mcux) * hs + jj % hs;
         by = (m / g.mcux) * (comp == 0 ? g.vmax : 1) + jj / hs;
-        const int16_t *cf = coef + ((size_t)b * g.nblk + n) * 64;
-        const uint16_t *q = tabs[b].q[comp];
         int in[8], o[8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) in[r] = (int)cf[c_izz[r * 8 + c]] * (int)q[r * 8 + c];         // blocks are stored in zigzag order
+        for (int r = 0; r < 8; ++r) in[r] = (int)cz[lb][izz[r * 8 + c]] * (int)qs[comp][r * 8 + c];
         jidct8(in, o);
 #pragma unroll
         for (int r = 0; r < 8; ++r) ws[lb][r * 9 + c] = (o[r] + (1 << 10)) >> 11;
