@@ -21,8 +21,9 @@
 //   5. k_jpeg_idct: dequantisation + ISLOW IDCT, 8 lanes per block (columns, then rows through LDS) -> component planes.
 //   6. k_jpeg_color: fancy upsampling + colour conversion -> BGR8.
 // The decoder state at a symbol boundary is (byte cursor, bits left in the buffer, zigzag index, block-in-MCU); it is canonical —
-// a function of the true bit position only — because the bit buffer is refilled byte by byte to 25..32 bits before every symbol
-// and before every run of extra bits, so two decoders that agree on a symbol boundary agree on the whole state.
+// a function of the true bit position only — because the bit buffer is refilled byte by byte to 32..39 bits before every symbol
+// (enough for the longest code plus the longest run of extra bits), so two decoders that agree on a symbol boundary agree on
+// the whole state.  Restart markers (RSTn) are handled inside the same scheme, see jrefill / jrun.
 #include "ofk_internal.h"
 #include <string.h>
 #include <stdlib.h>
@@ -254,7 +255,12 @@ __global__ __launch_bounds__(1024) void k_jpeg_scan(const jpeg_tab *__restrict__
 struct jemit_store {
     int16_t *row;                                                 // this thread's LDS row (zigzag order, zero between blocks)
     int16_t *out; int n0, nblk; bool head_partial;
-    __device__ void coef(int k, int v) { row[k] = (int16_t)v; }
+    int16_t *dc; int cur;                                         // DC differences go to a dense array of their own (k_jpeg_dc scans it)
+    __device__ void coef(int k, int v)
+    {
+        row[k] = (int16_t)v;
+        if (k == 0 && n0 + cur < nblk) dc[n0 + cur] = (int16_t)v;
+    }
     __device__ void scatter(int n)
     {
         int16_t *dst = out + (size_t)n * 64;
@@ -263,6 +269,7 @@ struct jemit_store {
     __device__ void block(int done)
     {
         const int n = n0 + done;
+        cur = done + 1;
         if (n >= nblk) return;
         if (done == 0 && head_partial) { scatter(n); return; }
         const uint32_t *src = (const uint32_t *)row;
@@ -276,7 +283,7 @@ struct jemit_store {
 
 __global__ __launch_bounds__(JTPB) void k_jpeg_write(const jpeg_tab *__restrict__ tabs, const uint8_t *__restrict__ ent, jpeg_geom g, int nch_max,
                                                      const unsigned long long *__restrict__ state, const int *__restrict__ base,
-                                                     int16_t *__restrict__ coef, int *__restrict__ endinfo)
+                                                     int16_t *__restrict__ coef, int16_t *__restrict__ dcarr, int *__restrict__ endinfo)
 {
     __shared__ jlds T;
     __shared__ int16_t rows[JTPB][JBLK_PITCH];
@@ -293,7 +300,7 @@ __global__ __launch_bounds__(JTPB) void k_jpeg_write(const jpeg_tab *__restrict_
     if (i == 0) jstart(r, 0, g.jch);
     else { junpack(r, state[(size_t)b * nch_max + i - 1]); jrebuild(r); }
     for (int q = 0; q < JBLK_PITCH / 2; ++q) ((uint32_t *)rows[threadIdx.x])[q] = 0;
-    jemit_store em = {rows[threadIdx.x], coef + (size_t)b * g.nblk * 64, n0, g.nblk, r.k != 0};
+    jemit_store em = {rows[threadIdx.x], coef + (size_t)b * g.nblk * 64, n0, g.nblk, r.k != 0, dcarr + (size_t)b * g.nblk, 0};
     const int n = jrun(T, r, (uint32_t)(i + 1) * (uint32_t)g.jch + JB0, g, g.nblk - n0, em);
     if (r.k != 0 && n0 + n < g.nblk) em.scatter(n0 + n);          // the block still in progress continues in the next chunk
     if (n0 + n == g.nblk && n > 0) {                              // this thread finished the last block: where the scan ended
@@ -304,7 +311,7 @@ __global__ __launch_bounds__(JTPB) void k_jpeg_write(const jpeg_tab *__restrict_
 
 // DC prediction: inclusive prefix sum of the DC differences of one component in decode order (one workgroup per image x component),
 // restarted at every restart interval (segmented scan: flag = first block of an interval)
-__global__ __launch_bounds__(1024) void k_jpeg_dc(const jpeg_tab *__restrict__ tabs, jpeg_geom g, int16_t *__restrict__ coef)
+__global__ __launch_bounds__(1024) void k_jpeg_dc(const jpeg_tab *__restrict__ tabs, jpeg_geom g, int16_t *__restrict__ dcarr)
 {
     __shared__ int wsum[16], wflag[16];
     __shared__ int carry;
@@ -313,25 +320,42 @@ __global__ __launch_bounds__(1024) void k_jpeg_dc(const jpeg_tab *__restrict__ t
     const int total = g.mcux * g.mcuy * nbc;
     const int seg = tabs[b].ri * nbc;                           // blocks of this component per restart interval (0: one interval)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    int16_t *cf = coef + (size_t)b * g.nblk * 64;
+    int16_t *dc = dcarr + (size_t)b * g.nblk;                   // dense: the strided DC slots of the coefficient blocks cost 0.29 ms, this 0.0x
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
-    for (int j0 = 0; j0 < total; j0 += 1024) {
-        const int j = j0 + threadIdx.x;
-        size_t n = 0;
-        int v = 0;
-        if (j < total) { n = (size_t)(j / nbc) * g.bpm + off + j % nbc; v = cf[n * 64]; }
-        int s = v, f = seg > 0 && j % seg == 0;
-        for (int d = 1; d < 64; d <<= 1) {
-            const int ts = __shfl_up(s, d, 64), tf = __shfl_up(f, d, 64);
-            if (lane >= d) { if (!f) s += ts; f |= tf; }
+    for (int j0 = 0; j0 < total; j0 += 4096) {                  // four consecutive blocks per thread: a quarter of the barriers
+        const int jb = j0 + 4 * threadIdx.x;
+        size_t n[4];
+        int v[4], f[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int j = jb + i;
+            n[i] = 0; v[i] = 0;
+            f[i] = seg > 0 && j % seg == 0;
+            if (j < total) { n[i] = (size_t)(j / nbc) * g.bpm + off + j % nbc; v[i] = dc[n[i]]; }
         }
-        if (lane == 63) { wsum[wv] = s; wflag[wv] = f; }
+        int sl[4], gl[4];                                       // sums since the last interval start inside the thread / "one was seen"
+        sl[0] = v[0]; gl[0] = f[0];
+#pragma unroll
+        for (int i = 1; i < 4; ++i) { sl[i] = f[i] ? v[i] : sl[i - 1] + v[i]; gl[i] = gl[i - 1] | f[i]; }
+        int s = sl[3], fl = gl[3];
+        for (int d = 1; d < 64; d <<= 1) {
+            const int ts = __shfl_up(s, d, 64), tf = __shfl_up(fl, d, 64);
+            if (lane >= d) { if (!fl) s += ts; fl |= tf; }
+        }
+        if (lane == 63) { wsum[wv] = s; wflag[wv] = fl; }
+        int ex = __shfl_up(s, 1, 64), exf = __shfl_up(fl, 1, 64);   // the same, up to the thread in front of this one
+        if (lane == 0) { ex = 0; exf = 0; }
         __syncthreads();
         int pre = carry;                                        // sum since the last interval start in front of this wave
         for (int k = 0; k < wv; ++k) pre = wflag[k] ? wsum[k] : pre + wsum[k];
-        const int r = f ? s : pre + s;
-        if (j < total) cf[n * 64] = (int16_t)r;
+        const int pt = exf ? ex : pre + ex;                     // ... in front of this thread
+        int r = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            r = gl[i] ? sl[i] : sl[i] + pt;
+            if (jb + i < total) dc[n[i]] = (int16_t)r;
+        }
         __syncthreads();
         if (threadIdx.x == 1023) carry = r;
         __syncthreads();
@@ -385,7 +409,7 @@ __device__ inline uint32_t jrange_limit(int x)
 
 // 8 lanes per block, 32 blocks per workgroup
 __global__ __launch_bounds__(256) void k_jpeg_idct(const jpeg_tab *__restrict__ tabs, jpeg_geom g, const int16_t *__restrict__ coef,
-                                                   uint8_t *__restrict__ planes)
+                                                   const int16_t *__restrict__ dcarr, uint8_t *__restrict__ planes)
 {
     __shared__ int ws[32][72];
     __shared__ int16_t cz[32][72];                                // the blocks as stored (zigzag order), one 16-byte load per lane
@@ -398,7 +422,10 @@ __global__ __launch_bounds__(256) void k_jpeg_idct(const jpeg_tab *__restrict__ 
     int comp = 0, bx = 0, by = 0;
     if (threadIdx.x < 192) qs[threadIdx.x >> 6][threadIdx.x & 63] = tabs[b].q[threadIdx.x >> 6][threadIdx.x & 63];
     else izz[threadIdx.x - 192] = c_izz[threadIdx.x - 192];
-    if (live) *reinterpret_cast<uint4 *>(&cz[lb][8 * c]) = reinterpret_cast<const uint4 *>(coef + ((size_t)b * g.nblk + n) * 64)[c];
+    if (live) {
+        *reinterpret_cast<uint4 *>(&cz[lb][8 * c]) = reinterpret_cast<const uint4 *>(coef + ((size_t)b * g.nblk + n) * 64)[c];
+        if (c == 0) cz[lb][0] = dcarr[(size_t)b * g.nblk + n];     // the predicted DC (the block holds the difference)
+    }
     __syncthreads();
     if (live) {
         const int m = n / g.bpm, j = n % g.bpm, ny = g.comp_nb[0];
@@ -743,7 +770,7 @@ int ofk_jpeg_decode_device(ofk_ctx *c, const uint8_t *const *jpeg, const size_t 
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += jup(bytes, 256); return o; };
     const size_t o_stage = take(stage), o_state = take(B * nch_max * 8), o_used = take(B * nch_max * 8), o_count = take(B * nch_max * 4),
-                 o_base = take(B * (nch_max + 1) * 4), o_flags = take(JMAX_ITERS * 4 + B * 8), o_coef = take(B * g.nblk * 128),
+                 o_base = take(B * (nch_max + 1) * 4), o_flags = take(JMAX_ITERS * 4 + B * 8), o_coef = take(B * g.nblk * 130),
                  o_planes = take(B * g.plane_stride);
     const size_t own_stride = jup((size_t)g.w * g.h * 3, 256);
     const size_t o_out = dst ? 0 : take(B * own_stride);
@@ -757,12 +784,12 @@ int ofk_jpeg_decode_device(ofk_ctx *c, const uint8_t *const *jpeg, const size_t 
     const uint8_t *dent = (const uint8_t *)(S + o_stage + tab_bytes);
     unsigned long long *state = (unsigned long long *)(S + o_state), *used = (unsigned long long *)(S + o_used);
     int *count = (int *)(S + o_count), *base = (int *)(S + o_base), *flags = (int *)(S + o_flags), *endinfo = flags + JMAX_ITERS;
-    int16_t *coef = (int16_t *)(S + o_coef);
+    int16_t *coef = (int16_t *)(S + o_coef), *dcarr = coef + B * g.nblk * 64;     // coefficient blocks, then the dense DC array
     uint8_t *planes = (uint8_t *)(S + o_planes);
     hipStream_t st = c->stream;
     OFK_HIP(c, hipMemcpyAsync(S + o_stage, c->hstage, stage, hipMemcpyHostToDevice, st));
     OFK_HIP(c, hipMemsetAsync(flags, 0, JMAX_ITERS * 4 + B * 8, st));
-    OFK_HIP(c, hipMemsetAsync(coef, 0, B * g.nblk * 128, st));
+    OFK_HIP(c, hipMemsetAsync(coef, 0, B * g.nblk * 130, st));
     const dim3 dgrid((nch_max + JTPB - 1) / JTPB, batch);
     int hflags[JMAX_ITERS];
     int iter = 0;
@@ -784,9 +811,9 @@ int ofk_jpeg_decode_device(ofk_ctx *c, const uint8_t *const *jpeg, const size_t 
         if (!converged && iter > nch_max + 2) return ofk_fail(c, OFK_E_INVALID, "ofk_jpeg: entropy decoders did not converge");
     }
     hipLaunchKernelGGL(k_jpeg_scan, dim3(batch), dim3(1024), 0, st, dt, nch_max, count, base);
-    hipLaunchKernelGGL(k_jpeg_write, dgrid, dim3(JTPB), 0, st, dt, dent, g, nch_max, state, base, coef, endinfo);
-    hipLaunchKernelGGL(k_jpeg_dc, dim3(batch, g.ncomp), dim3(1024), 0, st, dt, g, coef);
-    hipLaunchKernelGGL(k_jpeg_idct, dim3((g.nblk + 31) / 32, batch), dim3(256), 0, st, dt, g, coef, planes);
+    hipLaunchKernelGGL(k_jpeg_write, dgrid, dim3(JTPB), 0, st, dt, dent, g, nch_max, state, base, coef, dcarr, endinfo);
+    hipLaunchKernelGGL(k_jpeg_dc, dim3(batch, g.ncomp), dim3(1024), 0, st, dt, g, dcarr);
+    hipLaunchKernelGGL(k_jpeg_idct, dim3((g.nblk + 31) / 32, batch), dim3(256), 0, st, dt, g, coef, dcarr, planes);
     hipLaunchKernelGGL(k_jpeg_color, dim3((g.w + 511) / 512, (g.h + 3) / 4, batch), dim3(64, 4), 0, st, g, planes, dst, dst_stride);
     int *hend = (int *)malloc(B * 8);
     if (!hend) return ofk_fail(c, OFK_E_INVALID, "ofk_jpeg: out of host memory");
