@@ -931,7 +931,7 @@ static int stream_alloc(ofk_ctx *c)
 // gray + pyramid of a batch of BGR frames (host) into pyramid slot k
 static int stream_ingest(ofk_ctx *c, int k, const uint8_t *bgr, int batch, int h, int w, const ofk_levels &lv)
 {
-    TRY(h2d(c, c->bgr[k], c->bgr_stride, bgr, (size_t)h * w * 3, batch));
+    if (bgr) TRY(h2d(c, c->bgr[k], c->bgr_stride, bgr, (size_t)h * w * 3, batch));      // NULL: the frames are in bgr[k] already (JPEG ingest)
     ofk_launch_gray(c->stream, c->bgr[k], c->bgr_stride, c->pyr[k], c->pyr_stride, batch, h, w);
     for (int l = ofk_launch_pyr3(c->stream, c->pyr[k], nullptr, c->pyr_stride, lv, batch, batch) ? 4 : 1; l <= lv.n; ++l)
         ofk_launch_pyr_down(c->stream, c->pyr[k] + lv.off[l - 1], c->pyr_stride, lv.h[l - 1], lv.w[l - 1], c->pyr[k] + lv.off[l],
@@ -974,11 +974,9 @@ static int stream_fetch_tracks(ofk_ctx *c, int batch, int max_corners, float *tr
     return OFK_OK;
 }
 
-extern "C" int ofk_stream_begin(ofk_ctx *c, const uint8_t *first_bgr, int batch, int h, int w, const ofk_params *p, float *tracks,
-                                int *counts)
+// first_bgr == NULL: the first frames have been decoded into bgr[0] already (ofk_stream_begin_jpeg)
+static int stream_begin_impl(ofk_ctx *c, const uint8_t *first_bgr, int batch, int h, int w, const ofk_params *p, float *tracks, int *counts)
 {
-    TRY(check_geom(c, batch, h, w, "ofk_stream_begin"));
-    if (!first_bgr || !p) return ofk_fail(c, OFK_E_INVALID, "ofk_stream_begin: NULL argument");
     TRY(check_block(c, h, w, p->block_size));
     TRY(check_select(c, p->max_corners, p->quality, p->min_distance));
     TRY(check_lk(c, h, w, p->win, p->max_level));
@@ -990,13 +988,32 @@ extern "C" int ofk_stream_begin(ofk_ctx *c, const uint8_t *first_bgr, int batch,
     return stream_fetch_tracks(c, batch, p->max_corners, tracks, counts);
 }
 
-extern "C" int ofk_stream_step(ofk_ctx *c, const uint8_t *next_bgr, const double *sensors, const ofk_params *p, int min_features,
-                               int mask_radius, double *records, float *tracks, int *counts)
+extern "C" int ofk_stream_begin(ofk_ctx *c, const uint8_t *first_bgr, int batch, int h, int w, const ofk_params *p, float *tracks,
+                                int *counts)
 {
-    if (!c || !next_bgr || !sensors || !p) return ofk_fail(c, OFK_E_INVALID, "ofk_stream_step: NULL argument");
-    if (c->stream_batch < 1) return ofk_fail(c, OFK_E_INVALID, "ofk_stream_step: call ofk_stream_begin first");
-    if (hipSetDevice(c->device) != hipSuccess) return ofk_fail(c, OFK_E_HIP, "hipSetDevice failed");
-    join_slices(c);
+    TRY(check_geom(c, batch, h, w, "ofk_stream_begin"));
+    if (!first_bgr || !p) return ofk_fail(c, OFK_E_INVALID, "ofk_stream_begin: NULL argument");
+    return stream_begin_impl(c, first_bgr, batch, h, w, p, tracks, counts);
+}
+
+// The same with the frames arriving as baseline JPEG streams (CompressedImage payloads, node:112): decoded on the device straight
+// into the stream's frame buffer, no decoded frame ever crosses PCIe.
+extern "C" int ofk_stream_begin_jpeg(ofk_ctx *c, const uint8_t *const *jpeg, const size_t *nbytes, int batch, const ofk_params *p,
+                                     float *tracks, int *counts)
+{
+    if (!c || !jpeg || !nbytes || !p || batch < 1) return ofk_fail(c, OFK_E_INVALID, "ofk_stream_begin_jpeg: bad argument");
+    int h = 0, w = 0;
+    if (ofk_jpeg_info(jpeg[0], nbytes[0], &h, &w, nullptr) != OFK_OK) return ofk_fail(c, OFK_E_INVALID, "ofk_stream_begin_jpeg: stream 0 is not a supported JPEG stream");
+    TRY(check_geom(c, batch, h, w, "ofk_stream_begin_jpeg"));
+    c->stream_batch = 0;
+    TRY(ofk_jpeg_decode_device(c, jpeg, nbytes, batch, c->bgr[0], c->bgr_stride, c->P, &h, &w, nullptr, nullptr));
+    return stream_begin_impl(c, nullptr, batch, h, w, p, tracks, counts);
+}
+
+// next_bgr == NULL: the new frames are in bgr[1] already (ofk_stream_step_jpeg)
+static int stream_step_impl(ofk_ctx *c, const uint8_t *next_bgr, const double *sensors, const ofk_params *p, int min_features,
+                            int mask_radius, double *records, float *tracks, int *counts)
+{
     const int B = c->stream_batch, h = c->stream_h, w = c->stream_w;
     TRY(check_block(c, h, w, p->block_size));
     TRY(check_select(c, p->max_corners, p->quality, p->min_distance));
@@ -1030,6 +1047,30 @@ extern "C" int ofk_stream_step(ofk_ctx *c, const uint8_t *next_bgr, const double
     uint8_t *t = c->pyr[0]; c->pyr[0] = c->pyr[1]; c->pyr[1] = t;
     t = c->bgr[0]; c->bgr[0] = c->bgr[1]; c->bgr[1] = t;
     return OFK_OK;
+}
+
+extern "C" int ofk_stream_step(ofk_ctx *c, const uint8_t *next_bgr, const double *sensors, const ofk_params *p, int min_features,
+                               int mask_radius, double *records, float *tracks, int *counts)
+{
+    if (!c || !next_bgr || !sensors || !p) return ofk_fail(c, OFK_E_INVALID, "ofk_stream_step: NULL argument");
+    if (c->stream_batch < 1) return ofk_fail(c, OFK_E_INVALID, "ofk_stream_step: call ofk_stream_begin first");
+    if (hipSetDevice(c->device) != hipSuccess) return ofk_fail(c, OFK_E_HIP, "hipSetDevice failed");
+    join_slices(c);
+    return stream_step_impl(c, next_bgr, sensors, p, min_features, mask_radius, records, tracks, counts);
+}
+
+extern "C" int ofk_stream_step_jpeg(ofk_ctx *c, const uint8_t *const *jpeg, const size_t *nbytes, const double *sensors, const ofk_params *p,
+                                    int min_features, int mask_radius, double *records, float *tracks, int *counts)
+{
+    if (!c || !jpeg || !nbytes || !sensors || !p) return ofk_fail(c, OFK_E_INVALID, "ofk_stream_step_jpeg: NULL argument");
+    if (c->stream_batch < 1) return ofk_fail(c, OFK_E_INVALID, "ofk_stream_step_jpeg: call ofk_stream_begin / ofk_stream_begin_jpeg first");
+    if (hipSetDevice(c->device) != hipSuccess) return ofk_fail(c, OFK_E_HIP, "hipSetDevice failed");
+    join_slices(c);
+    int h = 0, w = 0;
+    TRY(ofk_jpeg_decode_device(c, jpeg, nbytes, c->stream_batch, c->bgr[1], c->bgr_stride, c->P, &h, &w, nullptr, nullptr));
+    if (h != c->stream_h || w != c->stream_w)
+        return ofk_fail(c, OFK_E_INVALID, "ofk_stream_step_jpeg: frames are %dx%d, the streams were begun with %dx%d", w, h, c->stream_w, c->stream_h);
+    return stream_step_impl(c, nullptr, sensors, p, min_features, mask_radius, records, tracks, counts);
 }
 
 extern "C" int ofk_set_streams(ofk_ctx *c, int nstreams)

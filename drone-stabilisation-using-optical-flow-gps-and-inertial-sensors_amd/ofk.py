@@ -27,6 +27,7 @@ SYMBOLS = (
     "ofk_good_features", "ofk_lk_pyr", "ofk_flow_model", "ofk_feasibility", "ofk_velocity_solve", "ofk_imu_propagate",
     "ofk_post_solve", "ofk_kf_predict_update", "ofk_of_simulation", "ofk_associate_sensors", "ofk_feature_eval", "ofk_d_split", "ofk_pairs_upload", "ofk_pairs_upload_jpeg", "ofk_jpeg_info", "ofk_jpeg_decode_bgr8", "ofk_pairs_set_sensors",
     "ofk_pairs_run", "ofk_pairs_download", "ofk_pairs_export_records_f32", "ofk_stream_begin", "ofk_stream_step",
+    "ofk_stream_begin_jpeg", "ofk_stream_step_jpeg",
     "ofk_set_streams", "ofk_set_overlap", "ofk_mark", "ofk_mark_wait", "ofk_profile_enable", "ofk_profile_read",
 )
 
@@ -106,6 +107,8 @@ def load_library():
         L.ofk_pairs_export_records_f32.argtypes = [vp, vp, i]
         L.ofk_stream_begin.argtypes = [vp, vp, i, i, i, C.POINTER(Params), vp, vp]
         L.ofk_stream_step.argtypes = [vp, vp, vp, C.POINTER(Params), i, i, vp, vp, vp]
+        L.ofk_stream_begin_jpeg.argtypes = [vp, vp, vp, i, C.POINTER(Params), vp, vp]
+        L.ofk_stream_step_jpeg.argtypes = [vp, vp, vp, vp, C.POINTER(Params), i, i, vp, vp, vp]
         L.ofk_set_streams.argtypes = [vp, i]
         L.ofk_set_overlap.argtypes = [vp, i]
         L.ofk_mark.argtypes = [vp, i]; L.ofk_mark_wait.argtypes = [vp, i]
@@ -536,6 +539,31 @@ class Context:
         with self._lock:
             self._ck(self._L.ofk_stream_step(self._h, _p(next_bgr), _p(sensors), C.byref(params), int(min_features), int(mask_radius),
                                              _p(rec), _p(tracks), _p(counts)))
+        return rec, tracks, counts
+
+    def stream_begin_jpeg(self, streams, params):
+        """stream_begin with one baseline JPEG stream per camera (CompressedImage payloads), decoded on the device."""
+        h, w, _ = jpeg_info(streams[0])
+        keep, ptrs, sizes = self._jpeg_args(streams)
+        B, mc = len(keep), int(params.max_corners)
+        tracks = np.zeros((B, mc, 2), np.float32); counts = np.zeros(B, np.int32)
+        with self._lock:
+            self._ck(self._L.ofk_stream_begin_jpeg(self._h, ptrs, sizes, B, C.byref(params), _p(tracks), _p(counts)))
+        self._stream = (B, h, w)
+        return tracks, counts
+
+    def stream_step_jpeg(self, streams, sensors, params, min_features, mask_radius):
+        B, h, w = self._stream
+        if len(streams) != B:
+            raise ValueError(f"expected {B} JPEG streams")
+        keep, ptrs, sizes = self._jpeg_args(streams)
+        sensors = _arr(sensors, np.float64).reshape(B, SENSOR_DOUBLES)
+        mc = int(params.max_corners)
+        rec = np.zeros((B, RECORD_DOUBLES), np.float64)
+        tracks = np.zeros((B, mc, 2), np.float32); counts = np.zeros(B, np.int32)
+        with self._lock:
+            self._ck(self._L.ofk_stream_step_jpeg(self._h, ptrs, sizes, _p(sensors), C.byref(params), int(min_features), int(mask_radius),
+                                                  _p(rec), _p(tracks), _p(counts)))
         return rec, tracks, counts
 
     def set_overlap(self, on):

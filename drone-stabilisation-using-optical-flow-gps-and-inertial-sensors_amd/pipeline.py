@@ -75,6 +75,13 @@ class FlowStream:
     def step(self, next_bgr, sensors):
         return self.ctx.stream_step(next_bgr, sensors, self._params, self.min_features, self.mask_radius)
 
+    def begin_jpeg(self, first_streams):
+        """begin() with the frames as the node receives them: one JPEG stream (CompressedImage payload) per camera."""
+        return self.ctx.stream_begin_jpeg(first_streams, self._params)
+
+    def step_jpeg(self, next_streams, sensors):
+        return self.ctx.stream_step_jpeg(next_streams, sensors, self._params, self.min_features, self.mask_radius)
+
     def close(self):
         self.ctx.close()
 

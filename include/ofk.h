@@ -238,6 +238,13 @@ int ofk_stream_begin(ofk_ctx *ctx, const uint8_t *first_bgr, int batch, int h, i
                      int *counts);
 int ofk_stream_step(ofk_ctx *ctx, const uint8_t *next_bgr, const double *sensors, const ofk_params *p, int min_features,
                     int mask_radius, double *records, float *tracks, int *counts);
+/* The same with the frames as the node receives them (node:112, 215): one baseline JPEG stream per camera (the payload of a
+ * sensor_msgs/CompressedImage), decoded on the device into the stream's frame buffer - no decoded frame crosses PCIe.  Frame size
+ * comes from the streams (all of one size and sampling; later frames must match the first). */
+int ofk_stream_begin_jpeg(ofk_ctx *ctx, const uint8_t *const *jpeg, const size_t *nbytes, int batch, const ofk_params *p, float *tracks,
+                          int *counts);
+int ofk_stream_step_jpeg(ofk_ctx *ctx, const uint8_t *const *jpeg, const size_t *nbytes, const double *sensors, const ofk_params *p,
+                         int min_features, int mask_radius, double *records, float *tracks, int *counts);
 
 /* ---- compressed-image ingest (cv2.imdecode of the reference's CompressedImage callback, velocity_measurment_node.py:112) ----
  * ofk_jpeg_info: header fields of a JPEG stream (host only; no context, no GPU).  OFK_E_INVALID if the stream is not one the decoder

@@ -94,3 +94,38 @@ def test_stream_velocity_is_physical(pkg, ofk):
         rec, tracks, counts = fs.step(frames[t][None], sensors)
         assert rec[0, 4] == 3 and np.linalg.norm(rec[0, :3] - info["v"]) < 0.15 * np.linalg.norm(info["v"])
     fs.close()
+
+
+def test_stream_from_jpeg_frames_equals_stream_from_decoded_frames(pkg, ofk):
+    """The node's real input (node:112, 215): CompressedImage payloads.  begin_jpeg / step_jpeg decode on the device into the
+    stream's frame buffer; tracks, counts and records must equal those of the same loop fed with the frames the JPEG oracle
+    decodes (two cameras in one context, restart markers on one of them)."""
+    Image = pytest.importorskip("PIL.Image")
+    import io as _io
+    from oracle import jpeg_oracle as jo
+    from of_amd import synth
+    from of_amd.pipeline import FlowStream, PipelineConfig
+    h, w, T = 480, 640, 5
+    seqs = [synth.render_sequence(h, w, 21 + k, T, v=(0.004, -0.003 + 0.001 * k, 0.002), omega=(0.002, 0.001, -0.003), d=1.0) for k in range(2)]
+    info = seqs[0][1]
+
+    def enc(img, k):
+        buf = _io.BytesIO()
+        Image.fromarray(img).save(buf, "JPEG", quality=90, **({"restart_marker_rows": 2} if k else {}))
+        return buf.getvalue()
+
+    streams = [[enc(seqs[k][0][t], k) for k in range(2)] for t in range(T)]
+    decoded = [np.stack([jo.decode(s) for s in streams[t]]) for t in range(T)]
+    cfg = PipelineConfig(max_corners=120, quality=0.02, min_distance=10, block_size=7)
+    sensors = ofk.make_sensors(2, d=1.0, normal=info["n"], omega=info["omega"], scaling=info["scaling"], cx=info["cx"], cy=info["cy"])
+    a = FlowStream(w, h, 2, cfg, min_features=100, mask_radius=20)
+    b = FlowStream(w, h, 2, cfg, min_features=100, mask_radius=20)
+    ta, ca = a.begin_jpeg(streams[0]); tb, cb = b.begin(decoded[0])
+    assert np.array_equal(ca, cb) and np.array_equal(ta, tb) and int(ca.min()) > 30
+    for t in range(1, T):
+        ra, ta, ca = a.step_jpeg(streams[t], sensors)
+        rb, tb, cb = b.step(decoded[t], sensors)
+        assert np.array_equal(ca, cb) and np.array_equal(ta, tb) and np.array_equal(ra, rb), t
+    with pytest.raises(ofk.OfkError):
+        a.step_jpeg([enc(seqs[0][0][0][:240], 0)] * 2, sensors)   # another frame size
+    a.close(); b.close()
