@@ -68,6 +68,24 @@ def run_stream(name, w, h, streams, cfg, frames):
     dt = (time.perf_counter() - t0) / frames
     print(f"{name}: {streams} stream(s) {w}x{h}: {dt * 1e3:.3f} ms per step = {streams / dt:.0f} frames/s, tracks per stream {np.mean(counts):.0f} "
           f"(a 30 fps camera leaves {1e3 / 30:.1f} ms per frame)", flush=True)
+    try:                                                        # the same loop on compressed frames (what the node receives), if an encoder is around
+        import io
+        from PIL import Image
+
+        def enc(img):
+            buf = io.BytesIO()
+            Image.fromarray(img).save(buf, "JPEG", quality=80)
+            return buf.getvalue()
+        j0 = [enc(f) for f in f0]; j1 = [enc(f) for f in f1]
+        fs.begin_jpeg(j0)
+        fs.step_jpeg(j1, sensors)
+        t0 = time.perf_counter()
+        for k in range(frames):
+            rec, tracks, counts = fs.step_jpeg(j0 if k & 1 else j1, sensors)
+        dt = (time.perf_counter() - t0) / frames
+        print(f"{name} (JPEG frames, {np.mean([len(s) for s in j0]) / 1e3:.0f} kB each): {dt * 1e3:.3f} ms per step = {streams / dt:.0f} frames/s", flush=True)
+    except ImportError:
+        pass
     fs.close()
 
 
