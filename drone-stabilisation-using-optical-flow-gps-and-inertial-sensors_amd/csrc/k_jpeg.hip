@@ -711,6 +711,7 @@ int ofk_jpeg_decode_device(ofk_ctx *c, const uint8_t *const *jpeg, const size_t 
         }
         ent_total += JPAD(jh[b].ent_len);
     }
+    if (ent_total >= (1ull << 32)) { free(jh); return ofk_fail(c, OFK_E_INVALID, "ofk_jpeg: more than 4 GiB of entropy data in one batch"); }
     jpeg_geom g = jgeom(jh[0]);
     g.jch = JCH;
     while (g.jch > JCH_MIN && ent_total / (size_t)g.jch < 131072) g.jch >>= 1;   // keep >= 128 k decoder threads if the data allows
@@ -764,7 +765,6 @@ int ofk_jpeg_decode_device(ofk_ctx *c, const uint8_t *const *jpeg, const size_t 
     }
     free(eoff);
     free(jh);
-    if (ent_total >= (1ull << 32)) return ofk_fail(c, OFK_E_INVALID, "ofk_jpeg: more than 4 GiB of entropy data in one batch");
     // device scratch
     const size_t B = (size_t)batch;
     size_t off = 0;
