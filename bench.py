@@ -21,12 +21,23 @@ Schedule (default): the batch runs as two free-running slices (--streams 2; DESI
 and auxiliary stream, the slices are offset by one response kernel and are not joined between steps.
 
 The JSON line also carries
-  roofline     : the longest stage on the step's critical path, from HIP events recorded inside the timed region on the
-                 stream the stage is launched on; achieved = SURVEY.md §8(d) algorithmic bytes per pair x B / mean stage
-                 time, traffic = HBM bytes from the committed PMC passes; `valu` = the same kernel against the VALU
-                 issue peak (its real bound), from the committed SQ_INSTS_VALU count and its time alone on the chip.
-  stages       : the same for every stage (ms per step, algorithmic GB/s) under the default overlapped schedule.
-  stages_isolated : every stage alone on the chip (serial pass after the timed region), with its HBM fraction.
+  roofline     : the dominant kernel = the longest stage of the step's critical chain (response -> select -> LK -> solve).
+                 Its duration is taken from the SERIAL pass that follows the timed region (same process, same resident
+                 frames, every stage alone on one stream, HIP events on that stream): under the overlapped schedule two
+                 slices' kernels share the chip and an event bracket then measures contention, not the kernel.  The dominant
+                 kernel is bound by VALU issue, so `bound` is "valu": achieved = wave-level VALU instructions per launch
+                 (committed SQ_INSTS_VALU count, profiles/r02_valu_pmc.json) / that duration, peak = one wave instruction per
+                 2 clocks per SIMD at 2.4 GHz on 1024 SIMDs (MI355X_MICROARCH.md) = 1228.8 G/s; `isa_mix` prices the same
+                 kernel against the issue cycles of its own instruction mix (profiles/r02_isa_mix.json); `hbm` keeps the
+                 HBM view (SURVEY.md §8(d) algorithmic bytes per launch / the same duration) and `traffic` the HBM bytes per
+                 launch from the committed PMC passes (profiles/r02_traffic_pmc.json).
+  north_star_group : SURVEY.md §8(d)'s "pyramid + LK group" = (G_pyr + G_lk) x B / (t_pyr + t_lk), serial-pass times.
+  north_star_kernel: the pyramid kernel alone (the HBM-bound member of that group).
+  stages       : every stage under the default overlapped schedule (event brackets inside the timed region; they include
+                 contention from the other slice and are NOT kernel durations).
+  stages_isolated : every stage alone on the chip (the serial pass), with its HBM fraction.
+  ingest_inclusive : pairs/s when the frames are NOT resident: raw BGR over PCIe every step, and JPEG streams decoded on the
+                 device every step (bounded: a few steps each, outside the timed region).
   cpu_baseline : the CPU oracle (oracle/, single thread, kind "port") timed on this host over a bounded sample of the
                  same frame pairs (rank 0, N=1 only).
 """
@@ -47,6 +58,10 @@ from __graft_entry__ import load_package  # noqa: E402
 
 H, W = 1080, 1920
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 2.0      # 1228.8 G wave-instr/s: wave64 VALU = 2 clocks on a SIMD-32, 1024 SIMDs, 2.4 GHz
+PROFILE_TAG = "r02"          # profiles/<tag>_traffic_pmc.json, _valu_pmc.json, _isa_mix.json (tools/profile_round.sh)
+KERNEL_OF = {"gray": "k_gray_bgr8", "pyr": "k_pyr3_stream", "eig": "k_mineig_pair<7,false>", "select": "k_select", "lk": "k_lk15",
+             "solve": "k_pairs_solve", "nms": "-"}
 
 
 def algorithmic_bytes(cfg, n_pts, n_cand):
@@ -71,28 +86,90 @@ def algorithmic_bytes(cfg, n_pts, n_cand):
     }
 
 
+def _profile(name):
+    for tag in (PROFILE_TAG, "r01"):
+        try:
+            return json.load(open(os.path.join(ROOT, "profiles", f"{tag}_{name}.json"))), tag
+        except Exception:
+            continue
+    return None, None
+
+
 def pmc_traffic(stage, pairs_per_launch):
-    """HBM bytes per launch group of the stage from the committed rocprofv3 PMC passes (profiles/r01_traffic_pmc.json,
+    """HBM bytes per launch group of the stage from the committed rocprofv3 PMC passes (profiles/r02_traffic_pmc.json,
     written by tools/profile_round.sh + tools/make_traffic_json.py from this same command), scaled to the pairs one launch
     group processes; None if absent."""
+    t, _ = _profile("traffic_pmc")
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic_pmc.json")))
         return int(t["stages"][stage]["hbm_bytes_per_step"] * pairs_per_launch / t["batch"])
     except Exception:
         return None
 
 
 def valu_roof(stage, pairs_per_launch, isolated_ms):
-    """VALU issue rate of the stage's kernel against the chip's issue peak (one wave instruction per 4 clocks per SIMD):
-    wave-level instruction count per pair from the committed PMC pass x pairs / the kernel's time alone on the chip."""
+    """The stage's kernel against the VALU issue peak: wave-level instructions per launch (committed SQ_INSTS_VALU count, scaled
+    to the pairs of one launch) / the kernel's duration alone on the chip.  Returns (achieved G/s, instructions per launch,
+    source file tag) or None."""
+    t, tag = _profile("valu_pmc")
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r01_valu_pmc.json")))
         n = t["stages"][stage]["SQ_INSTS_VALU_per_launch"] * pairs_per_launch / t["batch"]
-        rate = n / (isolated_ms * 1e-3) / 1e9
-        return {"achieved": round(rate, 1), "peak": t["valu_peak_ginstr_per_s"], "unit": "G wave-instr/s",
-                "frac": round(rate / t["valu_peak_ginstr_per_s"], 4), "isolated_ms": round(isolated_ms, 4)}
+        return n / (isolated_ms * 1e-3) / 1e9, int(n), tag
     except Exception:
         return None
+
+
+def isa_mix_roof(stage, pairs_per_launch, isolated_ms):
+    """Issue-cycle bound of the kernel's own instruction mix (tools/isa_mix.py -> profiles/r02_isa_mix.json: VALU issue cycles
+    per pair = sum over instruction classes of count x measured issue cost): the time the chip's 1024 SIMDs need to issue that
+    mix at 2.4 GHz with no stall at all, over the measured duration."""
+    t, tag = _profile("isa_mix")
+    try:
+        cyc = t["stages"][stage]["valu_issue_cycles_per_pair"] * pairs_per_launch
+        floor_ms = cyc / (1024 * 2.4e9) * 1e3
+        return {"issue_floor_ms": round(floor_ms, 4), "frac": round(floor_ms / isolated_ms, 4),
+                "mean_cycles_per_valu_instr": t["stages"][stage].get("mean_cycles_per_valu_instr"), "source": f"profiles/{tag}_isa_mix.json"}
+    except Exception:
+        return None
+
+
+def ingest_inclusive(pipe, prev, nxt, sensors, B, reps=2):
+    """Pairs/s when the frames are not resident (never `value`): every step uploads its B pairs first — as raw BGR over PCIe
+    (ofk_pairs_upload, 12.4 MB per 1080p pair) and as baseline JPEG streams decoded on the device (ofk_pairs_upload_jpeg; what
+    the reference's node receives, node:112,221).  Wall clock around upload + ofk_pairs_run + sync, `reps` steps each."""
+    out = {}
+    try:
+        pipe.upload(prev, nxt, sensors); pipe.run_async(); pipe.sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            pipe.upload(prev, nxt, sensors); pipe.run_async()
+        pipe.sync()
+        dt = time.perf_counter() - t0
+        out["raw_bgr_upload"] = {"value": round(B * reps / dt, 1), "unit": "frame-pairs/s", "bytes_per_pair": int(prev[0].nbytes + nxt[0].nbytes)}
+    except Exception as e:                                       # never lose the bench line over an optional leg
+        out["raw_bgr_upload"] = {"error": str(e)[:200]}
+    try:
+        import io as _io
+        from PIL import Image
+
+        def enc(img):
+            buf = _io.BytesIO()
+            Image.fromarray(img).save(buf, "JPEG", quality=80, subsampling=2)      # compressed_image_transport's defaults
+            return buf.getvalue()
+        D = min(8, B)
+        sp = [enc(prev[b]) for b in range(D)]; sn = [enc(nxt[b]) for b in range(D)]
+        jp = [bytes(bytearray(sp[b % D])) for b in range(B)]; jn = [bytes(bytearray(sn[b % D])) for b in range(B)]
+        pipe.upload_jpeg(jp, jn, sensors); pipe.run_async(); pipe.sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            pipe.upload_jpeg(jp, jn, sensors); pipe.run_async()
+        pipe.sync()
+        dt = time.perf_counter() - t0
+        out["jpeg_decode_on_device"] = {"value": round(B * reps / dt, 1), "unit": "frame-pairs/s",
+                                        "bytes_per_pair": int(np.mean([len(a) + len(b) for a, b in zip(jp, jn)])),
+                                        "streams": f"{D} distinct 1080p 4:2:0 quality-80 frames per side, repeated"}
+    except Exception as e:
+        out["jpeg_decode_on_device"] = {"error": str(e)[:200]}
+    return out
 
 
 def cpu_baseline(prev, nxt, sensors, cfg, sample, threads=1):
@@ -133,6 +210,7 @@ def main():
     ap.add_argument("--no-isolated", action="store_true", help="skip the serial pass behind the timed region (profiling: the kernel "
                     "trace then holds the timed schedule's launches only)")
     ap.add_argument("--cpu-sample", type=int, default=24, help="pairs timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--no-ingest", action="store_true", help="skip the ingest-inclusive legs (raw BGR upload / JPEG decode every step)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -241,14 +319,29 @@ def main():
             per_step = ms / args.steps                   # summed over the slices (streams) of a step
             stages[s] = {"ms_per_step": round(per_step, 4), "launches_per_step": nl // max(1, args.steps),
                          "algorithmic_GBps": round(ab[s] * B / (per_step * 1e-3) / 1e9, 2) if per_step > 0 else None}
-        # dominant kernel = the longest stage on the step's critical path.  With overlap on, gray and the pyramids run on
-        # the auxiliary stream beside the response kernel and LK (their event times then include the contention and
-        # are not on the critical path), so the candidates are the stages of the context's own stream.
-        critical = ofk.STAGES if args.no_overlap else [s for s in ofk.STAGES if s not in ("gray", "pyr")]
-        dom = max(critical, key=lambda s: prof[s][0])
-        slices = max(1, prof[dom][1] // max(1, args.steps))       # event pairs (= stage launches) per step
-        dom_ms = prof[dom][0] / max(1, prof[dom][1])             # mean duration of one bracketed launch group
-        achieved = ab[dom] * (B / slices) / (dom_ms * 1e-3) / 1e9
+        # dominant kernel = the longest stage of the critical chain, by its duration ALONE on the chip (serial pass): event
+        # brackets under the overlapped schedule include the other slice's kernels and are not kernel durations
+        chain = [s for s in ofk.STAGES if s not in ("gray", "pyr", "nms")]
+        iso_ms = {s: (iso[s][0] / iso[s][1] if iso[s][1] else 0.0) for s in ofk.STAGES}     # mean duration of one launch (B pairs)
+        iso_pairs = B                                             # the serial pass runs one slice: every launch covers the whole batch
+        dom = max(chain, key=lambda s: iso_ms[s])
+        dom_ms = iso_ms[dom]
+        hbm_ach = ab[dom] * iso_pairs / (dom_ms * 1e-3) / 1e9
+        vr = valu_roof(dom, iso_pairs, dom_ms)
+        roof = {"kernel": f"{KERNEL_OF[dom]} (stage {dom})", "avg_ms": round(dom_ms, 4), "pairs_per_launch": iso_pairs,
+                "timing": "mean HIP-event duration of the kernel's launches in the serial pass of this run (every stage alone on one "
+                          "stream, after the timed region); a kernel's time per step is <= ms_per_step by construction",
+                "hbm": {"achieved": round(hbm_ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_ach / HBM_PEAK_GBS, 4),
+                        "algorithmic_bytes_per_launch": int(ab[dom] * iso_pairs)},
+                "traffic": pmc_traffic(dom, iso_pairs)}
+        if vr is not None:
+            roof.update({"bound": "valu", "achieved": round(vr[0], 1), "peak": VALU_PEAK_GINSTR, "unit": "G wave-instr/s",
+                         "frac": round(vr[0] / VALU_PEAK_GINSTR, 4), "valu_instr_per_launch": vr[1],
+                         "valu_source": f"profiles/{vr[2]}_valu_pmc.json", "isa_mix": isa_mix_roof(dom, iso_pairs, dom_ms)})
+        else:                                                     # no committed instruction count: only the HBM view can be stated
+            roof.update({"bound": "hbm", "achieved": roof["hbm"]["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": roof["hbm"]["frac"]})
+        t_grp = iso_ms["pyr"] + iso_ms["lk"]
+        grp_bytes = (ab["pyr"] + ab["lk"]) * iso_pairs
         line = {
             "metric": "frame-pairs/sec @1920x1080 (LK+velocity)",
             "value": round(world * B * args.steps / dt, 2),
@@ -265,12 +358,14 @@ def main():
             "config": {"workload": "1920x1080 frame pairs, 500 Shi-Tomasi corners, 3-level LK pyramid (BASELINE configs[1])",
                        "pairs_per_gpu_per_step": B, "streams_per_gpu": args.streams, "corners_mean": round(n_pts, 1), "candidates_mean": round(n_cand, 1), "win": cfg.win, "max_level": cfg.max_level,
                        "sharding": f"{world} x independent pair batches, all_gather of [B,8] f32 records"},
-            "roofline": {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom, B / slices),
-                         "algorithmic_bytes_per_launch": int(ab[dom] * B / slices), "avg_ms": round(dom_ms, 4),
-                         # the response and LK kernels are bound by VALU issue, not by HBM: their real roof, from the
-                         # committed SQ_INSTS_VALU counts (profiles/r01_valu_pmc.json) and this run's isolated kernel time
-                         "valu": valu_roof(dom, B * args.steps / max(1, iso[dom][1]), iso[dom][0] / max(1, iso[dom][1]))},
+            "roofline": roof,
+            # "Pyramid+LK group (north-star kernel)" = G_pyr + G_lk (Scharr fused into LK), serial-pass durations
+            "north_star_group": {"kernels": f"{KERNEL_OF['pyr']} + {KERNEL_OF['lk']}", "bound": "hbm",
+                                 "achieved": round(grp_bytes / (t_grp * 1e-3) / 1e9, 1) if t_grp > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": round(grp_bytes / (t_grp * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if t_grp > 0 else None,
+                                 "algorithmic_bytes_per_launch": int(grp_bytes), "avg_ms": {"pyr": round(iso_ms["pyr"], 4), "lk": round(iso_ms["lk"], 4)},
+                                 "traffic": (pmc_traffic("pyr", iso_pairs) or 0) + (pmc_traffic("lk", iso_pairs) or 0) or None,
+                                 "note": "LK is bound by VALU issue, not HBM (stages_isolated.lk, roofline of stage lk in DESIGN.md §4)"},
             "pipeline_algorithmic_GBps": round(sum(ab.values()) * world * B * args.steps / dt / 1e9, 1),
             "stages": stages,
             # every stage alone on the chip (serial pass outside the timed region) and the HBM-bound group BASELINE.json's
@@ -279,7 +374,8 @@ def main():
                                     "algorithmic_GBps": round(ab[s] * B / (iso[s][0] / args.steps * 1e-3) / 1e9, 2) if iso[s][0] > 0 else None,
                                     "hbm_frac": round(ab[s] * B / (iso[s][0] / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if iso[s][0] > 0 else None}
                                 for s in ofk.STAGES},
-            # BASELINE.json's target names the pyramid construction: its roofline from this run's serial pass (alone on the chip)
+            # the HBM-bound member of that group alone: SURVEY's 6.8 MB/pair counts re-reading levels 1 and 2, which the one-pass
+            # kernel never does, so `traffic` (what it really moves) is the lower number
             "north_star_kernel": {"kernel": "k_pyr3_stream (pyramid levels 1-3 of both frames, one launch)", "bound": "hbm",
                                   "achieved": round(ab["pyr"] * B * args.steps / (iso["pyr"][0] * 1e-3) / 1e9, 1) if iso["pyr"][0] > 0 else None,
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -301,6 +397,8 @@ def main():
                                               f"host has {os.cpu_count()} cores",
                                     "velocity_max_rel_diff_vs_gpu": float(np.max(np.abs(v_cpu - rec[sample - 1, :3]) / np.abs(v_cpu))),
                                     "multi_thread": {"value": round(cps_mt, 3), "cores": nthr, "sample": f"{msample} pairs, one pair per thread"}}
+        if world == 1 and not args.no_ingest:
+            line["ingest_inclusive"] = ingest_inclusive(pipe, prev, nxt, sensors, B)
         print(json.dumps(line), flush=True)
     pipe.close()
     if dist is not None:

@@ -17,7 +17,7 @@
 //       All window sums are integers, so the result does not depend on the summation order (bit-exact vs oracle).
 //       FUSED = false: the f32 map is written to HBM (ofk_mineig_response).
 //       FUSED = true : no map.  The region overlaps its neighbours by one pixel, the block applies the 3x3
-//         local-max test itself and appends the survivors as 64-bit keys (~bits(value) << 32 | linear index) with
+//         local-max test itself and appends the survivors as 64-bit keys (~bits(value) << 32 | ~linear index: ascending key = value desc, index desc, OpenCV's greaterThanPtr order) with
 //         ONE global atomic per block.  The quality threshold needs the image-wide maximum, which is not known yet;
 //         the block prunes with the running maximum (atomicMax so far), a valid lower bound, and k_select applies the
 //         exact threshold.  HBM traffic: P read + O(candidates) written, instead of P + 4P + 4P.
@@ -26,7 +26,7 @@
 //   k_select : one 1024-thread workgroup per image.  Repeats { pick the next <= 4096 keys in ascending key order
 //              with an 11-bit histogram over (key - lower bound), bitonic sort in LDS, greedy min-distance over the
 //              sorted chunk } until max_corners are accepted or the keys below the threshold key are exhausted.
-//              Result identical to a full sort (value desc, index asc) followed by the serial greedy pass.
+//              Result identical to a full sort (value desc, index desc) followed by the serial greedy pass.
 #include "ofk_internal.h"
 
 __device__ __forceinline__ int reflect101(int i, int n)
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void k_mineig(const uint8_t *__restrict__ gray
                                   fmaxf(fmaxf(c[1], c[ME_OW - 1]), fmaxf(c[ME_OW], c[ME_OW + 1])));
             if (m > v) continue;
             const int slot = atomicAdd(&s_misc[5], 1);
-            if (slot < ME_CAND_MAX) s_cand[slot] = ((unsigned long long)(~__float_as_uint(v)) << 32) | (unsigned)(gy * w + gx);
+            if (slot < ME_CAND_MAX) s_cand[slot] = ((unsigned long long)(~__float_as_uint(v)) << 32) | (unsigned)~(unsigned)(gy * w + gx);
         }
     }
     __syncthreads();
@@ -332,9 +332,6 @@ __device__ __forceinline__ int box_row(int a, int ad2, int ad4, int adl)
 {
     if constexpr (BS == 5 || BS == 7 || BS == 12) {
         const int p = DPP_SHR1(a) + a;                                           // x-1 .. x
-#ifdef OFK_ABLATE_GATHER                                                         /* timing experiment only (tools/variants.sh): wrong sums */
-        return p + (ad2 + ad4) + adl;
-#endif
         if constexpr (BS == 5) return p + __builtin_amdgcn_ds_bpermute(ad2, p) + __builtin_amdgcn_ds_bpermute(ad4, a);
         if constexpr (BS == 7) return p + __builtin_amdgcn_ds_bpermute(ad2, p) + (__builtin_amdgcn_ds_bpermute(ad4, p) + __builtin_amdgcn_ds_bpermute(adl, a));
         if constexpr (BS == 12) {
@@ -400,17 +397,14 @@ __device__ __forceinline__ int box_row(int a, int ad2, int ad4, int adl)
         if (MASK) is = is & (mk[(size_t)min(max(yn, 0), h - 1) * w + xoc] != 0);                                       \
         const unsigned long long bal = __builtin_amdgcn_ballot_w64(is);                                                \
         if (is) buf[cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))] =   \
-            ((unsigned long long)(~(unsigned)e1i) << 32) | (unsigned)(yn * w + xo);                                    \
+            ((unsigned long long)(~(unsigned)e1i) << 32) | (unsigned)~(unsigned)(yn * w + xo);                                   \
         cnt += __popcll(bal);                                                                                          \
         e1i = e2i; hm0 = hm1; hm1 = hm2;                                                                               \
         g0 = g1; g1 = g2;                                                                                              \
     }
 
-#ifndef OFK_EIG_WAVES
-#define OFK_EIG_WAVES 4
-#endif
 template <int BS, bool MASK>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OFK_EIG_WAVES, 8))) void k_mineig_stream(const uint8_t *__restrict__ gray, size_t gray_stride, int h, int w,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_mineig_stream(const uint8_t *__restrict__ gray, size_t gray_stride, int h, int w,
                                                        int rows_per_strip, float kd, float ko,
                                                        unsigned int *__restrict__ maxbits, const uint8_t *__restrict__ mask,
                                                        size_t mask_stride, double quality,
@@ -419,16 +413,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OFK_EIG_WAV
 {
     constexpr int AN = BS / 2, SW = 61 - BS;
     constexpr int NBUF = 64 + BS * SW;                          // keys a wave can hold between two flush points
-    __shared__ unsigned long long s_buf[4][NBUF + 64];          // + 64: a flush reads one whole 64-key chunk past the count
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform: strip geometry stays in SGPRs
-    const int sx = blockIdx.x * 4 + wave;
+    __shared__ unsigned long long s_buf[NBUF + 64];             // + 64: a flush reads one whole 64-key chunk past the count
+    const int lane = threadIdx.x;                               // one wave per workgroup (see k_mineig_pair): no half-empty workgroups
+    const int sx = blockIdx.x;                                  // wave-uniform: strip geometry stays in SGPRs
     if (sx * SW >= w) return;                                   // whole wave
     const int b = blockIdx.z;
     const int ya = blockIdx.y * rows_per_strip, yb = min(h, ya + rows_per_strip);
     const uint8_t *img = gray + (size_t)b * gray_stride;
     const uint8_t *mk = MASK ? mask + (size_t)b * mask_stride : nullptr;
-    unsigned long long *buf = s_buf[wave];                      // private to this wave: LDS executes a wave's accesses in order
+    unsigned long long *buf = s_buf;                            // private to this wave: LDS executes a wave's accesses in order
 
     const int gx = sx * SW - 2 - AN + lane;                     // gray / product column of this lane
     const int gxr = reflect101(gx, w);
@@ -664,9 +657,9 @@ __device__ __forceinline__ int lambda_min_bits(int vxx, int vxy, int vyy, float 
         const unsigned long long bale = __builtin_amdgcn_ballot_w64(ise), balo = __builtin_amdgcn_ballot_w64(iso);     \
         const int ne = (int)__popcll(bale);                                                                            \
         if (ise) buf[cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bale >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bale, 0u))] =   \
-            ((unsigned long long)(~(unsigned)e1e) << 32) | (unsigned)(yn * w + xo_e);                                  \
+            ((unsigned long long)(~(unsigned)e1e) << 32) | (unsigned)~(unsigned)(yn * w + xo_e);                                 \
         if (iso) buf[cnt + ne + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(balo >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)balo, 0u))] = \
-            ((unsigned long long)(~(unsigned)e1o) << 32) | (unsigned)(yn * w + xo_o);                                  \
+            ((unsigned long long)(~(unsigned)e1o) << 32) | (unsigned)~(unsigned)(yn * w + xo_o);                                 \
         cnt += ne + (int)__popcll(balo);                                                                               \
         e1e = e2e; e1o = e2o; hm0e = hm1e; hm0o = hm1o; hm1e = hm2e; hm1o = hm2o;                                      \
         g0e = g1e; g0o = g1o; g1e = ge2; g1o = go2;                                                                    \
@@ -678,11 +671,13 @@ template <int BS> struct pair_geom {
 
 // BS = 7 keeps 42 ring registers per lane: 168 VGPRs = 3 waves per SIMD without spills (a 4th wave spills 43 dwords and
 // runs 1.65x slower; two waves per SIMD, forced by padding the LDS, 1.35x slower)
-#ifndef OFK_PAIR_ATTR
-#define OFK_PAIR_ATTR __attribute__((amdgpu_waves_per_eu(3, 8)))
-#endif
+// One WAVE per workgroup.  With four strips per 256-thread workgroup a 1080p frame (17 strips) left every fifth workgroup
+// with one live wave: its three dead waves' register slots could not host another workgroup (4 x 168 VGPRs) until the live wave
+// had marched down its 540 rows, and the 2560 workgroups of a 256-frame launch made 3.33 rounds over the chip's 768 slots.
+// Wave-granular workgroups fill every slot: SQ counters put the wave-slot utilisation of the old launch at 66 %
+// (profiles/r02a_valu_pmc.json: 6.1 G live wave-cycles in 9.3 G slot-cycles).
 template <int BS, bool MASK>
-__global__ __launch_bounds__(256) OFK_PAIR_ATTR void k_mineig_pair(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void k_mineig_pair(
     const uint8_t *__restrict__ gray, size_t gray_stride, int h, int w, int rows_per_strip, float kd, float ko,
     unsigned int *__restrict__ maxbits, const uint8_t *__restrict__ mask, size_t mask_stride, double quality,
     unsigned long long *__restrict__ seg, int seg_cap, int *__restrict__ seg_count, int *__restrict__ flags)
@@ -691,9 +686,8 @@ __global__ __launch_bounds__(256) OFK_PAIR_ATTR void k_mineig_pair(
     constexpr int AN = pair_geom<BS>::AN, PAD = pair_geom<BS>::PAD, D = pair_geom<BS>::D, SW = pair_geom<BS>::SW;
     constexpr int L0 = (BS + 1) / 2, L1 = (BS + 1 + SW) / 2;    // lanes [L0, L1) hold output columns (both slots)
     constexpr int NBUF = 64 + BS * SW;                          // keys a wave can hold between two flush points
-    __shared__ unsigned long long s_buf[4][NBUF + 64];          // + 64: a flush reads one whole 64-key chunk past the count
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    __shared__ unsigned long long s_buf[NBUF + 64];             // + 64: a flush reads one whole 64-key chunk past the count
+    const int lane = threadIdx.x;
     // XCD-aware block -> (image, chunk, strip block) map: workgroups are dealt round-robin over the 8 XCDs (blocks n and
     // n + 8 share one L2); an image's strips and chunks go to ONE XCD, so the halo columns and rows they share are fetched once.
     int bxi = blockIdx.x, byi = blockIdx.y, b = blockIdx.z;
@@ -702,12 +696,12 @@ __global__ __launch_bounds__(256) OFK_PAIR_ATTR void k_mineig_pair(
         b = 8 * (int)(k / per) + (int)(n & 7);
         byi = (int)(rem / gridDim.x); bxi = (int)(rem % gridDim.x);
     }
-    const int sx = bxi * 4 + wave;
+    const int sx = bxi;
     if (sx * SW - D >= w) return;                               // whole wave
     const int ya = byi * rows_per_strip, yb = min(h, ya + rows_per_strip);
     const uint8_t *img = gray + (size_t)b * gray_stride;
     const uint8_t *mk = MASK ? mask + (size_t)b * mask_stride : nullptr;
-    unsigned long long *buf = s_buf[wave];
+    unsigned long long *buf = s_buf;                           // one wave per workgroup: LDS executes its accesses in order, no barriers
 
     const int G0 = sx * SW - PAD;                              // gray column of lane 0's even slot: a multiple of 4
     const int ce = G0 + 2 * lane;                               // this lane's even gray / product column (odd: ce + 1)
@@ -856,12 +850,12 @@ static int launch_mineig_stream(hipStream_t s, const uint8_t *gray, size_t gray_
     const int strips = (w + SW - 1) / SW;
     const double scale = 1.0 / (4.0 * BS * 255.0);
     const float kd = (float)(0.5 * scale * scale), ko = (float)(scale * scale);
-    dim3 grid((strips + 3) / 4, (h + rows - 1) / rows, batch);
+    dim3 grid(strips, (h + rows - 1) / rows, batch);
     if (mask)
-        hipLaunchKernelGGL((k_mineig_stream<BS, true>), grid, dim3(256), 0, s, gray, gray_stride, h, w, rows, kd, ko, maxbits, mask,
+        hipLaunchKernelGGL((k_mineig_stream<BS, true>), grid, dim3(256 / 4), 0, s, gray, gray_stride, h, w, rows, kd, ko, maxbits, mask,
                            mask_stride, quality, seg, seg_cap, seg_count, flags);
     else
-        hipLaunchKernelGGL((k_mineig_stream<BS, false>), grid, dim3(256), 0, s, gray, gray_stride, h, w, rows, kd, ko, maxbits, mask,
+        hipLaunchKernelGGL((k_mineig_stream<BS, false>), grid, dim3(256 / 4), 0, s, gray, gray_stride, h, w, rows, kd, ko, maxbits, mask,
                            mask_stride, quality, seg, seg_cap, seg_count, flags);
     *nseg_out = nseg; *segcap_out = seg_cap;
     return 0;
@@ -880,12 +874,12 @@ static int launch_mineig_pair(hipStream_t s, const uint8_t *gray, size_t gray_st
     const int strips = (w + D + SW - 1) / SW;
     const double scale = 1.0 / (4.0 * BS * 255.0);
     const float kd = (float)(0.5 * scale * scale), ko = (float)(scale * scale);
-    dim3 grid((strips + 3) / 4, (h + rows - 1) / rows, batch);
+    dim3 grid(strips, (h + rows - 1) / rows, batch);
     if (mask)
-        hipLaunchKernelGGL((k_mineig_pair<BS, true>), grid, dim3(256), 0, s, gray, gray_stride, h, w, rows, kd, ko, maxbits, mask,
+        hipLaunchKernelGGL((k_mineig_pair<BS, true>), grid, dim3(64), 0, s, gray, gray_stride, h, w, rows, kd, ko, maxbits, mask,
                            mask_stride, quality, seg, seg_cap, seg_count, flags);
     else
-        hipLaunchKernelGGL((k_mineig_pair<BS, false>), grid, dim3(256), 0, s, gray, gray_stride, h, w, rows, kd, ko, maxbits, mask,
+        hipLaunchKernelGGL((k_mineig_pair<BS, false>), grid, dim3(64), 0, s, gray, gray_stride, h, w, rows, kd, ko, maxbits, mask,
                            mask_stride, quality, seg, seg_cap, seg_count, flags);
     *nseg_out = nseg; *segcap_out = seg_cap;
     return 0;
@@ -978,7 +972,7 @@ __global__ __launch_bounds__(256) void k_nms(const float *__restrict__ eig, size
                 const float *r0 = e + i - w, *r2 = e + i + w;
                 const float m = fmaxf(fmaxf(fmaxf(r0[-1], r0[0]), fmaxf(r0[1], e[i - 1])),
                                       fmaxf(fmaxf(e[i + 1], r2[-1]), fmaxf(r2[0], r2[1])));
-                if (!(m > v)) s_cand[atomicAdd(&s_n, 1)] = ((unsigned long long)(~__float_as_uint(v)) << 32) | (unsigned)(y * w + x);
+                if (!(m > v)) s_cand[atomicAdd(&s_n, 1)] = ((unsigned long long)(~__float_as_uint(v)) << 32) | (unsigned)~(unsigned)(y * w + x);
             }
         }
     }
@@ -1007,12 +1001,6 @@ void ofk_launch_nms(hipStream_t s, const float *eig, size_t eig_stride, const ui
 #define SEL_T 1024
 #define SEL_BINS 2048
 
-#ifdef OFK_SEL_STAMPS
-__device__ long long *g_stamps;
-#define OFK_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_stamps[k] = clock64(); } while (0)
-#else
-#define OFK_STAMP(k) do { } while (0)
-#endif
 __global__ __launch_bounds__(SEL_T) void k_select(unsigned long long *__restrict__ cand_all, int cand_cap,
                                                   int *__restrict__ cand_count, const unsigned long long *__restrict__ seg,
                                                   int seg_cap, const int *__restrict__ seg_count, int nseg,
@@ -1032,7 +1020,6 @@ __global__ __launch_bounds__(SEL_T) void k_select(unsigned long long *__restrict
     __shared__ int s_n, s_nacc, s_D, s_cum;
 
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    OFK_STAMP(0);
     unsigned long long *cand = cand_all + (size_t)b * cand_cap;
     const unsigned mb = maxbits[b * OFK_MAX_STRIDE];
     if (tid == 0) { s_nacc = 0; s_n = 0; counts[b] = 0; }
@@ -1117,7 +1104,6 @@ __global__ __launch_bounds__(SEL_T) void k_select(unsigned long long *__restrict
         C = min(cand_count[b * OFK_CNT_STRIDE], cand_cap);
     }
     if (C == 0 || !(thr < __uint_as_float(mb))) return;         // nothing is strictly above the threshold
-    OFK_STAMP(1);
 
     // keys handled per round: about twice the corners still wanted (sorting 4096 keys to accept 500 wasted 2/3 of the sort)
     int tgt = 512;
@@ -1166,7 +1152,6 @@ __global__ __launch_bounds__(SEL_T) void k_select(unsigned long long *__restrict
             if (bin_end < curB) curB = bin_end;
         }
         if (none_left) break;
-        OFK_STAMP(2);
         // ---- gather keys in [a, T)
         __syncthreads();
         if (tid == 0) s_n = 0;
@@ -1181,7 +1166,6 @@ __global__ __launch_bounds__(SEL_T) void k_select(unsigned long long *__restrict
         while (npad < n) npad <<= 1;
         for (int i = n + tid; i < npad; i += SEL_T) s_key[i] = ~0ull;
         __syncthreads();
-        OFK_STAMP(3);
         // ---- bitonic sort ascending
         // (element i belongs to thread i % 1024, so for j < 64 both partners of a compare-exchange sit in the same wave:
         //  those steps need no workgroup barrier — LDS executes a wave's accesses in order)
@@ -1198,14 +1182,13 @@ __global__ __launch_bounds__(SEL_T) void k_select(unsigned long long *__restrict
                 if (j >= 64 || j == 1) __syncthreads();         // j == 1 ends a kk stage: the next stage starts with j = kk/2
                 else __builtin_amdgcn_wave_barrier();
             }
-        OFK_STAMP(4);
         // ---- greedy over the sorted chunk, 64 candidates per round
         for (int base = 0; base < n; base += 64) {
             const int nacc = s_nacc;
             if (nacc >= max_corners) break;
             const int ci = base + lane;
             const bool live = ci < n;
-            const unsigned idx = live ? (unsigned)(s_key[ci] & 0xffffffffu) : 0u;
+            const unsigned idx = live ? ~(unsigned)(s_key[ci] & 0xffffffffu) : 0u;     // the key holds ~index: equal responses sort by DESCENDING index
             const int cx = (int)(idx % (unsigned)w), cy = (int)(idx / (unsigned)w);
             // every wave tests the round's 64 candidates against its share of the accepted set (4 independent LDS reads
             // in flight, no early exit) and builds 4 rows of the round's conflict matrix
@@ -1262,7 +1245,6 @@ __global__ __launch_bounds__(SEL_T) void k_select(unsigned long long *__restrict
         a = T;
         __syncthreads();
     }
-    OFK_STAMP(5);
     if (tid == 0) counts[b] = s_nacc;
 }
 

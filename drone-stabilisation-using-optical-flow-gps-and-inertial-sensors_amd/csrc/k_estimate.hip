@@ -50,6 +50,21 @@ __device__ __forceinline__ double block_sum(double v, double *s_red)
     return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
 }
 
+__device__ __forceinline__ double block_minmax(double v, bool want_max, double *s_red)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double u = __shfl_xor(v, o);
+        v = want_max ? fmax(v, u) : fmin(v, u);
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const double a = want_max ? fmax(s_red[0], s_red[1]) : fmin(s_red[0], s_red[1]);
+    const double b = want_max ? fmax(s_red[2], s_red[3]) : fmin(s_red[2], s_red[3]);
+    return want_max ? fmax(a, b) : fmin(a, b);
+}
+
 __device__ void acc_block_sum(Acc &a, double *s_red)
 {
     a.m00 = block_sum(a.m00, s_red); a.m01 = block_sum(a.m01, s_red); a.m02 = block_sum(a.m02, s_red);
@@ -568,24 +583,140 @@ void ofk_launch_of_simulation(hipStream_t s, const double *truth, const double *
     hipLaunchKernelGGL(k_of_simulation, dim3(trials), dim3(256), 0, s, truth, sig, pos, true_flow, n, z, v_obs, bound);
 }
 
+// ------------------------------------------------------------------------------------------------ multi-plane sorting statistics
+// feas_simulation (simulation.py:70-104), one block per trial: perturbed inputs -> solve (simulation.py:15-30) -> backward
+// feasibility with the solved velocity and forward feasibility with the noisy prior velocity (simulation.py:108-120) -> per-point
+// residual norms of both velocities in the rows of the system.  truth: v[0..2] omega[3..5] height[6] normal[7..9] t[10..12]
+// true_vel[13..15]; sig: ang_vel, translation, height, flow, position, normal, velocity.  z: the reference's draw order
+// (omega 3, t 3, height 1, flow 2n, position 2n, velocity 3, orient 1, orient2 1).  per [trial][6][n] in the reference's return
+// order: backward_para, backward_dist, forward_para, forward_dist, backward_res, forward_res.
+__device__ __forceinline__ void feas_sim_point(double px, double py, double ux, double uy, const double *vv, const double *om,
+                                               const double *tb, const double *nn, double &rr, double &dv)
+{
+    const double l0 = vv[0] - (om[1] * tb[2] - om[2] * tb[1]), l1 = vv[1] - (om[2] * tb[0] - om[0] * tb[2]),
+                 l2 = vv[2] - (om[0] * tb[1] - om[1] * tb[0]);
+    const double w0 = om[1] - om[2] * py, w1 = om[2] * px - om[0], w2 = om[0] * py - om[1] * px;   // omega x p
+    double f0, f1, f2, g0, g1, g2;
+    cross_p(px, py, l0, l1, l2, f0, f1, f2);
+    cross_p(px, py, ux - w0, uy - w1, -w2, g0, g1, g2);
+    const double n1 = sqrt(f0 * f0 + f1 * f1 + f2 * f2), n2 = sqrt(g0 * g0 + g1 * g1 + g2 * g2);
+    rr = (f0 * g0 + f1 * g1 + f2 * g2) / (n1 * n2);
+    dv = n1 / n2 * (px * nn[0] + py * nn[1] + nn[2]);
+}
+
+__global__ __launch_bounds__(256) void k_feas_simulation(const double *__restrict__ truth, const double *__restrict__ sig,
+                                                         const double *__restrict__ pos, const double *__restrict__ true_flow,
+                                                         int n, const double *__restrict__ z, double *__restrict__ per,
+                                                         double *__restrict__ v_obs)
+{
+    __shared__ double s_red[4];
+    __shared__ double s_v[4];
+    const int trial = blockIdx.x, tid = threadIdx.x;
+    const double *zi = z + (size_t)trial * (14 + 4 * (size_t)n);
+    const double ang[3] = {truth[3] + sig[0] * zi[0], truth[4] + sig[0] * zi[1], truth[5] + sig[0] * zi[2]};
+    const double trn[3] = {truth[10] + sig[1] * zi[3], truth[11] + sig[1] * zi[4], truth[12] + sig[1] * zi[5]};
+    const double h_err = truth[6] + sig[2] * zi[6];
+    const double *zf = zi + 7, *zp = zi + 7 + 2 * (size_t)n, *zv = zi + 7 + 4 * (size_t)n;
+    const double vel[3] = {truth[13] + sig[6] * zv[0], truth[14] + sig[6] * zv[1], truth[15] + sig[6] * zv[2]};
+    // orient_err = normal_sig * N(0, normal_sig) (simulation.py:87-88); normal_err = Ry(o2) Rx(o1) normal (simulation.py:89)
+    const double o1 = sig[5] * (sig[5] * zv[3]), o2 = sig[5] * (sig[5] * zv[4]);
+    const double c1 = cos(o1), s1 = sin(o1), c2 = cos(o2), s2 = sin(o2);
+    const double r0 = truth[7], r1 = c1 * truth[8] - s1 * truth[9], r2 = s1 * truth[8] + c1 * truth[9];      // Rx n
+    const double ne[3] = {c2 * r0 + s2 * r2, r1, -s2 * r0 + c2 * r2};                                        // Ry (Rx n)
+    Acc a; acc_zero(a);
+    for (int i = tid; i < n; i += 256) {
+        const double x = pos[2 * i] + sig[4] * zp[2 * i], y = pos[2 * i + 1] + sig[4] * zp[2 * i + 1];
+        const double ux = true_flow[2 * i] + sig[3] * zf[2 * i], uy = true_flow[2 * i + 1] + sig[3] * zf[2 * i + 1];
+        double q0, q1, q2, sA, sB;
+        point_terms(OFK_SOLVE_SIM, x, y, ux, uy, ne, ang, h_err, 1.0, q0, q1, q2, sA, sB);
+        acc_point(a, x, y, q0, q1, q2, sA, sB);
+    }
+    acc_block_sum(a, s_red);
+    if (tid == 0) {
+        double v[3], s3[3];
+        solve_from_acc(a, v, s3);
+        s_v[0] = v[0] - (ang[1] * trn[2] - ang[2] * trn[1]);      // v - omega x t (simulation.py:28)
+        s_v[1] = v[1] - (ang[2] * trn[0] - ang[0] * trn[2]);
+        s_v[2] = v[2] - (ang[0] * trn[1] - ang[1] * trn[0]);
+        if (v_obs) { v_obs[3 * trial] = s_v[0]; v_obs[3 * trial + 1] = s_v[1]; v_obs[3 * trial + 2] = s_v[2]; }
+    }
+    __syncthreads();
+    const double vo[3] = {s_v[0], s_v[1], s_v[2]};
+    double *o = per + (size_t)trial * 6 * n;
+    for (int i = tid; i < n; i += 256) {
+        const double x = pos[2 * i] + sig[4] * zp[2 * i], y = pos[2 * i + 1] + sig[4] * zp[2 * i + 1];
+        const double ux = true_flow[2 * i] + sig[3] * zf[2 * i], uy = true_flow[2 * i + 1] + sig[3] * zf[2 * i + 1];
+        double bp, bd, fp, fd;
+        feas_sim_point(x, y, ux, uy, vo, ang, trn, ne, bp, bd);
+        feas_sim_point(x, y, ux, uy, vel, ang, trn, ne, fp, fd);
+        double q0, q1, q2, sA, sB;
+        point_terms(OFK_SOLVE_SIM, x, y, ux, uy, ne, ang, 1.0, 1.0, q0, q1, q2, sA, sB);          // rows A_j = [p]x (n.p), b_j = [p]x (u + [p]x w)
+        o[i] = bp; o[n + i] = bd; o[2 * (size_t)n + i] = fp; o[3 * (size_t)n + i] = fd;
+        o[4 * (size_t)n + i] = sqrt(resid_point(x, y, q0, q1, q2, sA, 1.0, vo));
+        o[5 * (size_t)n + i] = sqrt(resid_point(x, y, q0, q1, q2, sA, 1.0, vel));
+    }
+}
+
+// np.mean(axis = 0) over the trials: one thread per (quantity, point), trials summed in order
+__global__ void k_trial_mean(const double *__restrict__ per, int trials, int cols, double *__restrict__ mean)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    double s = 0.0;
+    for (int t = 0; t < trials; ++t) s += per[(size_t)t * cols + c];
+    mean[c] = s / (double)trials;
+}
+
+void ofk_launch_feas_simulation(hipStream_t s, const double *truth, const double *sig, const double *pos, const double *true_flow,
+                                int n, const double *z, int trials, double *per, double *mean, double *v_obs)
+{
+    hipLaunchKernelGGL(k_feas_simulation, dim3(trials), dim3(256), 0, s, truth, sig, pos, true_flow, n, z, per, v_obs);
+    hipLaunchKernelGGL(k_trial_mean, dim3((6 * n + 255) / 256), dim3(256), 0, s, per, trials, 6 * n, mean);
+}
+
+// overlap(data1, data2) (simulation.py:124-136): common bin edges = np.histogram(hstack, bins)[1] = linspace(min, max, bins + 1)
+// (min == max: the range is widened by 0.5 on both sides, as numpy does), both histograms over those edges (bins half open,
+// the last one closed), sum of the bin-wise minima.  One block; edges in LDS, every element binary-searches them exactly as
+// np.searchsorted does, so the counts are numpy's counts.
+#define OVL_MAX_BINS 1024
+__global__ __launch_bounds__(256) void k_hist_overlap(const double *__restrict__ d1, int n1, const double *__restrict__ d2, int n2,
+                                                      int bins, int *__restrict__ out)
+{
+    __shared__ double s_edge[OVL_MAX_BINS + 1];
+    __shared__ int s_h1[OVL_MAX_BINS], s_h2[OVL_MAX_BINS];
+    __shared__ double s_red[4];
+    const int tid = threadIdx.x;
+    double lo = 1.0 / 0.0, hi = -1.0 / 0.0;
+    for (int i = tid; i < n1 + n2; i += 256) { const double v = i < n1 ? d1[i] : d2[i - n1]; lo = fmin(lo, v); hi = fmax(hi, v); }
+    lo = block_minmax(lo, false, s_red); hi = block_minmax(hi, true, s_red);
+    if (lo == hi) { lo -= 0.5; hi += 0.5; }
+    const double step = (hi - lo) / (double)bins;
+    for (int i = tid; i <= bins; i += 256) s_edge[i] = i == bins ? hi : (double)i * step + lo;      // np.linspace: arange * step + start, last = stop
+    for (int i = tid; i < bins; i += 256) { s_h1[i] = 0; s_h2[i] = 0; }
+    __syncthreads();
+    for (int i = tid; i < n1 + n2; i += 256) {
+        const double v = i < n1 ? d1[i] : d2[i - n1];
+        int a = 0, b = bins;                                    // largest k with edge[k] <= v (searchsorted side='right' - 1)
+        while (a < b) { const int m = (a + b + 1) >> 1; if (s_edge[m] <= v) a = m; else b = m - 1; }
+        const int k = a == bins ? bins - 1 : a;                 // v == last edge falls into the last bin
+        if (v >= s_edge[0] && v <= s_edge[bins]) atomicAdd(i < n1 ? &s_h1[k] : &s_h2[k], 1);
+    }
+    __syncthreads();
+    double acc = 0.0;
+    for (int i = tid; i < bins; i += 256) acc += (double)min(s_h1[i], s_h2[i]);
+    acc = block_sum(acc, s_red);
+    if (tid == 0) *out = (int)acc;
+}
+
+void ofk_launch_hist_overlap(hipStream_t s, const double *d1, int n1, const double *d2, int n2, int bins, int *out)
+{
+    hipLaunchKernelGGL(k_hist_overlap, dim3(1), dim3(256), 0, s, d1, n1, d2, n2, bins, out);
+}
+
 // ------------------------------------------------------------------------------------------------ per-feature estimators
 // of_library.py:270-286 (calc_height), :53-75 + :100-114 (convert_to_of inside dynamic_immobile), :291-317 (eval_ft), batched
 // over track sets: one block per set.  The reference's functions carry undefined names; the formulas are the
 // ones they spell out, restated in oracle/estimation_oracle.py.  f64 throughout, same operation order as the oracle.
-__device__ __forceinline__ double block_minmax(double v, bool want_max, double *s_red)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const double u = __shfl_xor(v, o);
-        v = want_max ? fmax(v, u) : fmin(v, u);
-    }
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    const double a = want_max ? fmax(s_red[0], s_red[1]) : fmin(s_red[0], s_red[1]);
-    const double b = want_max ? fmax(s_red[2], s_red[3]) : fmin(s_red[2], s_red[3]);
-    return want_max ? fmax(a, b) : fmin(a, b);
-}
 
 __global__ __launch_bounds__(256) void k_feature_eval(const double *__restrict__ pos, const double *__restrict__ pos_err,
                                                       const double *__restrict__ oldpos, const double *__restrict__ oldpos_err,

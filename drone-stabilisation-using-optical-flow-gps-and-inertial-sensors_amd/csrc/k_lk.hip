@@ -236,17 +236,9 @@ __global__ __launch_bounds__(64) void k_lk(const uint8_t *__restrict__ prev, con
 //     4 v_readlane, int64 scalar adds — no LDS traffic, no ds_bpermute.
 // compiler-level ordering of LDS accesses inside the single wave of a workgroup (see the staging code of k_lk15)
 #define LDS_FENCE() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
-#ifndef LK_PATCH_ON
-#define LK_PATCH_ON true                             /* timing experiments only */
-#endif
-#ifndef LK_ITER_CAP
-#define LK_ITER_CAP(n) (n)                            /* timing experiments only (tools/variants.sh): cap the Newton iterations */
-#endif
 #define LKF_IP 24                                  // pitch of the staged prev neighbourhood (18 x 18 used)
 #define LKF_JW 32                                  // staged next region: 32 x 32 = win + 1 + 2*LK_M at win 15
-#ifndef LKF_JP
 #define LKF_JP 40                                  // its LDS pitch: 10 banks per row, so the 16 rows a wave reads together hit 16 different bank groups (pitch 32: 4-way conflicts)
-#endif
 
 __device__ __forceinline__ int row_sum16(int v)
 {
@@ -262,45 +254,19 @@ __device__ __forceinline__ long long wave_sum_rows(int v)
     return (long long)__builtin_amdgcn_readlane(v, 0) + (long long)__builtin_amdgcn_readlane(v, 16) +
            (long long)__builtin_amdgcn_readlane(v, 32) + (long long)__builtin_amdgcn_readlane(v, 48);
 }
-// f32(S * 2^-20) of an exact integer S, round to nearest even — bit for bit what (float)((double)S * 0x1p-20) returns (the
-// double is exact, the scaling a power of two).  S is wave-uniform, so the whole conversion runs on the SCALAR unit
-// (s_flbit_i32_b64, 64-bit shifts); the f64 route cost ten half-rate VALU instructions per sum, two sums per Newton step.
-__device__ __forceinline__ float scaled_f32_from_i64(long long S)
-{
-    if (S == 0) return 0.f;
-    const unsigned sign = S < 0 ? 0x80000000u : 0u;
-    const unsigned long long M = S < 0 ? (unsigned long long)(-S) : (unsigned long long)S;
-    const int e = 63 - __builtin_clzll(M);                                        // position of the leading one
-    unsigned q;                                                                    // 24-bit significand, leading one included
-    if (e <= 23) {
-        q = (unsigned)(M << (23 - e));
-    } else {
-        const int sh = e - 23;
-        q = (unsigned)(M >> sh);
-        const unsigned long long rem = M & ((1ull << sh) - 1), half = 1ull << (sh - 1);
-        q += (unsigned)((rem > half) | ((rem == half) & (q & 1u)));               // may carry into 2^24: the add below absorbs it
-    }
-    return __uint_as_float(sign | (((unsigned)(e - 20 + 126) << 23) + q));         // (E-1) << 23 plus the significand with its leading one
-}
 __device__ __forceinline__ float wave_sum_rows_scaled(int v)
 {
     v = row_sum16(v);
-#ifdef OFK_LK_SCALAR_CVT          /* measured: the scalar route is 5 % slower (three scalar branches, 64-bit compares fall back to the VALU) */
-    const long long S = (long long)__builtin_amdgcn_readlane(v, 0) + (long long)__builtin_amdgcn_readlane(v, 16) +
-                        (long long)__builtin_amdgcn_readlane(v, 32) + (long long)__builtin_amdgcn_readlane(v, 48);
-    return scaled_f32_from_i64(S);
-#elif defined(OFK_LK_F64_ADDS)
-    // the sum of four int32 row sums is exact in f64, so this equals f32(f64(int64 sum) * 2^-20)
-    const double d = ((double)__builtin_amdgcn_readlane(v, 0) + (double)__builtin_amdgcn_readlane(v, 16)) +
-                     ((double)__builtin_amdgcn_readlane(v, 32) + (double)__builtin_amdgcn_readlane(v, 48));
-    return (float)(d * 0x1p-20);
-#else
     // the four row sums are added as 64-bit integers on the scalar unit (they sit in SGPRs after v_readlane); the int64 is
     // below 2^33, so its f64 image and the scaling are exact and one rounding to f32 remains — as in the oracle
     const long long S = ((long long)__builtin_amdgcn_readlane(v, 0) + (long long)__builtin_amdgcn_readlane(v, 16)) +
                         ((long long)__builtin_amdgcn_readlane(v, 32) + (long long)__builtin_amdgcn_readlane(v, 48));
+    // Nearly every sum fits 32 bits (the mismatch sums always do in practice): v_cvt_f32_i32 rounds to nearest even exactly as
+    // f64 -> f32 does, and the scaling is a power of two, so one conversion + one multiply replace ten half-rate f64
+    // instructions.  S is wave-uniform: the test and the branch run on the scalar unit.
+    const int s32 = (int)S;
+    if (__builtin_expect((long long)s32 == S, 1)) return (float)s32 * 0x1p-20f;
     return (float)((double)S * 0x1p-20);
-#endif
 }
 
 // 5 consecutive bytes starting at byte offset `off` of an LDS byte array (4-byte aligned base)
@@ -333,7 +299,7 @@ __device__ __forceinline__ unsigned lk_as_u(lk_s2 v) { return __builtin_bit_cast
 __device__ __forceinline__ int lk_dot2(unsigned a, unsigned w, int acc) { return __builtin_amdgcn_sdot2(lk_as_s2(a), lk_as_s2(w), acc, false); }
 #define LK_PAIR_SEL(k) ((unsigned)(k) | 0x0c00u | ((unsigned)((k) + 1) << 16) | 0x0c000000u)   /* v_perm selector: (byte k, 0, byte k+1, 0) */
 
-__global__ __launch_bounds__(64) void k_lk15(const uint8_t *__restrict__ prev, const uint8_t *__restrict__ next,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_lk15(const uint8_t *__restrict__ prev, const uint8_t *__restrict__ next,
                                              size_t pyr_stride, ofk_levels lv, const float *__restrict__ prev_pts,
                                              const int *__restrict__ counts, int pts_stride, int win, int max_count,
                                              double eps2, float eps2_lo, float eps2_hi, double min_eig_thr,
@@ -457,7 +423,7 @@ __global__ __launch_bounds__(64) void k_lk15(const uint8_t *__restrict__ prev, c
         lk_weights(px - (float)ipx, py - (float)ipy, w00, w01, w10, w11);
         int a11 = 0, a12 = 0, a22 = 0;
         pI[0] = pI[1] = pI[2] = pI[3] = 0; pIx[0] = pIx[1] = pIx[2] = pIx[3] = 0; pIy[0] = pIy[1] = pIy[2] = pIy[3] = 0;
-        if (LK_PATCH_ON && npx > 0) {
+        if (npx > 0) {
             // rows wy..wy+3 of s_I, columns wx0..wx0+7 (the staged rows are dword aligned): P[r][k] = (n[r][k], n[r][k+1])
             unsigned P[4][7];
 #pragma unroll
@@ -525,7 +491,7 @@ __global__ __launch_bounds__(64) void k_lk15(const uint8_t *__restrict__ prev, c
         }
         D = 1.f / D;
         float pdx = 0.f, pdy = 0.f;
-        for (int j = 0; j < LK_ITER_CAP(max_count); ++j) {
+        for (int j = 0; j < max_count; ++j) {
             // every lane holds the same position: move the integer part to the scalar unit (bounds tests, LDS offsets)
             const int iqx = __builtin_amdgcn_readfirstlane((int)floorf(qx)), iqy = __builtin_amdgcn_readfirstlane((int)floorf(qy));
             if (iqx < -win || iqx >= lw || iqy < -win || iqy >= lh) {
@@ -612,9 +578,6 @@ void ofk_launch_lk(hipStream_t s, const uint8_t *prev, const uint8_t *next, size
     if (win <= 15)
         hipLaunchKernelGGL(k_lk15, grid, dim3(64), 0, s, prev, next, pyr_stride, lv, prev_pts, counts, pts_stride, win,
                            max_count, eps2, (float)(eps2 * (1.0 - 1e-5)), (float)(eps2 * (1.0 + 1e-5)), min_eig_thr, next_pts, status, err);
-    else if (win <= 15)
-        hipLaunchKernelGGL(k_lk<15>, grid, dim3(64), 0, s, prev, next, pyr_stride, lv, prev_pts, counts, pts_stride, win,
-                           max_count, eps2, min_eig_thr, next_pts, status, err);
     else if (win <= 21)
         hipLaunchKernelGGL(k_lk<21>, grid, dim3(64), 0, s, prev, next, pyr_stride, lv, prev_pts, counts, pts_stride, win,
                            max_count, eps2, min_eig_thr, next_pts, status, err);

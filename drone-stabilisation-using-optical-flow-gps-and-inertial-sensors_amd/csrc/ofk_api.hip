@@ -19,6 +19,7 @@ int ofk_fail(ofk_ctx *ctx, int code, const char *fmt, ...)
     return code;
 }
 
+#define TRY(expr) do { int rc_ = (expr); if (rc_ != OFK_OK) return rc_; } while (0)
 static size_t up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 ofk_levels ofk_make_levels(int h, int w, int win, int max_level)
@@ -185,33 +186,49 @@ static int need_streams(ofk_ctx *c, int slices, bool overlap)
 // The last slice's stream once every other slice of the latest call has finished: where record export and marks are queued while
 // the slices are open.  The slices are offset in time and the last one finishes last, so the waits cost it nothing; a stream of
 // their own would have to share a hardware queue with one of the slices.
-static hipStream_t tail_stream(ofk_ctx *c)
+static int tail_stream(ofk_ctx *c, hipStream_t *out)
 {
-    if (!c->slices_open) return c->stream;
+    *out = c->stream;
+    if (!c->slices_open) return OFK_OK;
     hipStream_t s = c->streams[c->open_slices - 1];
-    for (int k = 0; k + 1 < c->open_slices; ++k) hipStreamWaitEvent(s, c->ev_end[k], 0);
-    return s;
+    for (int k = 0; k + 1 < c->open_slices; ++k) OFK_HIP(c, hipStreamWaitEvent(s, c->ev_end[k], 0));
+    *out = s;
+    return OFK_OK;
 }
 
-static void join_slices(ofk_ctx *c)
+static int join_slices(ofk_ctx *c)
 {
     if (c->slices_open) {
-        for (int k = 1; k < c->open_slices; ++k) hipStreamWaitEvent(c->stream, c->ev_end[k], 0);
+        for (int k = 1; k < c->open_slices; ++k) OFK_HIP(c, hipStreamWaitEvent(c->stream, c->ev_end[k], 0));
         c->slices_open = 0;
     }
     if (c->x_pending) {
-        hipStreamWaitEvent(c->stream, c->ev_x, 0);
+        OFK_HIP(c, hipStreamWaitEvent(c->stream, c->ev_x, 0));
         c->x_pending = 0;
     }
+    return OFK_OK;
 }
 
-void ofk_join_slices(ofk_ctx *c) { join_slices(c); }
+int ofk_join_slices(ofk_ctx *c) { return join_slices(c); }
 
 extern "C" int ofk_sync(ofk_ctx *c)
 {
     if (!c) return OFK_E_INVALID;
-    join_slices(c);
+    TRY(join_slices(c));
     OFK_HIP(c, hipStreamSynchronize(c->stream));
+    return OFK_OK;
+}
+
+// every stream of the context idle (slice, auxiliary and context stream)
+static int drain_all(ofk_ctx *c)
+{
+    OFK_HIP(c, hipSetDevice(c->device));
+    TRY(join_slices(c));
+    OFK_HIP(c, hipStreamSynchronize(c->stream));
+    for (int k = 0; k < OFK_MAX_STREAMS; ++k) {
+        if (k && c->streams[k]) OFK_HIP(c, hipStreamSynchronize(c->streams[k]));
+        if (c->aux[k]) OFK_HIP(c, hipStreamSynchronize(c->aux[k]));
+    }
     return OFK_OK;
 }
 
@@ -231,7 +248,7 @@ static int check_geom(ofk_ctx *c, int batch, int h, int w, const char *who)
     if (hipSetDevice(c->device) != hipSuccess) return ofk_fail(c, OFK_E_HIP, "hipSetDevice failed");
     if (batch < 1 || batch > c->max_batch || h < 1 || w < 1 || (size_t)h * w > c->P || h > 16384 || w > 16384)
         return ofk_fail(c, OFK_E_INVALID, "%s: batch %d / %dx%d exceeds the context (batch %d, %zu px)", who, batch, w, h, c->max_batch, c->P);
-    join_slices(c);
+    TRY(join_slices(c));
     return OFK_OK;
 }
 
@@ -253,7 +270,6 @@ static int check_launch(ofk_ctx *c, const char *who)
     if (e != hipSuccess) return ofk_fail(c, OFK_E_HIP, "%s: kernel launch failed: %s", who, hipGetErrorString(e));
     return OFK_OK;
 }
-#define TRY(expr) do { int rc_ = (expr); if (rc_ != OFK_OK) return rc_; } while (0)
 
 static int lazy_mask(ofk_ctx *c)
 {
@@ -392,14 +408,6 @@ extern "C" int ofk_good_features(ofk_ctx *c, const uint8_t *gray, const uint8_t 
     ofk_launch_select(c->stream, c->cand, c->cand_cap, c->cand_count, c->cand_seg, segcap, c->seg_count, nseg, c->maxbits, quality, w,
                       max_corners, (float)min_distance, c->pts_prev, c->max_pts, c->counts, nullptr, batch);
     TRY(check_launch(c, "corner detection"));
-    if (getenv("OFK_DEBUG")) {
-        unsigned mb[4 * OFK_MAX_STRIDE] = {0}; int cc[4 * OFK_CNT_STRIDE] = {0}; int cn[4] = {0};
-        hipStreamSynchronize(c->stream);
-        hipMemcpy(mb, c->maxbits, 4 * OFK_MAX_STRIDE * (batch < 4 ? batch : 4), hipMemcpyDeviceToHost);
-        hipMemcpy(cc, c->cand_count, 4 * OFK_CNT_STRIDE * (batch < 4 ? batch : 4), hipMemcpyDeviceToHost);
-        hipMemcpy(cn, c->counts, 4 * (batch < 4 ? batch : 4), hipMemcpyDeviceToHost);
-        for (int b = 0; b < batch && b < 4; ++b) fprintf(stderr, "[ofk debug] image %d: maxbits 0x%08x candidates %d corners %d\n", b, mb[b * OFK_MAX_STRIDE], cc[b * OFK_CNT_STRIDE], cn[b]);
-    }
     return fetch_corners(c, batch, max_corners, pts, counts);
 }
 
@@ -501,7 +509,7 @@ static int est_begin(ofk_ctx *c, size_t bytes, Bump &bp)
 {
     if (!c) return OFK_E_INVALID;
     if (hipSetDevice(c->device) != hipSuccess) return ofk_fail(c, OFK_E_HIP, "hipSetDevice failed");
-    join_slices(c);
+    TRY(join_slices(c));
     TRY(ofk_need_scratch(c, bytes + 64 * 256));
     bp.c = c; bp.base = (char *)c->scratch; bp.off = 0; bp.rc = OFK_OK;
     return OFK_OK;
@@ -700,6 +708,39 @@ extern "C" int ofk_of_simulation(ofk_ctx *c, const double *truth, const double *
     return get(c, bound, db, (size_t)trials * 8);
 }
 
+extern "C" int ofk_feas_simulation(ofk_ctx *c, const double *truth, const double *sig, const double *pos, const double *true_flow,
+                                   int n, const double *z, int trials, double *mean, double *per_trial, double *v_obs)
+{
+    if (!c || !truth || !sig || !pos || !true_flow || !z || !mean || n < 1 || trials < 1)
+        return ofk_fail(c, OFK_E_INVALID, "ofk_feas_simulation: bad argument");
+    const size_t zb = (size_t)trials * (14 + 4 * (size_t)n) * 8, pb = (size_t)trials * 6 * n * 8;
+    Bump bp;
+    TRY(est_begin(c, zb + pb + (size_t)n * 32 + (size_t)n * 48 + (size_t)trials * 24 + 8 * 256, bp));
+    double *dt = bp.put(truth, OFK_FEAS_SIM_TRUTH * 8), *ds = bp.put(sig, OFK_FEAS_SIM_SIG * 8), *dp = bp.put(pos, (size_t)n * 16),
+           *df = bp.put(true_flow, (size_t)n * 16), *dz = bp.put(z, zb), *dper = bp.take(pb), *dmean = bp.take((size_t)n * 48),
+           *dv = bp.take((size_t)trials * 24);
+    if (bp.rc) return ofk_fail(c, OFK_E_HIP, "ofk_feas_simulation: upload failed");
+    ofk_launch_feas_simulation(c->stream, dt, ds, dp, df, n, dz, trials, dper, dmean, dv);
+    TRY(check_launch(c, "k_feas_simulation"));
+    if (per_trial) TRY(get(c, per_trial, dper, pb));
+    if (v_obs) TRY(get(c, v_obs, dv, (size_t)trials * 24));
+    return get(c, mean, dmean, (size_t)n * 48);
+}
+
+extern "C" int ofk_hist_overlap(ofk_ctx *c, const double *data1, int n1, const double *data2, int n2, int bins, int *overlap)
+{
+    if (!c || !data1 || !data2 || !overlap || n1 < 1 || n2 < 1 || bins < 1 || bins > 1024)
+        return ofk_fail(c, OFK_E_INVALID, "ofk_hist_overlap: bad argument (bins 1..1024, both samples non-empty)");
+    Bump bp;
+    TRY(est_begin(c, ((size_t)n1 + n2) * 8 + 1024, bp));
+    double *d1 = bp.put(data1, (size_t)n1 * 8), *d2 = bp.put(data2, (size_t)n2 * 8);
+    int *dout = (int *)bp.take(16);
+    if (bp.rc) return ofk_fail(c, OFK_E_HIP, "ofk_hist_overlap: upload failed");
+    ofk_launch_hist_overlap(c->stream, d1, n1, d2, n2, bins, dout);
+    TRY(check_launch(c, "k_hist_overlap"));
+    return get(c, overlap, dout, 4);
+}
+
 // ------------------------------------------------------------------------------------------------ resident pipeline
 extern "C" int ofk_pairs_upload(ofk_ctx *c, const uint8_t *prev_bgr, const uint8_t *next_bgr, int batch, int h, int w)
 {
@@ -721,7 +762,7 @@ extern "C" int ofk_pairs_upload_jpeg(ofk_ctx *c, const uint8_t *const *prev_jpeg
     if (!c) return OFK_E_INVALID;
     if (hipSetDevice(c->device) != hipSuccess) return ofk_fail(c, OFK_E_HIP, "hipSetDevice failed");
     if (batch < 1 || batch > c->max_batch) return ofk_fail(c, OFK_E_INVALID, "ofk_pairs_upload_jpeg: batch %d exceeds the context (%d)", batch, c->max_batch);
-    join_slices(c);
+    TRY(join_slices(c));
     int h0 = 0, w0 = 0, h1 = 0, w1 = 0;
     c->cur_batch = 0;
     TRY(ofk_jpeg_decode_device(c, prev_jpeg, prev_bytes, batch, c->bgr[0], c->bgr_stride, c->P, &h0, &w0, nullptr, nullptr));
@@ -736,7 +777,7 @@ extern "C" int ofk_jpeg_decode_bgr8(ofk_ctx *c, const uint8_t *const *jpeg, cons
     if (!c) return OFK_E_INVALID;
     if (hipSetDevice(c->device) != hipSuccess) return ofk_fail(c, OFK_E_HIP, "hipSetDevice failed");
     if (!bgr) return ofk_fail(c, OFK_E_INVALID, "ofk_jpeg_decode_bgr8: NULL output");
-    join_slices(c);
+    TRY(join_slices(c));
     int h = 0, w = 0;
     uint8_t *dev = nullptr;
     size_t stride = 0;
@@ -747,7 +788,7 @@ extern "C" int ofk_jpeg_decode_bgr8(ofk_ctx *c, const uint8_t *const *jpeg, cons
 extern "C" int ofk_pairs_set_sensors(ofk_ctx *c, const double *sensors, int batch)
 {
     if (!c || !sensors || batch < 1 || batch > c->max_batch) return ofk_fail(c, OFK_E_INVALID, "ofk_pairs_set_sensors: bad argument");
-    join_slices(c);
+    TRY(join_slices(c));
     OFK_HIP(c, hipMemcpyAsync(c->sensors, sensors, (size_t)batch * OFK_SENSOR_DOUBLES * 8, hipMemcpyHostToDevice, c->stream));
     OFK_HIP(c, hipStreamSynchronize(c->stream));
     return OFK_OK;
@@ -805,15 +846,15 @@ extern "C" int ofk_pairs_run(ofk_ctx *c, const ofk_params *p)
     const bool fork = S > 1 && !c->slices_open;
     TRY(need_streams(c, S, overlap));
     if (fork) {
-        hipEventRecord(c->ev_fork, c->stream);
-        for (int k = 1; k < S; ++k) hipStreamWaitEvent(c->streams[k], c->ev_fork, 0);
+        OFK_HIP(c, hipEventRecord(c->ev_fork, c->stream));
+        for (int k = 1; k < S; ++k) OFK_HIP(c, hipStreamWaitEvent(c->streams[k], c->ev_fork, 0));
     }
     for (int k = 0; k < S; ++k) {
         const int b0 = (int)((long long)B * k / S), nb = (int)((long long)B * (k + 1) / S) - b0;
         if (nb <= 0) continue;
         hipStream_t st = k == 0 ? c->stream : c->streams[k];
         hipStream_t sa = overlap ? c->aux[k] : st;
-        if (overlap) hipStreamWaitEvent(sa, c->ev_lkdone[set][k], 0);
+        if (overlap) OFK_HIP(c, hipStreamWaitEvent(sa, c->ev_lkdone[set][k], 0));
         uint8_t *bgr0 = c->bgr[0] + (size_t)b0 * c->bgr_stride, *bgr1 = c->bgr[1] + (size_t)b0 * c->bgr_stride;
         uint8_t *pyr0 = P0 + (size_t)b0 * c->pyr_stride, *pyr1 = P1 + (size_t)b0 * c->pyr_stride;
         unsigned int *maxbits = c->maxbits + (size_t)b0 * OFK_MAX_STRIDE;
@@ -829,7 +870,7 @@ extern "C" int ofk_pairs_run(ofk_ctx *c, const ofk_params *p)
             StageTimer t(c, OFK_STAGE_GRAY, sa);
             ofk_launch_gray(sa, bgr0, c->bgr_stride, pyr0, c->pyr_stride, nb, h, w);
         }
-        if (overlap) hipEventRecord(c->ev_g0[k], sa);
+        if (overlap) OFK_HIP(c, hipEventRecord(c->ev_g0[k], sa));
         {
             StageTimer t(c, OFK_STAGE_GRAY, sa);
             ofk_launch_gray(sa, bgr1, c->bgr_stride, pyr1, c->pyr_stride, nb, h, w);
@@ -841,38 +882,38 @@ extern "C" int ofk_pairs_run(ofk_ctx *c, const ofk_params *p)
                                      pyr1 + lv.off[l], c->pyr_stride, nb);
         }
         if (overlap) {
-            hipEventRecord(c->ev_aux[k], sa);
-            hipStreamWaitEvent(st, c->ev_g0[k], 0);              // the response kernel needs the previous frame's gray level
+            OFK_HIP(c, hipEventRecord(c->ev_aux[k], sa));
+            OFK_HIP(c, hipStreamWaitEvent(st, c->ev_g0[k], 0));              // the response kernel needs the previous frame's gray level
         }
-        if (fork && k > 0) hipStreamWaitEvent(st, c->ev_stagger[k - 1], 0);
+        if (fork && k > 0) OFK_HIP(c, hipStreamWaitEvent(st, c->ev_stagger[k - 1], 0));
         {
             StageTimer t(c, OFK_STAGE_EIG, st);                  // response + 3x3 NMS + candidate keys, no map in HBM
-            hipMemsetAsync(maxbits, 0, (size_t)nb * OFK_MAX_STRIDE * 4, st);
-            hipMemsetAsync(cand_count, 0, (size_t)nb * OFK_CNT_STRIDE * 4, st);
+            OFK_HIP(c, hipMemsetAsync(maxbits, 0, (size_t)nb * OFK_MAX_STRIDE * 4, st));
+            OFK_HIP(c, hipMemsetAsync(cand_count, 0, (size_t)nb * OFK_CNT_STRIDE * 4, st));
             if (ofk_launch_mineig_cand(st, pyr0, c->pyr_stride, h, w, p->block_size, maxbits, nullptr, 0, p->quality, cand, c->cand_cap,
                                        cand_count, cand_seg, c->seg_keys, seg_count, OFK_SEG_MAX, c->dev_flags, nb, &nseg, &segcap))
                 return ofk_fail(c, OFK_E_INVALID, "corner response: block_size %d does not fit (LDS tile / key segments)", p->block_size);
         }
-        if (fork) hipEventRecord(c->ev_stagger[k], st);
+        if (fork) OFK_HIP(c, hipEventRecord(c->ev_stagger[k], st));
         {
             StageTimer t(c, OFK_STAGE_SELECT, st);
             ofk_launch_select(st, cand, c->cand_cap, cand_count, cand_seg, segcap, seg_count, nseg, maxbits, p->quality, w, p->max_corners,
                               (float)p->min_distance, pts_prev, c->max_pts, counts, nullptr, nb);
         }
-        if (overlap) hipStreamWaitEvent(st, c->ev_aux[k], 0);    // LK needs both pyramids
+        if (overlap) OFK_HIP(c, hipStreamWaitEvent(st, c->ev_aux[k], 0));    // LK needs both pyramids
         {
             StageTimer t(c, OFK_STAGE_LK, st);
             ofk_launch_lk(st, pyr0, pyr1, c->pyr_stride, lv, pts_prev, counts, c->max_pts, p->win, p->max_count, p->eps, p->min_eig_thr,
                           pts_next, status, err, nb);
         }
-        if (overlap) hipEventRecord(c->ev_lkdone[set][k], st);   // this pyramid set may be rewritten from here on
-        if (c->x_pending) hipStreamWaitEvent(st, c->ev_x, 0);    // the previous call's records are still being exported
+        if (overlap) OFK_HIP(c, hipEventRecord(c->ev_lkdone[set][k], st));   // this pyramid set may be rewritten from here on
+        if (c->x_pending) OFK_HIP(c, hipStreamWaitEvent(st, c->ev_x, 0));    // the previous call's records are still being exported
         {
             StageTimer t(c, OFK_STAGE_SOLVE, st);
             ofk_launch_pairs_solve(st, pts_prev, pts_next, status, counts, c->max_pts, c->sensors + (size_t)b0 * OFK_SENSOR_DOUBLES,
                                    p->solve_variant, p->use_feasibility, p->feas_T, cand_count, c->records + (size_t)b0 * OFK_RECORD_DOUBLES, nb);
         }
-        if (S > 1) hipEventRecord(c->ev_end[k], st);             // joined lazily (join_slices), not here
+        if (S > 1) OFK_HIP(c, hipEventRecord(c->ev_end[k], st));             // joined lazily (join_slices), not here
     }
     if (S > 1) { c->slices_open = 1; c->open_slices = S; }
     return check_launch(c, "ofk_pairs_run");
@@ -886,7 +927,7 @@ extern "C" int ofk_pairs_download(ofk_ctx *c, double *records, float *prev_pts, 
     const int B = c->cur_batch;
     const size_t np = (size_t)B * c->max_pts;
     int flags[4];
-    join_slices(c);
+    TRY(join_slices(c));
     OFK_HIP(c, hipMemcpyAsync(flags, c->dev_flags, 16, hipMemcpyDeviceToHost, c->stream));
     if (records) OFK_HIP(c, hipMemcpyAsync(records, c->records, (size_t)B * OFK_RECORD_DOUBLES * 8, hipMemcpyDeviceToHost, c->stream));
     if (prev_pts) OFK_HIP(c, hipMemcpyAsync(prev_pts, c->pts_prev, np * 8, hipMemcpyDeviceToHost, c->stream));
@@ -908,10 +949,11 @@ extern "C" int ofk_pairs_download(ofk_ctx *c, double *records, float *prev_pts, 
 extern "C" int ofk_pairs_export_records_f32(ofk_ctx *c, void *device_dst, int batch)
 {
     if (!c || !device_dst || batch < 1 || batch > c->cur_batch) return ofk_fail(c, OFK_E_INVALID, "ofk_pairs_export_records_f32: bad argument");
-    hipStream_t s = tail_stream(c);
+    hipStream_t s;
+    TRY(tail_stream(c, &s));
     ofk_launch_records_f32(s, c->records, (float *)device_dst, batch);
     if (c->slices_open) {                                        // the other slices' next solve must not overtake the export
-        hipEventRecord(c->ev_x, s);
+        OFK_HIP(c, hipEventRecord(c->ev_x, s));
         c->x_pending = 1;
     }
     return check_launch(c, "k_records_f32");
@@ -1043,10 +1085,12 @@ static int stream_step_impl(ofk_ctx *c, const uint8_t *next_bgr, const double *s
                              c->pts_prev, c->counts, p->max_corners, B);
     TRY(check_launch(c, "ofk_stream_step"));
     if (records) OFK_HIP(c, hipMemcpyAsync(records, c->records, (size_t)B * OFK_RECORD_DOUBLES * 8, hipMemcpyDeviceToHost, c->stream));
-    TRY(stream_fetch_tracks(c, B, p->max_corners, tracks, counts));
+    // The tracks on the device already belong to the new frame (k_update_tracks), so the frame swap happens whatever the fetch
+    // reports (OFK_E_CAPACITY from a re-detection, a failed copy): the next step must track against THIS frame's pyramid.
+    const int rc = stream_fetch_tracks(c, B, p->max_corners, tracks, counts);
     uint8_t *t = c->pyr[0]; c->pyr[0] = c->pyr[1]; c->pyr[1] = t;
     t = c->bgr[0]; c->bgr[0] = c->bgr[1]; c->bgr[1] = t;
-    return OFK_OK;
+    return rc;
 }
 
 extern "C" int ofk_stream_step(ofk_ctx *c, const uint8_t *next_bgr, const double *sensors, const ofk_params *p, int min_features,
@@ -1055,7 +1099,7 @@ extern "C" int ofk_stream_step(ofk_ctx *c, const uint8_t *next_bgr, const double
     if (!c || !next_bgr || !sensors || !p) return ofk_fail(c, OFK_E_INVALID, "ofk_stream_step: NULL argument");
     if (c->stream_batch < 1) return ofk_fail(c, OFK_E_INVALID, "ofk_stream_step: call ofk_stream_begin first");
     if (hipSetDevice(c->device) != hipSuccess) return ofk_fail(c, OFK_E_HIP, "hipSetDevice failed");
-    join_slices(c);
+    TRY(join_slices(c));
     return stream_step_impl(c, next_bgr, sensors, p, min_features, mask_radius, records, tracks, counts);
 }
 
@@ -1065,7 +1109,7 @@ extern "C" int ofk_stream_step_jpeg(ofk_ctx *c, const uint8_t *const *jpeg, cons
     if (!c || !jpeg || !nbytes || !sensors || !p) return ofk_fail(c, OFK_E_INVALID, "ofk_stream_step_jpeg: NULL argument");
     if (c->stream_batch < 1) return ofk_fail(c, OFK_E_INVALID, "ofk_stream_step_jpeg: call ofk_stream_begin / ofk_stream_begin_jpeg first");
     if (hipSetDevice(c->device) != hipSuccess) return ofk_fail(c, OFK_E_HIP, "hipSetDevice failed");
-    join_slices(c);
+    TRY(join_slices(c));
     int h = 0, w = 0;
     TRY(ofk_jpeg_decode_device(c, jpeg, nbytes, c->stream_batch, c->bgr[1], c->bgr_stride, c->P, &h, &w, nullptr, nullptr));
     if (h != c->stream_h || w != c->stream_w)
@@ -1076,7 +1120,10 @@ extern "C" int ofk_stream_step_jpeg(ofk_ctx *c, const uint8_t *const *jpeg, cons
 extern "C" int ofk_set_streams(ofk_ctx *c, int nstreams)
 {
     if (!c || nstreams < 1 || nstreams > OFK_MAX_STREAMS) return ofk_fail(c, OFK_E_INVALID, "ofk_set_streams: 1..%d", OFK_MAX_STREAMS);
-    join_slices(c);
+    // A different slice count moves the slice boundaries: a new slice's auxiliary stream would only wait for the LK of the OLD
+    // slice with the same index (ev_lkdone[set][k]) while another old slice may still read the pyramid rows it is about to
+    // rewrite.  Changing the schedule is rare (set-up time), so drain everything.
+    TRY(drain_all(c));
     c->nstreams = nstreams;
     return OFK_OK;
 }
@@ -1084,6 +1131,7 @@ extern "C" int ofk_set_streams(ofk_ctx *c, int nstreams)
 extern "C" int ofk_set_overlap(ofk_ctx *c, int on)
 {
     if (!c) return OFK_E_INVALID;
+    TRY(drain_all(c));                                           // same hazard as ofk_set_streams
     c->overlap = on ? 1 : 0;
     return OFK_OK;
 }
@@ -1093,7 +1141,9 @@ extern "C" int ofk_mark(ofk_ctx *c, int slot)
     if (!c || slot < 0 || slot >= 8) return ofk_fail(c, OFK_E_INVALID, "ofk_mark: slot 0..7");
     OFK_HIP(c, hipSetDevice(c->device));
     if (!c->marks[slot]) OFK_HIP(c, hipEventCreateWithFlags(&c->marks[slot], hipEventDisableTiming));
-    OFK_HIP(c, hipEventRecord(c->marks[slot], tail_stream(c)));  // "everything enqueued so far" includes every slice
+    hipStream_t s;
+    TRY(tail_stream(c, &s));                                     // "everything enqueued so far" includes every slice
+    OFK_HIP(c, hipEventRecord(c->marks[slot], s));
     return OFK_OK;
 }
 
@@ -1115,7 +1165,7 @@ extern "C" int ofk_profile_enable(ofk_ctx *c, int stage_mask)
 extern "C" int ofk_profile_read(ofk_ctx *c, double *ms_total, int *launches)
 {
     if (!c || !ms_total || !launches) return OFK_E_INVALID;
-    join_slices(c);
+    TRY(join_slices(c));
     OFK_HIP(c, hipStreamSynchronize(c->stream));
     for (int s = 0; s < OFK_N_STAGES; ++s) { ms_total[s] = 0.0; launches[s] = 0; }
     for (int i = 0; i + 1 < c->ev_n; i += 2) {

@@ -82,7 +82,7 @@ int ofk_fail(ofk_ctx *ctx, int code, const char *fmt, ...);
     } while (0)
 ofk_levels ofk_make_levels(int h, int w, int win, int max_level);   // win <= 0: ignore the winSize stop rule
 int ofk_need_scratch(ofk_ctx *ctx, size_t bytes);
-void ofk_join_slices(ofk_ctx *ctx);                                   // before touching the context's stream / shared buffers
+int ofk_join_slices(ofk_ctx *ctx);                                    // before touching the context's stream / shared buffers
 int ofk_jpeg_decode_device(ofk_ctx *c, const uint8_t *const *jpeg, const size_t *nbytes, int batch, uint8_t *dst, size_t dst_stride,
                            size_t dst_capacity_px, int *h_out, int *w_out, uint8_t **out, size_t *out_stride);   // k_jpeg.hip
 
@@ -142,6 +142,9 @@ void ofk_launch_kf(hipStream_t s, int ns, int nm, int nc, const double *F, const
 void ofk_launch_of_simulation(hipStream_t s, const double *truth, const double *sig, const double *pos,
                               const double *true_flow, int n, const double *z, int trials, double *v_obs,
                               double *bound);
+void ofk_launch_feas_simulation(hipStream_t s, const double *truth, const double *sig, const double *pos, const double *true_flow,
+                                int n, const double *z, int trials, double *per, double *mean, double *v_obs);
+void ofk_launch_hist_overlap(hipStream_t s, const double *d1, int n1, const double *d2, int n2, int bins, int *out);
 void ofk_launch_feature_eval(hipStream_t s, const double *pos, const double *pos_err, const double *oldpos, const double *oldpos_err,
                              const int *counts, int batch, int stride, const double *vel, const double *vel_err, double focal,
                              double dummy, double tx, double ty, const double *weight, double *height, double *height_err,

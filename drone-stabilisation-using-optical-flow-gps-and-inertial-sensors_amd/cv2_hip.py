@@ -41,9 +41,11 @@ def imdecode(buf, flags=IMREAD_COLOR):
     data = np.asarray(buf, dtype=np.uint8).tobytes() if not isinstance(buf, (bytes, bytearray, memoryview)) else bytes(buf)
     try:
         h, w, ncomp = ofk.jpeg_info(data)
-    except ofk.OfkError:
+        if h > ofk.MAX_DIM or w > ofk.MAX_DIM:      # a corrupt SOF header can claim 65535 x 65535: not a frame, no context for it
+            return None
+        img = ofk.default_context(w, h).jpeg_decode([data])[0]
+    except ofk.OfkError:                            # unsupported / truncated stream, or no memory for a frame this size
         return None
-    img = ofk.default_context(w, h).jpeg_decode([data])[0]
     return np.ascontiguousarray(img[:, :, 0]) if (ncomp == 1 and flags == IMREAD_UNCHANGED) else img
 
 
@@ -78,6 +80,8 @@ def calcOpticalFlowPyrLK(prevImg, nextImg, prevPts, nextPts=None, status=None, e
     if winSize[0] != winSize[1]:
         raise NotImplementedError("square windows only (the reference uses (15,15))")
     prevImg = np.asarray(prevImg); nextImg = np.asarray(nextImg)
+    if prevImg.ndim != 2 or prevImg.dtype != np.uint8 or nextImg.shape != prevImg.shape or nextImg.dtype != np.uint8:
+        raise ValueError("calcOpticalFlowPyrLK expects two HxW uint8 images of equal size")
     h, w = prevImg.shape
     pts = np.asarray(prevPts, np.float32).reshape(-1, 2)
     cnt, eps = _criteria(criteria)

@@ -18,6 +18,7 @@ SOLVE_NODE, SOLVE_SIM, SOLVE_OFMODULE = 0, 1, 2
 FEAS_RTILDE, FEAS_LEGACY, FEAS_SIM = 0, 1, 2
 SENSOR_DOUBLES, RECORD_DOUBLES, SOLVE_DOUBLES = 28, 16, 8
 IMU_STATE, IMU_MSG = 24, 15
+MAX_DIM = 16384          # ofk_create rejects larger frames
 STAGES = ("gray", "pyr", "eig", "nms", "select", "lk", "solve")
 
 # every entry point include/ofk.h declares (tests/test_abi.py checks the library exports them all)
@@ -25,7 +26,7 @@ SYMBOLS = (
     "ofk_version", "ofk_last_error", "ofk_device_count", "ofk_create", "ofk_destroy", "ofk_sync", "ofk_device_sync",
     "ofk_gray_bgr8", "ofk_pyr_down_u8", "ofk_pyramid_u8", "ofk_scharr_s16", "ofk_mineig_response", "ofk_select_corners",
     "ofk_good_features", "ofk_lk_pyr", "ofk_flow_model", "ofk_feasibility", "ofk_velocity_solve", "ofk_imu_propagate",
-    "ofk_post_solve", "ofk_kf_predict_update", "ofk_of_simulation", "ofk_associate_sensors", "ofk_feature_eval", "ofk_d_split", "ofk_pairs_upload", "ofk_pairs_upload_jpeg", "ofk_jpeg_info", "ofk_jpeg_decode_bgr8", "ofk_pairs_set_sensors",
+    "ofk_post_solve", "ofk_kf_predict_update", "ofk_of_simulation", "ofk_feas_simulation", "ofk_hist_overlap", "ofk_associate_sensors", "ofk_feature_eval", "ofk_d_split", "ofk_pairs_upload", "ofk_pairs_upload_jpeg", "ofk_jpeg_info", "ofk_jpeg_decode_bgr8", "ofk_pairs_set_sensors",
     "ofk_pairs_run", "ofk_pairs_download", "ofk_pairs_export_records_f32", "ofk_stream_begin", "ofk_stream_step",
     "ofk_stream_begin_jpeg", "ofk_stream_step_jpeg",
     "ofk_set_streams", "ofk_set_overlap", "ofk_mark", "ofk_mark_wait", "ofk_profile_enable", "ofk_profile_read",
@@ -97,6 +98,8 @@ def load_library():
         L.ofk_d_split.argtypes = [vp, vp, vp, i, i, d, vp, vp, vp]
         L.ofk_kf_predict_update.argtypes = [vp, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i]
         L.ofk_of_simulation.argtypes = [vp, vp, vp, vp, vp, i, vp, i, vp, vp]
+        L.ofk_feas_simulation.argtypes = [vp, vp, vp, vp, vp, i, vp, i, vp, vp, vp]
+        L.ofk_hist_overlap.argtypes = [vp, vp, i, vp, i, i, C.POINTER(i)]
         L.ofk_pairs_upload.argtypes = [vp, vp, vp, i, i, i]
         L.ofk_pairs_upload_jpeg.argtypes = [vp, vp, vp, vp, vp, i]
         L.ofk_jpeg_info.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
@@ -277,6 +280,8 @@ class Context:
         prev, single = self._batched(prev, 2)
         nxt, _ = self._batched(nxt, 2)
         prev = _arr(prev, np.uint8); nxt = _arr(nxt, np.uint8)
+        if nxt.shape != prev.shape:
+            raise ValueError(f"lk_pyr: next frame {nxt.shape} does not match the previous frame {prev.shape}")
         B, h, w = prev.shape
         if single:
             pp = _arr(prev_pts, np.float32).reshape(1, -1, 2)
@@ -284,7 +289,11 @@ class Context:
         else:
             pp = _arr(prev_pts, np.float32)
             counts = _arr(counts, np.int32, (B,))
+        if pp.ndim != 3 or pp.shape[0] != B or pp.shape[2] != 2:
+            raise ValueError(f"lk_pyr: prev_pts {pp.shape} is not [{B}, S, 2]")
         S = pp.shape[1]
+        if np.any(counts < 0) or np.any(counts > S):
+            raise ValueError("lk_pyr: counts outside 0..S")
         if S == 0:
             z = np.zeros((0, 1, 2), np.float32)
             return z, np.zeros((0, 1), np.uint8), np.zeros((0, 1), np.float32)
@@ -299,6 +308,8 @@ class Context:
     # ------------------------------------------------------------------ estimation
     def flow_model(self, x, v, omega, d, nrm, t=None):
         x = _arr(x, np.float64)
+        if x.ndim not in (2, 3) or x.shape[-1] != 2:
+            raise ValueError(f"flow_model: x {x.shape} must be [..., n, 2]")
         single = x.ndim == 2
         if single:
             x = x[None]
@@ -313,6 +324,8 @@ class Context:
 
     def feasibility(self, variant, x, u, nrm, v, dist=None, omega=None, t=None):
         x = _arr(x, np.float64); u = _arr(u, np.float64)
+        if u.shape != x.shape or x.shape[-1] != 2:
+            raise ValueError(f"feasibility: x {x.shape} and u {u.shape} must both be [..., n, 2]")
         single = x.ndim == 2
         if single:
             x = x[None]; u = u[None]
@@ -329,6 +342,8 @@ class Context:
     def velocity_solve(self, variant, x, u, d=None, nrm=None, omega=None, t=None, wgt=None, valid=None):
         """Returns out [B,8] = v[3], residual SS, rank, s[3] (single problem: [8])."""
         x = _arr(x, np.float64); u = _arr(u, np.float64)
+        if u.shape[:-1] != x.shape[:-1] or x.shape[-1] != 2 or u.shape[-1] < 2:
+            raise ValueError(f"velocity_solve: x {x.shape} must be [..., n, 2] and u {u.shape} [..., n, >=2] over the same points")
         single = x.ndim == 2
         if single:
             x = x[None]; u = u[None]
@@ -447,6 +462,30 @@ class Context:
         with self._lock:
             self._ck(self._L.ofk_of_simulation(self._h, _p(truth), _p(sig), _p(pos), _p(true_flow), n, _p(z), trials, _p(v), _p(bound)))
         return v, bound
+
+    def feas_simulation(self, truth, sig, pos, true_flow, z, per_trial=False):
+        """simulation.py:70-104 for all trials in one launch.  Returns (mean [6, n] in the reference's return order, v_obs
+        [trials, 3]) and, with per_trial=True, the per-trial table [trials, 6, n] as a third item."""
+        truth = _arr(truth, np.float64, (16,)); sig = _arr(sig, np.float64, (7,))
+        pos = _arr(pos, np.float64); true_flow = _arr(true_flow, np.float64)
+        n = len(pos)
+        if pos.shape != (n, 2) or true_flow.shape != (n, 2):
+            raise ValueError("feas_simulation: pos and true_flow must be [n, 2]")
+        z = _arr(z, np.float64).reshape(-1, 14 + 4 * n)
+        trials = len(z)
+        mean = np.empty((6, n), np.float64); v = np.empty((trials, 3), np.float64)
+        per = np.empty((trials, 6, n), np.float64) if per_trial else None
+        with self._lock:
+            self._ck(self._L.ofk_feas_simulation(self._h, _p(truth), _p(sig), _p(pos), _p(true_flow), n, _p(z), trials, _p(mean), _p(per), _p(v)))
+        return (mean, v, per) if per_trial else (mean, v)
+
+    def hist_overlap(self, data1, data2, bins=100):
+        """overlap(data1, data2) of simulation.py:124-136."""
+        d1 = _arr(np.ravel(data1), np.float64); d2 = _arr(np.ravel(data2), np.float64)
+        out = C.c_int(0)
+        with self._lock:
+            self._ck(self._L.ofk_hist_overlap(self._h, _p(d1), len(d1), _p(d2), len(d2), int(bins), C.byref(out)))
+        return int(out.value)
 
     # ------------------------------------------------------------------ resident frame-pair pipeline
     def pairs_upload(self, prev_bgr, next_bgr):
@@ -612,7 +651,10 @@ def default_context(min_w=0, min_h=0, min_pts=0, min_level=0):
         if c is None or c.max_w * c.max_h < min_w * min_h or c.max_pts < min_pts or c.max_level < min_level:
             w = max(min_w, c.max_w if c else 1920); h = max(min_h, c.max_h if c else 1080)
             pts = max(min_pts, c.max_pts if c else 512); lvl = max(min_level, c.max_level if c else 5)
+            # build the bigger context FIRST: if that fails (a corrupt JPEG header asking for 65535 x 65535, out of memory) the
+            # old one stays in place and the facade keeps working
+            new = Context(int(os.environ.get("OFK_DEVICE", "0")), w, h, 1, pts, lvl)
+            _default = new
             if c is not None:
                 c.close()
-            _default = Context(int(os.environ.get("OFK_DEVICE", "0")), w, h, 1, pts, lvl)
         return _default

@@ -53,6 +53,59 @@ class PipelineConfig:
                           int(self.solve_variant), 1 if self.use_feasibility else 0, float(self.feas_T))
 
 
+@dataclass
+class FilterModel:
+    """Matrices of the per-stream linear Kalman filter (k_kf; ofk_kf_predict_update / the resident filter of FlowStream).
+
+    kf3()  the reference's filter, of_module.py:63-76: cv2.KalmanFilter(3, 3, 0) with F = B = H = I, Q = 1e-5 I, R = 10 I,
+           P0 = 0.1 I, x0 = 0; predict(control) every frame (:122), correct(-v_obs) (:152).
+    ekf6() the build-defined 6-state superset BASELINE.json configs[2] asks for (the reference has no such filter and no GPS
+           data: DESIGN.md §2a): x = [v, b] with b the accelerometer bias in the velocity frame,
+               v' = v + u - b dt,   b' = b          F = [[I, -dt I], [0, I]],  B = [[I], [0]]
+           where the control u is the dead-reckoning increment R (a - 9.81 n) dt of node:80-82; the optical fix measures v
+           (H = [I 0], z = -v_obs as in the reference); with gps=True a second velocity measurement (what a GPS receiver's
+           velocity output would deliver) is stacked under it: H = [[I 0], [I 0]], R = diag(r I, r_gps I).  Both models are
+           linear, so the "EKF" is the Kalman filter itself; kf3 is its restriction to the first three states, and with
+           dt = 0 and no bias noise the v-block of ekf6 reproduces kf3 bit for bit (tested).
+    """
+    F: np.ndarray
+    B: np.ndarray
+    H: np.ndarray
+    Q: np.ndarray
+    R: np.ndarray
+    P0: np.ndarray
+    x0: np.ndarray
+
+    @property
+    def ns(self):
+        return self.F.shape[0]
+
+    @property
+    def nm(self):
+        return self.H.shape[0]
+
+    @property
+    def nc(self):
+        return self.B.shape[1]
+
+    @classmethod
+    def kf3(cls):
+        I = np.eye(3)
+        return cls(F=I.copy(), B=I.copy(), H=I.copy(), Q=1e-5 * I, R=10.0 * I, P0=0.1 * I, x0=np.zeros(3))
+
+    @classmethod
+    def ekf6(cls, dt=1.0 / 30.0, q_v=1e-5, q_b=1e-7, r=10.0, p0=0.1, gps=False, r_gps=1.0):
+        I, Z = np.eye(3), np.zeros((3, 3))
+        F = np.block([[I, -dt * I], [Z, I]])
+        Bm = np.vstack([I, Z])
+        H = np.hstack([I, Z])
+        R = r * I
+        if gps:
+            H = np.vstack([H, np.hstack([I, Z])])
+            R = np.block([[r * I, Z], [Z, r_gps * I]])
+        return cls(F=F, B=Bm, H=H, Q=np.diag([q_v] * 3 + [q_b] * 3), R=R, P0=p0 * np.eye(6), x0=np.zeros(6))
+
+
 class FlowStream:
     """`batch` independent video streams with persistent tracks on the device: the loop of velocity_measurment_node:92-177
     (commented-out blocks restored) / of_module.py:78-167 / evaluate_exp.py:77-121, one frame per `step`.

@@ -176,6 +176,24 @@ int ofk_kf_predict_update(ofk_ctx *ctx, int ns, int nm, int nc, const double *F,
 int ofk_of_simulation(ofk_ctx *ctx, const double *truth, const double *sig, const double *pos, const double *true_flow,
                       int n, const double *z, int trials, double *v_obs, double *bound);
 
+/* feas_simulation(...) - simulation.py:70-104 (driven by the live experiment simulation.py:753-812: three ground planes, the
+ * second one with randomly rotated flow), with the np.random.normal draws supplied by the caller:
+ * z [trials][14+4n] standard normals in the reference's draw order (omega 3, t 3, height 1, flow 2n, position 2n,
+ * velocity 3, orient 1, orient2 1).  truth = v[3] (unused by the reference's function body), omega[3], height, normal[3],
+ * t[3], true_vel[3] (16); sig = ang_vel, translation, height, flow, position, normal, velocity (7; the reference reads the
+ * last two from module globals).  pos, true_flow [n][2].  Per trial: perturbed inputs -> solve_lgs -> feasibility with the
+ * solved velocity ("backward") and with the noisy prior velocity ("forward") -> per-point residual norms of both.
+ * mean [6][n] = np.mean over the trials in the reference's return order: backward_para, backward_dist, forward_para,
+ * forward_dist, backward_res, forward_res; per_trial (nullable) [trials][6][n]; v_obs (nullable) [trials][3]. */
+#define OFK_FEAS_SIM_TRUTH 16
+#define OFK_FEAS_SIM_SIG    7
+int ofk_feas_simulation(ofk_ctx *ctx, const double *truth, const double *sig, const double *pos, const double *true_flow, int n,
+                        const double *z, int trials, double *mean, double *per_trial, double *v_obs);
+
+/* overlap(data1, data2) - simulation.py:124-136: histogram both samples over the `bins` (reference: 100, at most 1024) equal
+ * bins spanning their joint range (np.histogram's edges and bin rule) and sum the bin-wise minima. */
+int ofk_hist_overlap(ofk_ctx *ctx, const double *data1, int n1, const double *data2, int n2, int bins, int *overlap);
+
 /* ------------------------------------------------- resident frame-pair pipeline (the benchmarked path) */
 
 typedef struct ofk_params {

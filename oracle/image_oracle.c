@@ -155,7 +155,7 @@ static int cand_cmp(const void *pa, const void *pb)
     const cand_t *a = (const cand_t *)pa, *b = (const cand_t *)pb;
     if (a->v > b->v) return -1;
     if (a->v < b->v) return 1;
-    return (a->idx > b->idx) - (a->idx < b->idx);   /* tie: lower linear index first */
+    return (a->idx < b->idx) - (a->idx > b->idx);   /* tie: HIGHER linear index first - OpenCV's greaterThanPtr (featureselect.cpp) orders equal values by descending address */
 }
 
 /* ---- S2b: threshold vs q*max, 3x3 local max, sort, greedy min-distance, top-K ----

@@ -1,0 +1,140 @@
+"""GPU: the two BASELINE.json configurations at their stated sizes.
+
+  configs[3]  "8 synthetic 1920x1080 30 fps video streams" — FlowStream (persistent tracks, status filter, masked re-detection;
+              velocity_measurment_node:92-177 restored / of_module.py:78-167) on 8 streams x 31 frames of 1080p in ONE context, the
+              1-GPU stand-in for one stream per GPU.  First frames: tracks / counts / records bit-exact against the oracle loop
+              (tests/stream_oracle.py); all frames: rank 3, velocity within 3 % of the rendered truth, re-detection fires.
+  configs[2]  "batch of 1024 independent 640x480 frame pairs + per-frame 6-state EKF update" at B = 1024: oracle comparison on
+              a sample of the pairs, property checks on all 1024, the per-pair filter (the reference's 3-state one and the
+              6-state superset) through the resident pipeline.
+
+Frames are rendered once per module (numpy, seconds) and mirrored to make 8 streams out of 2 renders: a horizontally flipped
+video is the video of the mirrored motion (v_x, w_y, w_z change sign; the principal point moves to W-1-cx), likewise vertically —
+exact, so every stream has a known truth.
+"""
+import numpy as np
+import pytest
+
+from oracle import image_oracle as io, estimation_oracle as eo
+from stream_oracle import oracle_stream
+
+pytestmark = pytest.mark.gpu
+
+H, W, NF = 1080, 1920, 31
+
+
+def mirrored(frames, info, fx, fy):
+    """(frames, info) of the stream flipped horizontally (fx) and/or vertically (fy)."""
+    v, om = info["v"].copy(), info["omega"].copy()
+    cx, cy = info["cx"], info["cy"]
+    out = frames
+    if fx:
+        out = out[:, :, ::-1]; v[0] = -v[0]; om[1] = -om[1]; om[2] = -om[2]; cx = frames.shape[2] - 1 - cx
+    if fy:
+        out = out[:, ::-1]; v[1] = -v[1]; om[0] = -om[0]; om[2] = -om[2]; cy = frames.shape[1] - 1 - cy
+    return np.ascontiguousarray(out), dict(info, v=v, omega=om, cx=cx, cy=cy)
+
+
+@pytest.fixture(scope="module")
+def streams_1080p(pkg):
+    from of_amd import synth
+    base = [synth.render_sequence(H, W, 2000 + g, NF, v=(0.0030 - 0.0012 * g, -0.0020, 0.0010 + 0.0008 * g),
+                                  omega=(0.0020, -0.0010 + 0.0015 * g, 0.0030 - 0.0045 * g), d=1.0 + 0.5 * g) for g in range(2)]
+    out = []
+    for g in range(2):
+        for fx, fy in ((0, 0), (1, 0), (0, 1), (1, 1)):
+            out.append(mirrored(base[g][0], base[g][1], fx, fy))
+    return out                                                  # 8 x (frames [NF,H,W,3], info)
+
+
+def test_config3_eight_1080p_video_streams(pkg, ofk, streams_1080p):
+    from of_amd.pipeline import FlowStream, PipelineConfig
+    B = len(streams_1080p)
+    cfg = PipelineConfig(max_corners=300, quality=0.01, min_distance=12, block_size=7, win=15, max_level=3, max_count=20, eps=0.03)
+    min_feat, radius, n_exact = 292, 20, 4
+    infos = [s[1] for s in streams_1080p]
+    sensors = np.concatenate([ofk.make_sensors(1, d=i["d"], normal=i["n"], omega=i["omega"], scaling=i["scaling"], cx=i["cx"], cy=i["cy"])
+                              for i in infos])
+    fs = FlowStream(W, H, batch=B, cfg=cfg, min_features=min_feat, mask_radius=radius)
+    tracks, counts = fs.begin(np.stack([s[0][0] for s in streams_1080p]))
+    # the oracle loop on the first frames of three of the streams (an unflipped one, a flipped one, the other render)
+    exact = (0, 3, 5)
+    refs = {b: oracle_stream(streams_1080p[b][0][:n_exact + 1], cfg, sensors[b], min_feat, radius) for b in exact}
+    for b in exact:
+        assert counts[b] == len(refs[b][0]) == cfg.max_corners
+        assert np.array_equal(tracks[b, :counts[b]], refs[b][0])
+    redetected = np.zeros(B, bool)
+    worst = 0.0
+    for t in range(1, NF):
+        rec, tracks, counts = fs.step(np.stack([s[0][t] for s in streams_1080p]), sensors)
+        for b in range(B):
+            n_old, n_tracked = int(rec[b, 12]), int(rec[b, 13])
+            assert 200 <= n_tracked <= n_old <= cfg.max_corners and n_tracked <= counts[b] <= cfg.max_corners, (t, b, rec[b, 11:14], counts[b])
+            assert rec[b, 4] == 3 and np.all(np.isfinite(rec[b, :11])), (t, b)
+            rel = np.linalg.norm(rec[b, :3] - infos[b]["v"]) / np.linalg.norm(infos[b]["v"])
+            worst = max(worst, rel)
+            assert rel < 0.03, (t, b, rec[b, :3], infos[b]["v"])
+            redetected[b] |= counts[b] > n_tracked
+            if b in refs and t <= n_exact:
+                v, tr, ro, rt = refs[b][1][t - 1]
+                assert (n_old, n_tracked) == (ro, rt) and counts[b] == len(tr), (t, b)
+                assert np.array_equal(tracks[b, :counts[b]].view(np.uint32), tr.astype(np.float32).view(np.uint32)), (t, b)
+                np.testing.assert_allclose(rec[b, :3], v, rtol=1e-9, atol=1e-13)
+    assert redetected.all()                                     # tracks leave the frame: every stream re-detects at least once
+    print(f"config3: worst relative velocity error over {B} streams x {NF - 1} steps: {worst:.4f}")
+    fs.close()
+
+
+def test_config2_batch_1024_480p_pairs_with_filter(pkg, ofk):
+    from of_amd import synth
+    from of_amd.pipeline import FlowPipeline, PipelineConfig
+    B, D = 1024, 16
+    rng = np.random.default_rng(1000)
+    base = [synth.render_pair(480, 640, 1000 + i, v=tuple(rng.uniform(-0.004, 0.004, 3)), omega=tuple(rng.normal(0, 0.002, 3)),
+                              d=float(rng.uniform(0.5, 5))) for i in range(D)]
+    prev = np.empty((B, 480, 640, 3), np.uint8); nxt = np.empty_like(prev)
+    for b in range(B):
+        src = base[b % D]; k = b // D
+        sh = ((7 * k) % 480, (13 * k) % 640)                     # cyclic shifts: other pixels, same statistics (truth only holds for k = 0)
+        prev[b] = np.roll(src["prev"], sh, axis=(0, 1)); nxt[b] = np.roll(src["next"], sh, axis=(0, 1))
+    sensors = np.concatenate([ofk.make_sensors(1, d=base[b % D]["d"], normal=base[b % D]["n"], omega=base[b % D]["omega"],
+                                               scaling=base[b % D]["scaling"], cx=base[b % D]["cx"], cy=base[b % D]["cy"]) for b in range(B)])
+    cfg = PipelineConfig(max_corners=150, quality=0.02, min_distance=10, block_size=7)
+    pipe = FlowPipeline(640, 480, B, cfg, streams=2)
+    pipe.upload(prev, nxt, sensors)
+    out = pipe.run()
+    rec, cnt = out["records"], out["counts"]
+    # every pair: corners found, most of them tracked, a full-rank solve, finite numbers
+    assert np.all(cnt == cfg.max_corners) and np.all(rec[:, 12] == cnt) and np.all(rec[:, 13] >= 0.8 * cnt) and np.all(rec[:, 11] == rec[:, 13])
+    assert np.all(rec[:, 4] == 3) and np.all(np.isfinite(rec[:, :11]))
+    for b in range(D):                                           # the unshifted renders carry a physical truth; the translational flow
+        # scales with v / d, so a sub-pixel tracking error of ~0.05 px (scaling = 1/640) costs d * 1e-4 in velocity
+        assert np.linalg.norm(rec[b, :3] - base[b]["v"]) < 0.03 * np.linalg.norm(base[b]["v"]) + 1e-4 * base[b]["d"], (b, rec[b, :3], base[b]["v"], base[b]["d"])
+    for b in (0, 5, 17, 333, 512, 777, 1023):                    # the oracle chain on a sample
+        g0, g1 = io.gray_bgr8(prev[b]), io.gray_bgr8(nxt[b])
+        pts = io.good_features(g0, cfg.max_corners, cfg.quality, cfg.min_distance, cfg.block_size)
+        n, s, e = io.lk_pyr(g0, g1, pts, cfg.win, cfg.max_level, cfg.max_count, cfg.eps, cfg.min_eig_thr)
+        k = int(cnt[b]); ok = s.ravel() == 1
+        assert k == len(pts) and np.array_equal(out["prev_pts"][b, :k], pts.reshape(-1, 2))
+        assert np.array_equal(out["next_pts"][b, :k].view(np.uint32), n.reshape(-1, 2).view(np.uint32)) and np.array_equal(out["status"][b, :k], s.ravel())
+        sr = sensors[b]
+        new = n.reshape(-1, 2).astype(np.float64); old = pts.reshape(-1, 2).astype(np.float64)
+        v = eo.solve_lgs_node((new[ok] - [sr[20], sr[21]]) * sr[19], (new[ok] - old[ok]) * sr[19], sr[0], sr[1:4], sr[4:7])[0]
+        np.testing.assert_allclose(rec[b, :3], v, rtol=1e-9, atol=1e-13)
+    # per-pair filter on all 1024 results: the reference's 3-state filter fed with -v_obs (of_module.py:63-76, 122, 152) ...
+    I = np.eye(3)
+    v_obs = rec[:, :3]
+    x, P = pipe.ctx.kf_predict_update(I, I, 1e-5 * I, 10 * I, np.zeros((B, 3)), np.tile(0.1 * I, (B, 1, 1)), B=I, u=np.zeros((B, 3)), z=-v_obs)
+    pk = 0.1 + 1e-5; kk = pk / (pk + 10)
+    np.testing.assert_allclose(x, kk * -v_obs, rtol=1e-12, atol=1e-18)
+    np.testing.assert_allclose(P, np.tile((1 - kk) * pk * I, (B, 1, 1)), rtol=1e-12, atol=1e-18)
+    # ... and the 6-state superset [v, accelerometer bias], checked against the numpy restatement on a sample
+    from of_amd.pipeline import FilterModel
+    m = FilterModel.ekf6(dt=1.0)
+    x6 = np.zeros((B, 6)); P6 = np.tile(m.P0, (B, 1, 1))
+    gx, gP = pipe.ctx.kf_predict_update(m.F, m.H, m.Q, m.R, x6, P6, z=-v_obs)
+    for b in (0, 23, 511, 1023):
+        xr, Pr = eo.kf_predict(x6[b], P6[b], m.F, m.Q); xr, Pr = eo.kf_correct(xr, Pr, m.H, m.R, -v_obs[b])
+        np.testing.assert_allclose(gx[b], xr, rtol=1e-11, atol=1e-18); np.testing.assert_allclose(gP[b], Pr, rtol=1e-10, atol=1e-14)
+    assert np.all(np.isfinite(gx)) and np.all(np.isfinite(gP))
+    pipe.close()

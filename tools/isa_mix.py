@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""Instruction mix of the VALU-bound kernels' hot loops and the issue-cycle floor that mix implies (runs without a GPU).
+
+  python tools/isa_mix.py [--rates profiles/r02_valu_rates.txt] [--valu profiles/r02_valu_pmc.json] > profiles/r02_isa_mix.json
+
+1. hipcc -S (device only, the product's flags) of k_corners.hip and k_lk.hip.
+2. k_mineig_pair<7,false>: the main loop holds 7 unrolled rows twice (border version, interior version; 2 v_sqrt_f32 per row).
+   The INTERIOR version (the one almost every row of a 1080p frame runs) is the half of the loop body with fewer instructions;
+   its instructions are counted per mnemonic.  k_lk15: the whole kernel body (level set-up + Newton loop).
+3. Every VALU mnemonic is priced with its measured issue cost (tools/valu_rates.hip on the GPU box: ns per wave-instruction
+   per SIMD with 8 waves per SIMD, converted to clocks at the clock the probe ran at = cost relative to v_add_u32 x 2).
+4. issue floor per pair = (dynamic wave-level VALU instructions per pair, SQ_INSTS_VALU from the committed PMC pass)
+                          x (mean issue clocks per VALU instruction of the static mix).
+   bench.py divides that floor (on 1024 SIMDs at 2.4 GHz) by the measured kernel duration -> roofline.isa_mix.frac.
+"""
+import argparse
+import collections
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CS = os.path.join(ROOT, "drone-stabilisation-using-optical-flow-gps-and-inertial-sensors_amd", "csrc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", f"-I{ROOT}/include", f"-I{CS}",
+         "--cuda-device-only", "-S"]
+
+# issue clocks per wave-instruction per SIMD when several waves are ready (defaults = round-1 measurements, DESIGN.md §4;
+# overwritten by --rates): 2 = full rate on the SIMD-32
+DEFAULT_2CLK = {"v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_mov_b32", "v_add_f32", "v_sub_f32", "v_mul_f32", "v_fma_f32",
+                "v_or_b32", "v_xor_b32", "v_not_b32", "v_fmac_f32", "v_subrev_f32"}
+DEFAULT_8CLK = {"v_sqrt_f32", "v_rsq_f32", "v_rcp_f32", "v_exp_f32", "v_log_f32", "v_sin_f32", "v_cos_f32", "v_rcp_iflag_f32"}
+DEFAULT_F64 = 8                                     # f64 adds/muls/converts: half rate or worse
+
+
+def asm_of(src, extra=()):
+    out = tempfile.NamedTemporaryFile(suffix=".s", delete=False).name
+    subprocess.check_call(["/opt/rocm/bin/hipcc", *FLAGS, *extra, os.path.join(CS, src), "-o", out], stderr=subprocess.DEVNULL)
+    return open(out).read().splitlines()
+
+
+def body_of(lines, symbol):
+    i0 = next(i for i, l in enumerate(lines) if l.startswith(symbol + ":"))
+    i1 = next(i for i in range(i0, len(lines)) if ".amdhsa_kernel" in lines[i] or lines[i].startswith(".Lfunc_end"))
+    return lines[i0 + 1:i1]
+
+
+INSTR = re.compile(r"^\s+([vs]_[a-z0-9_]+|ds_[a-z0-9_]+|global_[a-z0-9_]+|buffer_[a-z0-9_]+|flat_[a-z0-9_]+)\b(.*)$")
+
+
+def mnemonics(lines):
+    out = []
+    for l in lines:
+        m = INSTR.match(l)
+        if m:
+            name, rest = m.group(1), m.group(2)
+            dpp = ("_dpp" in name) or any(k in rest for k in ("wave_shr", "wave_shl", "row_shr", "row_shl", "quad_perm", "row_mirror", "row_half_mirror", "row_bcast"))
+            out.append((name, dpp))
+    return out
+
+
+def load_rates(path):
+    """{measured name: clocks} from the output of tools/valu_rates.hip (x-factor relative to v_add_u32 = 2 clocks)."""
+    rates = {}
+    if not path or not os.path.exists(path):
+        return rates
+    for l in open(path):
+        m = re.match(r"^(\S.*?)\s+[\d.]+ ms\s+[\d.]+ ns/instr/SIMD\s+x([\d.]+)", l)
+        if m:
+            rates[m.group(1).strip()] = 2.0 * float(m.group(2))
+    return rates
+
+
+def cost(name, dpp, rates):
+    base = re.sub(r"_(e32|e64|dpp|sdwa|e64_dpp)$", "", name)
+    if dpp:
+        for k in (f"{base}_dpp wave_shr", f"{base}_dpp row_shr"):
+            if k in rates:
+                return round(rates[k])
+        return 4
+    if base in rates:
+        return max(2, round(rates[base]))
+    if base in DEFAULT_2CLK:
+        return 2
+    if base in DEFAULT_8CLK:
+        return 8
+    if "_f64" in base:
+        return DEFAULT_F64
+    return 4
+
+
+def mix(instrs, rates):
+    by = collections.Counter()
+    cyc = collections.Counter()
+    for name, dpp in instrs:
+        if name.startswith("v_") and not name.startswith(("v_readlane", "v_readfirstlane")) or name.startswith(("v_readlane", "v_readfirstlane")):
+            key = re.sub(r"_(e32|e64)$", "", name) + (" (dpp)" if dpp and "_dpp" not in name else "")
+            by[key] += 1
+            cyc[key] += cost(name, dpp, rates)
+    n = sum(by.values()); c = sum(cyc.values())
+    other = collections.Counter()
+    for name, _ in instrs:
+        if name.startswith("ds_"):
+            other["lds"] += 1
+        elif name.startswith("s_"):
+            other["salu"] += 1
+        elif name.startswith(("global_", "buffer_", "flat_")):
+            other["vmem"] += 1
+    classes = collections.Counter()
+    for k in by:
+        classes[f"{cyc[k] // by[k]}-clock"] += by[k]
+    return {"valu_instructions": n, "valu_issue_cycles": c, "mean_cycles_per_valu_instr": round(c / max(1, n), 3),
+            "by_issue_cost": dict(sorted(classes.items())), "lds_instructions": other["lds"], "salu_instructions": other["salu"],
+            "vmem_instructions": other["vmem"], "by_mnemonic": {k: {"count": by[k], "clocks_each": cyc[k] // by[k]} for k in sorted(by, key=lambda k: -cyc[k])}}
+
+
+def pair_interior_rows(body):
+    """The interior 7-row version of k_mineig_pair's loop: split the loop body at the label in front of the 15th v_sqrt_f32."""
+    sq = [i for i, l in enumerate(body) if "v_sqrt_f32" in l]
+    if len(sq) != 28:
+        raise SystemExit(f"expected 28 v_sqrt_f32 in k_mineig_pair<7,false> (2 versions x 7 rows x 2 columns), found {len(sq)}")
+    label = lambda i: max(j for j in range(i) if body[j].startswith(".LBB"))
+    start_a, start_b = label(sq[0]), label(sq[14])
+    end_b = next(j for j in range(sq[27], len(body)) if body[j].startswith(".LBB") and "s_cbranch" not in body[j] and j > sq[27] + 40)
+    half_a, half_b = body[start_a:start_b], body[start_b:end_b]
+    return (half_a, "first") if len(mnemonics(half_a)) < len(mnemonics(half_b)) else (half_b, "second")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rates", default=os.path.join(ROOT, "profiles", "r02_valu_rates.txt"))
+    ap.add_argument("--valu", default=os.path.join(ROOT, "profiles", "r02_valu_pmc.json"))
+    args = ap.parse_args()
+    rates = load_rates(args.rates)
+    try:
+        valu = json.load(open(args.valu))
+    except Exception:
+        valu = json.load(open(os.path.join(ROOT, "profiles", "r01_valu_pmc.json")))
+    out = {"_note": "tools/isa_mix.py: static instruction mix of the hot loops (hipcc -S, product flags), each VALU mnemonic priced with its "
+                    "measured issue cost (tools/valu_rates.hip; 2 clocks = full rate on the SIMD-32), and the issue floor per frame pair = "
+                    "dynamic SQ_INSTS_VALU per pair (PMC) x mean issue clocks per instruction of that mix.",
+           "rates_source": os.path.relpath(args.rates, ROOT) if rates else "defaults (round-1 measurements, DESIGN.md §4)",
+           "valu_source": os.path.relpath(args.valu, ROOT) if os.path.exists(args.valu) else "profiles/r01_valu_pmc.json", "stages": {}}
+    corners = asm_of("k_corners.hip", ["-fno-slp-vectorize"])
+    body = body_of(corners, "_Z13k_mineig_pairILi7ELb0EEvPKhmiiiffPjS1_mdPyiPiS4_")
+    rows, which = pair_interior_rows(body)
+    m = mix(mnemonics(rows), rates)
+    m["scope"] = f"interior version of the 7 unrolled rows ({which} half of the loop body): per wave-row = these counts / 7"
+    m["valu_per_wave_row"] = round(m["valu_instructions"] / 7, 1)
+    m["issue_cycles_per_wave_row"] = round(m["valu_issue_cycles"] / 7, 1)
+    dyn = valu["stages"]["eig"]["SQ_INSTS_VALU_per_launch"] / valu["batch"]
+    m["SQ_INSTS_VALU_per_pair"] = int(dyn)
+    m["valu_issue_cycles_per_pair"] = int(dyn * m["mean_cycles_per_valu_instr"])
+    out["stages"]["eig"] = m
+    lk = asm_of("k_lk.hip")
+    body = body_of(lk, next(l.split(":")[0] for l in lk if l.startswith("_Z6k_lk15")))
+    m = mix(mnemonics(body), rates)
+    m["scope"] = "whole body of k_lk15 (level set-up + Newton loop + error pass), static counts"
+    dyn = valu["stages"]["lk"]["SQ_INSTS_VALU_per_launch"] / valu["batch"]
+    m["SQ_INSTS_VALU_per_pair"] = int(dyn)
+    m["valu_issue_cycles_per_pair"] = int(dyn * m["mean_cycles_per_valu_instr"])
+    out["stages"]["lk"] = m
+    json.dump(out, sys.stdout, indent=1)
+    print()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,18 +1,31 @@
 #!/bin/bash
-# Profiles of one round (GPU box):  bash tools/profile_round.sh <tag> [batch]
+# Profiles of one round (GPU box):  bash tools/profile_round.sh <tag> [batch]     (results under gpurun_out/; copy into profiles/)
+#   0. tools/valu_rates.hip (issue cost per instruction kind)                      -> gpurun_out/<tag>_valu_rates.txt
 #   1. HBM traffic: --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs (kernel trace only, as the pool requires)
-#      -> profiles/r01_traffic_pmc.json (tools/make_traffic_json.py), read by bench.py for roofline.traffic
-#   2. rocprofv3 --kernel-trace --stats of the default bench command and of --no-overlap --streams 1 (every kernel alone on the chip)
-#      -> gpurun_out/prof_<tag>_{overlap,serial}/...kernel_stats.csv (copy into profiles/)
-#   3. the plain bench line -> gpurun_out/bench_<tag>.json
-TAG=${1:-r01}; BATCH=${2:-256}
+#      -> gpurun_out/<tag>_traffic_pmc.json (tools/make_traffic_json.py); bench.py reads profiles/<tag>_traffic_pmc.json for roofline.traffic
+#   2. SQ counters (SQ_INSTS_VALU ...) of every kernel, two runs  -> gpurun_out/<tag>_valu_pmc.json (tools/make_valu_json.py)
+#   3. rocprofv3 --kernel-trace --stats of the default bench command and of --no-overlap --streams 1 (every kernel alone on the chip)
+#      -> gpurun_out/<tag>_kernel_stats_{slices2,serial}.csv
+#   4. the plain bench line -> gpurun_out/<tag>_bench.json
+TAG=${1:-r02}; BATCH=${2:-256}
 R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out
+mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
+if [ -x $R/build_variants/valu_rates ]; then $R/build_variants/valu_rates > $O/${TAG}_valu_rates.txt 2>&1 || exit 1; fi
+QUIET="--cpu-sample 0 --no-ingest"
 for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf $R/gpurun_out/pmc_$c
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_$c -- python3 $R/bench.py --batch $BATCH --steps 2 --warmup 1 --cpu-sample 0 --streams 1 > $R/gpurun_out/pmc_$c.log 2>&1 || { tail -5 $R/gpurun_out/pmc_$c.log; exit 1; }
+  rm -rf $O/pmc_$c
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python3 $R/bench.py --batch $BATCH --steps 2 --warmup 1 $QUIET --streams 1 > $O/pmc_$c.log 2>&1 || { tail -5 $O/pmc_$c.log; exit 1; }
 done
-(cd $R && python3 tools/make_traffic_json.py profiles/r01_traffic_pmc.json $BATCH > gpurun_out/traffic_$TAG.log 2>&1 && cp profiles/r01_traffic_pmc.json gpurun_out/traffic_$TAG.json) || { tail -5 $R/gpurun_out/traffic_$TAG.log; exit 1; }
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_overlap -o p -- python3 $R/bench.py --batch $BATCH --steps 10 --warmup 2 --cpu-sample 0 --no-isolated > $R/gpurun_out/prof_${TAG}_overlap.log 2>&1 || exit 1
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_serial -o p -- python3 $R/bench.py --batch $BATCH --steps 10 --warmup 2 --cpu-sample 0 --no-overlap --streams 1 > $R/gpurun_out/prof_${TAG}_serial.log 2>&1 || exit 1
-cd $R && python3 bench.py --batch $BATCH > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err && python3 tools/show_bench.py gpurun_out/bench_$TAG.json
+(cd $R && python3 tools/make_traffic_json.py gpurun_out/${TAG}_traffic_pmc.json $BATCH > gpurun_out/traffic_$TAG.log 2>&1) || { tail -5 $O/traffic_$TAG.log; exit 1; }
+rm -rf $O/pmc_SQ
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY --output-format csv -d $O/pmc_SQ -- python3 $R/bench.py --batch $BATCH --steps 2 --warmup 1 $QUIET --no-overlap --streams 1 > $O/pmc_SQ.log 2>&1 || { tail -5 $O/pmc_SQ.log; exit 1; }
+rm -rf $O/pmc_SQ2
+rocprofv3 --kernel-trace --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_SQ2 -- python3 $R/bench.py --batch $BATCH --steps 2 --warmup 1 $QUIET --no-overlap --streams 1 > $O/pmc_SQ2.log 2>&1 || { tail -5 $O/pmc_SQ2.log; exit 1; }
+(cd $R && python3 tools/make_valu_json.py gpurun_out/${TAG}_valu_pmc.json $BATCH > gpurun_out/valu_$TAG.log 2>&1) || { tail -5 $O/valu_$TAG.log; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_overlap -o p -- python3 $R/bench.py --batch $BATCH --steps 10 --warmup 2 $QUIET --no-isolated > $O/prof_${TAG}_overlap.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_serial -o p -- python3 $R/bench.py --batch $BATCH --steps 10 --warmup 2 $QUIET --no-overlap --streams 1 > $O/prof_${TAG}_serial.log 2>&1 || exit 1
+cp $(find $O/prof_${TAG}_overlap -name '*kernel_stats.csv' | head -1) $O/${TAG}_kernel_stats_slices2.csv
+cp $(find $O/prof_${TAG}_serial -name '*kernel_stats.csv' | head -1) $O/${TAG}_kernel_stats_serial.csv
+cd $R && python3 bench.py --batch $BATCH > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err && python3 tools/show_bench.py gpurun_out/${TAG}_bench.json

@@ -14,7 +14,7 @@
     {                                                                                                         \
         int r0 = seed + threadIdx.x, r1 = r0 * 3, r2 = r0 * 5, r3 = r0 * 7, r4 = r0 * 11, r5 = r0 * 13, r6 = r0 * 17, r7 = r0 * 19; \
         int ad = ((threadIdx.x - 2) & 63) * 4;                                                                \
-        asm volatile("s_mov_b64 s[10:11], 0x5555" ::: "s10", "s11");                                          \
+        asm volatile("s_mov_b64 s[10:11], 0x5555" ::: "s10", "s11", "s12", "vcc");                                          \
         for (int it = 0; it < ITER; ++it) {                                                                   \
             asm volatile(ASM("%0") ASM("%1") ASM("%2") ASM("%3") ASM("%4") ASM("%5") ASM("%6") ASM("%7")          \
                          ASM("%0") ASM("%1") ASM("%2") ASM("%3") ASM("%4") ASM("%5") ASM("%6") ASM("%7")          \
@@ -65,6 +65,37 @@
 #define A_CMPCND(r) "v_cmp_gt_i32 vcc, " r ", " r "\nv_cndmask_b32 " r ", " r ", " r ", vcc\n"
 #define A_SAD(r) "v_sad_u32 " r ", " r ", " r ", " r "\n"
 
+#define A_NOT(r) "v_not_b32 " r ", " r "\n"
+#define A_XOR(r) "v_xor_b32 " r ", " r ", " r "\n"
+#define A_LSHR(r) "v_lshrrev_b32 " r ", 1, " r "\n"
+#define A_ASHR(r) "v_ashrrev_i32 " r ", 1, " r "\n"
+#define A_SUBF(r) "v_sub_f32 " r ", " r ", " r "\n"
+#define A_FMAC(r) "v_fmac_f32 " r ", " r ", " r "\n"
+#define A_CMPF(r) "v_cmp_gt_f32 vcc, " r ", " r "\n"
+#define A_ADDC(r) "v_addc_co_u32 " r ", vcc, " r ", " r ", vcc\n"
+#define A_MAX_DPP(r) "v_max_i32_dpp " r ", " r ", " r " wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+#define A_SUB_DPP(r) "v_sub_u32_dpp " r ", " r ", " r " wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+#define A_CVTUB(r) "v_cvt_f32_ubyte0 " r ", " r "\n"
+#define A_CVTU(r) "v_cvt_f32_u32 " r ", " r "\n"
+#define A_CVTRN(r) "v_cvt_i32_f32 " r ", " r "\n"
+#define A_DOT2(r) "v_dot2_i32_i16 " r ", " r ", " r ", " r "\n"
+#define A_DOT4(r) "v_dot4_u32_u8 " r ", " r ", " r ", " r "\n"
+#define A_READLANE(r) "v_readlane_b32 s12, " r ", 5\n"
+#define A_MBCNT(r) "v_mbcnt_lo_u32_b32 " r ", " r ", " r "\n"
+#define A_LSHLOR(r) "v_lshl_or_b32 " r ", " r ", 3, " r "\n"
+#define A_ANDOR(r) "v_and_or_b32 " r ", " r ", " r ", " r "\n"
+#define A_MED3(r) "v_med3_i32 " r ", " r ", " r ", " r "\n"
+#define A_MINF(r) "v_min_f32 " r ", " r ", " r "\n"
+#define A_RSQ(r) "v_rsq_f32 " r ", " r "\n"
+#define A_RCP(r) "v_rcp_f32 " r ", " r "\n"
+#define A_MULSGPR(r) "v_mul_f32 " r ", s10, " r "\n"
+#define A_FLOOR(r) "v_floor_f32 " r ", " r "\n"
+#define A_PKFMA16(r) "v_pk_fma_f16 " r ", " r ", " r ", " r "\n"
+#define A_PKMAD16(r) "v_pk_mad_u16 " r ", " r ", " r ", " r "\n"
+#define A_PKSUB16(r) "v_pk_sub_i16 " r ", " r ", " r "\n"
+#define A_ADDF64(r) "v_add_f64 v[20:21], v[20:21], v[22:23]\n"
+#define A_CVTF64(r) "v_cvt_f64_i32 v[20:21], " r "\n"
+
 KERNEL(k_add, A_ADD)
 KERNEL(k_add3, A_ADD3)
 KERNEL(k_max3, A_MAX3)
@@ -102,6 +133,34 @@ KERNEL(k_pkaddu16, A_PKADDU16)
 KERNEL(k_cmpcnd, A_CMPCND)
 KERNEL(k_sad, A_SAD)
 
+KERNEL(k_not, A_NOT)
+KERNEL(k_xor, A_XOR)
+KERNEL(k_lshr, A_LSHR)
+KERNEL(k_ashr, A_ASHR)
+KERNEL(k_subf, A_SUBF)
+KERNEL(k_fmac, A_FMAC)
+KERNEL(k_cmpf, A_CMPF)
+KERNEL(k_addc, A_ADDC)
+KERNEL(k_max_dpp, A_MAX_DPP)
+KERNEL(k_sub_dpp, A_SUB_DPP)
+KERNEL(k_cvtub, A_CVTUB)
+KERNEL(k_cvtu, A_CVTU)
+KERNEL(k_cvtrn, A_CVTRN)
+KERNEL(k_dot2, A_DOT2)
+KERNEL(k_dot4, A_DOT4)
+KERNEL(k_readlane, A_READLANE)
+KERNEL(k_mbcnt, A_MBCNT)
+KERNEL(k_lshlor, A_LSHLOR)
+KERNEL(k_andor, A_ANDOR)
+KERNEL(k_med3, A_MED3)
+KERNEL(k_minf, A_MINF)
+KERNEL(k_rsq, A_RSQ)
+KERNEL(k_rcp, A_RCP)
+KERNEL(k_mulsgpr, A_MULSGPR)
+KERNEL(k_floor, A_FLOOR)
+KERNEL(k_pkmad16, A_PKMAD16)
+KERNEL(k_pksub16, A_PKSUB16)
+
 int main()
 {
     hipDeviceProp_t p;
@@ -119,7 +178,13 @@ int main()
         {"v_lshl_add_u32", k_lshladd}, {"v_pk_mul_lo_u16", k_pkmul}, {"v_bfe_u32", k_bfe}, {"v_cndmask_b32 (sgpr mask)", k_cndmask_s},
         {"v_sub_u32", k_sub}, {"v_lshlrev_b32", k_lshl}, {"v_max_i32", k_maxi}, {"v_and_b32", k_and}, {"v_add_f32", k_addf}, {"v_max_f32", k_maxf},
         {"v_mov_b32", k_mov}, {"v_mad_u32_u24", k_madu24}, {"v_mul_u32_u24", k_mulu24}, {"v_pk_add_u16", k_pkaddu16},
-        {"v_cmp + v_cndmask (x2 instr)", k_cmpcnd}, {"v_sad_u32", k_sad}};
+        {"v_cmp + v_cndmask (x2 instr)", k_cmpcnd}, {"v_sad_u32", k_sad},
+        {"v_not_b32", k_not}, {"v_xor_b32", k_xor}, {"v_lshrrev_b32", k_lshr}, {"v_ashrrev_i32", k_ashr}, {"v_sub_f32", k_subf}, {"v_fmac_f32", k_fmac},
+        {"v_cmp_gt_f32", k_cmpf}, {"v_addc_co_u32", k_addc}, {"v_max_i32_dpp wave_shr", k_max_dpp}, {"v_sub_u32_dpp wave_shr", k_sub_dpp},
+        {"v_cvt_f32_ubyte0", k_cvtub}, {"v_cvt_f32_u32", k_cvtu}, {"v_cvt_i32_f32", k_cvtrn}, {"v_dot2_i32_i16", k_dot2}, {"v_dot4_u32_u8", k_dot4},
+        {"v_readlane_b32", k_readlane}, {"v_mbcnt_lo_u32_b32", k_mbcnt}, {"v_lshl_or_b32", k_lshlor}, {"v_and_or_b32", k_andor}, {"v_med3_i32", k_med3},
+        {"v_min_f32", k_minf}, {"v_rsq_f32", k_rsq}, {"v_rcp_f32", k_rcp}, {"v_mul_f32 (sgpr src)", k_mulsgpr}, {"v_floor_f32", k_floor},
+        {"v_pk_mad_u16", k_pkmad16}, {"v_pk_sub_i16", k_pksub16}};
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     double base = 0;
