@@ -10,12 +10,13 @@ A "step" is one pass of the whole hot path (BGR pair -> gray -> pyramids -> corn
 of B synthetic 1080p frame pairs per GPU that are already resident in HBM.  Frame pairs are independent, so ranks
 shard them with no data-path collective ("weak" scaling: B pairs per GPU); the only exchange is an RCCL all_gather
 of the [B,8] f32 velocity records after every step.  Timing: W warm-up steps, then exactly K steps between
-barrier + device synchronize on both sides, MAX over ranks.  Under torchrun the barrier/synchronize/all_gather are
-torch.distributed (nccl = RCCL) and torch.cuda.synchronize(); a plain single-process run (N=1) has nothing to
-exchange and uses hipDeviceSynchronize through the library, so torch is not imported at all.
+barrier + device synchronize on both sides, MAX over ranks.  torch.distributed.run is only the process LAUNCHER here
+(it exports RANK / LOCAL_RANK / WORLD_SIZE): this file never imports torch.  Barrier, MAX and the all_gather are RCCL
+collectives issued by libofk.so itself (ofk_comm_*: librccl.so bound with dlopen, unique id handed over through a
+node-local file, of_amd/sharding.py), hipDeviceSynchronize through the library stands in for torch.cuda.synchronize().
 
-Under torchrun the gather is pipelined one step behind the compute (ofk_mark / ofk_mark_wait): step k's records
-travel while step k+1 runs; K steps issue K gathers inside the timed region.
+The gather of step k is queued on the library's own stream right behind step k's solve (stream-ordered, no host wait), so
+step k+1 is launched while it travels; K steps issue K gathers inside the timed region.
 
 Schedule (default): the batch runs as two free-running slices (--streams 2): each slice has its own stage chain
 and auxiliary stream, the slices are offset by one response kernel and are not joined between steps.
@@ -213,24 +214,15 @@ def main():
     ap.add_argument("--no-ingest", action="store_true", help="skip the ingest-inclusive legs (raw BGR upload / JPEG decode every step)")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = torch = None
-    if "WORLD_SIZE" in os.environ and "RANK" in os.environ:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    if world != args.gpus and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; reporting n_gpus={world}", file=sys.stderr)
-
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # RCCL's device-memory IPC needs the dmabuf path on this pool
     load_package()
     import of_amd.ofk as ofk
     from of_amd import synth, sharding
     from of_amd.pipeline import FlowPipeline, PipelineConfig
+    rank, world, local = sharding.env_ranks()                   # RANK / WORLD_SIZE / LOCAL_RANK from the launcher; (0, 1, 0) when run plainly
+    launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; reporting n_gpus={world}", file=sys.stderr)
 
     cfg = PipelineConfig.baseline_1080p()
     B = args.batch
@@ -243,39 +235,21 @@ def main():
         pipe.ctx.set_overlap(False)
     pipe.upload(prev, nxt, sensors)
 
-    gathered = rec_t = None
-    if dist is not None:
-        rec_t = [torch.zeros((B, 8), dtype=torch.float32, device=f"cuda:{local}") for _ in range(2)]
-        gathered = torch.zeros((world * B, 8), dtype=torch.float32, device=f"cuda:{local}")
+    # The exchange: RCCL through the library (no torch in the process).  Step k's records are exported and all-gathered on the
+    # library's own stream right behind step k's solve (receive slot k % 2), so the host only queues work: step k+1 is
+    # launched while step k's gather travels.  K steps issue K gathers inside the timed region.
+    comm = sharding.Comm(pipe.ctx, rank, world, n_comms=max(1, args.streams)) if launched else None
 
     def sync_all():
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
+        if comm is not None:
+            comm.barrier()
         pipe.ctx._ck(pipe.ctx._L.ofk_device_sync())
-
-    # The exchange is software-pipelined by one step: step k is queued on the library's stream (its records exported into
-    # buffer k%2, a completion mark behind them), then the host waits for the mark of step k-1 and all_gathers THAT
-    # buffer over RCCL while the GPU is already working on step k.  K steps issue K gathers; the last one drains below.
-    pending = []
-
-    def gather_pending():
-        if pending:
-            k = pending.pop(0)
-            pipe.ctx.mark_wait(k % 2)                    # records of step k are complete in rec_t[k % 2]
-            sharding.gather_records(dist, rec_t[k % 2], out=gathered)
-            torch.cuda.current_stream().synchronize()    # the buffer is free again before step k+2 exports into it
 
     def run_steps(n, k0):
         for k in range(k0, k0 + n):
             pipe.run_async()
-            if dist is not None:
-                pipe.ctx.pairs_export_records_f32(rec_t[k % 2].data_ptr(), B)
-                pipe.ctx.mark(k % 2)
-                gather_pending()
-                pending.append(k)
-        if dist is not None:
-            gather_pending()
+            if comm is not None:
+                comm.gather_async(B, k % 2)
 
     run_steps(args.warmup, 0)
     sync_all()
@@ -304,11 +278,17 @@ def main():
         pipe.ctx.set_overlap(not args.no_overlap)
         pipe.ctx.set_streams(args.streams)
 
-    if dist is not None:
-        dt = sharding.max_over_ranks(dist, dt, device=f"cuda:{local}")
+    if comm is not None:
+        dt = comm.max(dt)
+        last = (args.warmup + args.steps - 1) % 2
+        gathered = comm.fetch(B, last)                             # [world, B, 8] f32 of the last timed step, every rank's records
 
     out = pipe.ctx.pairs_download(points=False)
     rec = out["records"]
+    if comm is not None:                                         # the gather carried this rank's own records, bit for bit (f32)
+        mine = np.stack([rec[:, 0], rec[:, 1], rec[:, 2], rec[:, 3], rec[:, 11], rec[:, 7], rec[:, 4], rec[:, 12]], 1).astype(np.float32)
+        if not np.array_equal(gathered[rank], mine) or not np.all(np.isfinite(gathered)):
+            raise SystemExit(f"rank {rank}: gathered records differ from the local ones")
     if rank == 0:
         n_pts = float(np.mean(out["counts"]))
         n_cand = float(np.mean(rec[:, 14]))
@@ -357,7 +337,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "1920x1080 frame pairs, 500 Shi-Tomasi corners, 3-level LK pyramid (BASELINE configs[1])",
                        "pairs_per_gpu_per_step": B, "streams_per_gpu": args.streams, "corners_mean": round(n_pts, 1), "candidates_mean": round(n_cand, 1), "win": cfg.win, "max_level": cfg.max_level,
-                       "sharding": f"{world} x independent pair batches, all_gather of [B,8] f32 records"},
+                       "sharding": f"{world} x independent pair batches, RCCL all_gather of [B,8] f32 records on the library's stream" + ("" if launched else " (single process: nothing to exchange)")},
             "roofline": roof,
             # "Pyramid+LK group (north-star kernel)" = G_pyr + G_lk (Scharr fused into LK), serial-pass durations
             "north_star_group": {"kernels": f"{KERNEL_OF['pyr']} + {KERNEL_OF['lk']}", "bound": "hbm",
@@ -400,10 +380,10 @@ def main():
         if world == 1 and not args.no_ingest:
             line["ingest_inclusive"] = ingest_inclusive(pipe, prev, nxt, sensors, B)
         print(json.dumps(line), flush=True)
+    if comm is not None:
+        comm.barrier()
+        comm.close()
     pipe.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -588,11 +588,16 @@ __device__ __forceinline__ void box_pair(int ae, int ao, int ad2, int ad3, int &
     }
 }
 
-__device__ __forceinline__ int lambda_min_bits(int vxx, int vxy, int vyy, float kd, float ko)
+// lambda_min = (a + c) - sqrt((a - c)^2 + b^2) with a = f32(Sxx) kd, c = f32(Syy) kd, b = f32(Sxy) ko and ko = 2 kd exactly
+// (both are one f64 value scaled by a power of two, then rounded).  Scaling by a power of two commutes with rounding, so
+// b = 2 y with y = f32(Sxy) kd, b*b = 4 (y*y) and fl(amc*amc + b*b) = fma(4, y*y, amc*amc) bit for bit — one constant
+// (kept in a VGPR: an SGPR operand halves the issue rate of v_mul_f32, tools/valu_rates.hip) instead of two.
+__device__ __forceinline__ int lambda_min_bits(int vxx, int vxy, int vyy, float kd)
 {
-    const float a = (float)vxx * kd, bb = (float)vxy * ko, c = (float)vyy * kd;
+    const float a = (float)vxx * kd, y = (float)vxy * kd, c = (float)vyy * kd;
     const float amc = a - c;
-    return __float_as_int((a + c) - sqrt_rn_normal(amc * amc + bb * bb));
+    const float y2 = y * y, amc2 = amc * amc;
+    return __float_as_int((a + c) - sqrt_rn_normal(__builtin_fmaf(4.f, y2, amc2)));
 }
 
 // (Measured and dropped: the same formula on float PAIRS — v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 — executes 11 fewer
@@ -606,7 +611,8 @@ __device__ __forceinline__ int lambda_min_bits(int vxx, int vxy, int vyy, float 
         if (!(IN)) {                                                                                                   \
             if (edge_strip) { ge2 = __builtin_amdgcn_ds_bpermute(mir_e, ge2); go2 = __builtin_amdgcn_ds_bpermute(mir_o, go2); } \
         }                                                                                                              \
-        const int se = g0e + 2 * g1e + ge2, so = g0o + 2 * g1o + go2, te = ge2 - g0e, to = go2 - g0o;                  \
+        const int r12e = g1e + ge2, r12o = g1o + go2;              /* Sobel column sums from row-pair sums: s = (g0+g1) + (g1+g2), */ \
+        const int se = r01e + r12e, so = r01o + r12o, te = r12e - r01e, to = r12o - r01o;   /* t = g2 - g0 = (g1+g2) - (g0+g1): three full-rate adds */ \
         const int nso = -so, nse = -se, tt = te + to;                                                                  \
         const int dxe = DPP_SHR1(nso) + so;                                                                            \
         const int dxo = DPP_SHL1(se) + nse;                                                                            \
@@ -629,7 +635,7 @@ __device__ __forceinline__ int lambda_min_bits(int vxx, int vxy, int vyy, float 
         vxxo += hxxo - rxxo[i]; vxyo += hxyo - rxyo[i]; vyyo += hyyo - ryyo[i];                                        \
         rxxe[i] = hxxe; rxye[i] = hxye; ryye[i] = hyye; rxxo[i] = hxxo; rxyo[i] = hxyo; ryyo[i] = hyyo;                \
         const int yo = ya - 2 + r - BS;                                                                                \
-        const int e2e = lambda_min_bits(vxxe, vxye, vyye, kd, ko), e2o = lambda_min_bits(vxxo, vxyo, vyyo, kd, ko);    \
+        const int e2e = lambda_min_bits(vxxe, vxye, vyye, kdv), e2o = lambda_min_bits(vxxo, vxyo, vyyo, kdv);    \
         if ((IN) && !MASK) {                                                                                           \
             lmaxi = max(max(lmaxi, e2e), e2o);                                                                         \
         } else {                                                                                                       \
@@ -662,7 +668,7 @@ __device__ __forceinline__ int lambda_min_bits(int vxx, int vxy, int vyy, float 
             ((unsigned long long)(~(unsigned)e1o) << 32) | (unsigned)~(unsigned)(yn * w + xo_o);                                 \
         cnt += ne + (int)__popcll(balo);                                                                               \
         e1e = e2e; e1o = e2o; hm0e = hm1e; hm0o = hm1o; hm1e = hm2e; hm1o = hm2o;                                      \
-        g0e = g1e; g0o = g1o; g1e = ge2; g1o = go2;                                                                    \
+        r01e = r12e; r01o = r12o; g1e = ge2; g1o = go2;                                                                  \
     }
 
 template <int BS> struct pair_geom {
@@ -746,7 +752,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
         OUT[q_] = (int)*reinterpret_cast<const unsigned *>(img + (size_t)(lrow ? b_ : a_) * w + ldoff);                \
     }
 
-    int g0e = 0, g0o = 0, g1e = 0, g1o = 0;
+    float kdv = kd;
+    asm volatile("" : "+v"(kdv));                               // keep the scale factor in a VGPR (see lambda_min_bits)
+    int r01e = 0, r01o = 0, g1e = 0, g1o = 0;                   // previous gray row and the sum of the two before it (per slot)
     int rxxe[BS], rxye[BS], ryye[BS], rxxo[BS], rxyo[BS], ryyo[BS];
 #pragma unroll
     for (int i = 0; i < BS; ++i) { rxxe[i] = rxye[i] = ryye[i] = rxxo[i] = rxyo[i] = ryyo[i] = 0; }
@@ -827,10 +835,11 @@ void ofk_stream_geometry(int h, int w, int block, int batch, int *rows, int *nse
     int SW = 61 - block, d = 0;
     if (pair_ok(w, block)) pair_sw(block, &SW, &d);
     const int strips = (w + d + SW - 1) / SW;
-    // fewer, longer strips when the batch already fills the chip: every strip pays BS + 3 warm-up rows, and under the
-    // overlapped schedule long-lived waves hold their SIMDs better against the auxiliary stream's kernels
-    // (1080p, B = 256: 128 rows 82.1 k pairs/s, 270 rows 84.8 k, 540 rows 85.4 k)
-    int r = batch >= 64 ? (h + (h + 539) / 540 - 1) / ((h + 539) / 540) : (batch >= 16 ? 128 : 32);
+    // strip length when the batch fills the chip: every strip pays BS + 3 warm-up rows (270 rows: 3.7 %), but a launch makes
+    // only a few rounds over the chip's 3072 wave slots (1080p, B = 256: 17 strips x chunks x 256 waves = 2.83 rounds at 540 rows,
+    // 5.67 at 270), and the last round's tail costs more than the warm-up: isolated 1.126 ms at 540 rows, 1.071 at 270 or 360,
+    // 1.08 at 135-216 (profiles/r02_eig_rows_sweep.txt)
+    int r = batch >= 64 ? (h + (h + 269) / 270 - 1) / ((h + 269) / 270) : (batch >= 16 ? 128 : 32);
     if (const char *e = getenv("OFK_EIG_ROWS")) { const int v = atoi(e); if (v >= 8 && v <= 4096) r = v; }   // tuning knob
     while (strips * ((h + r - 1) / r) > 2048) r *= 2;           // k_select walks at most 2048 segments per image
     *rows = r; *nseg = strips * ((h + r - 1) / r);
@@ -874,6 +883,7 @@ static int launch_mineig_pair(hipStream_t s, const uint8_t *gray, size_t gray_st
     const int strips = (w + D + SW - 1) / SW;
     const double scale = 1.0 / (4.0 * BS * 255.0);
     const float kd = (float)(0.5 * scale * scale), ko = (float)(scale * scale);
+    if (ko != 2.f * kd) return -1;                              // lambda_min_bits relies on it (always true: power-of-two scaling)
     dim3 grid(strips, (h + rows - 1) / rows, batch);
     if (mask)
         hipLaunchKernelGGL((k_mineig_pair<BS, true>), grid, dim3(64), 0, s, gray, gray_stride, h, w, rows, kd, ko, maxbits, mask,

@@ -612,7 +612,7 @@ __global__ __launch_bounds__(256) void k_feas_simulation(const double *__restric
     __shared__ double s_red[4];
     __shared__ double s_v[4];
     const int trial = blockIdx.x, tid = threadIdx.x;
-    const double *zi = z + (size_t)trial * (14 + 4 * (size_t)n);
+    const double *zi = z + (size_t)trial * (12 + 4 * (size_t)n);
     const double ang[3] = {truth[3] + sig[0] * zi[0], truth[4] + sig[0] * zi[1], truth[5] + sig[0] * zi[2]};
     const double trn[3] = {truth[10] + sig[1] * zi[3], truth[11] + sig[1] * zi[4], truth[12] + sig[1] * zi[5]};
     const double h_err = truth[6] + sig[2] * zi[6];

@@ -144,6 +144,7 @@ extern "C" int ofk_destroy(ofk_ctx *c)
     if (!c) return OFK_OK;
     hipSetDevice(c->device);
     if (c->stream) hipDeviceSynchronize();
+    ofk_comm_destroy(c);
     for (int k = 0; k < 2; ++k) { if (c->bgr[k]) hipFree(c->bgr[k]); if (c->pyr[k]) hipFree(c->pyr[k]); }
     void *ptrs[] = {c->eig, c->mask, c->deriv, c->cand, c->cand_seg, c->seg_count, c->cand_count, c->maxbits, c->pts_prev, c->pts_next, c->status, c->err,
                     c->counts, c->sensors, c->records, c->dev_flags, c->scratch, c->pts_new, c->new_counts, c->limit};
@@ -210,6 +211,7 @@ static int join_slices(ofk_ctx *c)
 }
 
 int ofk_join_slices(ofk_ctx *c) { return join_slices(c); }
+int ofk_prepare_streams(ofk_ctx *c) { return need_streams(c, c->nstreams < 1 ? 1 : c->nstreams, c->overlap != 0); }
 
 extern "C" int ofk_sync(ofk_ctx *c)
 {
@@ -713,7 +715,7 @@ extern "C" int ofk_feas_simulation(ofk_ctx *c, const double *truth, const double
 {
     if (!c || !truth || !sig || !pos || !true_flow || !z || !mean || n < 1 || trials < 1)
         return ofk_fail(c, OFK_E_INVALID, "ofk_feas_simulation: bad argument");
-    const size_t zb = (size_t)trials * (14 + 4 * (size_t)n) * 8, pb = (size_t)trials * 6 * n * 8;
+    const size_t zb = (size_t)trials * (12 + 4 * (size_t)n) * 8, pb = (size_t)trials * 6 * n * 8;
     Bump bp;
     TRY(est_begin(c, zb + pb + (size_t)n * 32 + (size_t)n * 48 + (size_t)trials * 24 + 8 * 256, bp));
     double *dt = bp.put(truth, OFK_FEAS_SIM_TRUTH * 8), *ds = bp.put(sig, OFK_FEAS_SIM_SIG * 8), *dp = bp.put(pos, (size_t)n * 16),
@@ -946,17 +948,25 @@ extern "C" int ofk_pairs_download(ofk_ctx *c, double *records, float *prev_pts, 
     return OFK_OK;
 }
 
-extern "C" int ofk_pairs_export_records_f32(ofk_ctx *c, void *device_dst, int batch)
+// k_records_f32 of the latest ofk_pairs_run on the stream that ends the step (the last slice's, behind the other slices' end
+// events); *stream_out lets a caller queue more work behind it (the RCCL gather of ofk_comm.hip)
+int ofk_export_records_stream(ofk_ctx *c, float *device_dst, int batch, hipStream_t *stream_out)
 {
-    if (!c || !device_dst || batch < 1 || batch > c->cur_batch) return ofk_fail(c, OFK_E_INVALID, "ofk_pairs_export_records_f32: bad argument");
     hipStream_t s;
     TRY(tail_stream(c, &s));
-    ofk_launch_records_f32(s, c->records, (float *)device_dst, batch);
+    ofk_launch_records_f32(s, c->records, device_dst, batch);
     if (c->slices_open) {                                        // the other slices' next solve must not overtake the export
         OFK_HIP(c, hipEventRecord(c->ev_x, s));
         c->x_pending = 1;
     }
+    if (stream_out) *stream_out = s;
     return check_launch(c, "k_records_f32");
+}
+
+extern "C" int ofk_pairs_export_records_f32(ofk_ctx *c, void *device_dst, int batch)
+{
+    if (!c || !device_dst || batch < 1 || batch > c->cur_batch) return ofk_fail(c, OFK_E_INVALID, "ofk_pairs_export_records_f32: bad argument");
+    return ofk_export_records_stream(c, (float *)device_dst, batch, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------ video streams
@@ -1125,7 +1135,10 @@ extern "C" int ofk_set_streams(ofk_ctx *c, int nstreams)
     // rewrite.  Changing the schedule is rare (set-up time), so drain everything.
     TRY(drain_all(c));
     c->nstreams = nstreams;
-    return OFK_OK;
+    // Create the slice and auxiliary streams NOW: the runtime deals streams onto its hardware queues in creation order, and a
+    // library that creates streams of its own later (RCCL does at ncclCommInitRank) must not get in between - with the
+    // pipeline's streams created lazily behind RCCL's, two of them shared a queue and the rate fell by 10 % (99 k -> 87 k).
+    return need_streams(c, nstreams, c->overlap != 0);
 }
 
 extern "C" int ofk_set_overlap(ofk_ctx *c, int on)

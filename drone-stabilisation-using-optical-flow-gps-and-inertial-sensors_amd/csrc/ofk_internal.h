@@ -19,8 +19,10 @@ struct ofk_levels {
     size_t off[OFK_MAX_LEVELS];     // byte offset of level l inside one image's pyramid slab (256-B aligned)
 };
 
+struct ofk_comm;
 struct ofk_ctx {
     int device;
+    ofk_comm *comm;                                       // RCCL communicator + gather buffers (ofk_comm.hip), NULL until ofk_comm_init
     hipStream_t stream;                           // the context's stream (slice 0); entry points synchronise on it
     hipStream_t streams[OFK_MAX_STREAMS]; int nstreams;   // extra slice streams (created on first use), joined back into `stream` by events
     hipEvent_t ev_fork;
@@ -82,7 +84,10 @@ int ofk_fail(ofk_ctx *ctx, int code, const char *fmt, ...);
     } while (0)
 ofk_levels ofk_make_levels(int h, int w, int win, int max_level);   // win <= 0: ignore the winSize stop rule
 int ofk_need_scratch(ofk_ctx *ctx, size_t bytes);
-int ofk_join_slices(ofk_ctx *ctx);                                    // before touching the context's stream / shared buffers
+int ofk_join_slices(ofk_ctx *ctx);
+int ofk_prepare_streams(ofk_ctx *ctx);                                 // create the slice / auxiliary streams of the current schedule
+int ofk_export_records_stream(ofk_ctx *c, float *device_dst, int batch, hipStream_t *stream_out);   // k_records_f32 on the stream that ends the step
+                                   // before touching the context's stream / shared buffers
 int ofk_jpeg_decode_device(ofk_ctx *c, const uint8_t *const *jpeg, const size_t *nbytes, int batch, uint8_t *dst, size_t dst_stride,
                            size_t dst_capacity_px, int *h_out, int *w_out, uint8_t **out, size_t *out_stride);   // k_jpeg.hip
 

@@ -30,6 +30,8 @@ SYMBOLS = (
     "ofk_pairs_run", "ofk_pairs_download", "ofk_pairs_export_records_f32", "ofk_stream_begin", "ofk_stream_step",
     "ofk_stream_begin_jpeg", "ofk_stream_step_jpeg",
     "ofk_set_streams", "ofk_set_overlap", "ofk_mark", "ofk_mark_wait", "ofk_profile_enable", "ofk_profile_read",
+    "ofk_comm_unique_id", "ofk_comm_init", "ofk_comm_destroy", "ofk_comm_rank", "ofk_comm_world", "ofk_comm_gather_records",
+    "ofk_comm_fetch_records", "ofk_comm_allreduce_f64",
 )
 
 
@@ -117,6 +119,10 @@ def load_library():
         L.ofk_mark.argtypes = [vp, i]; L.ofk_mark_wait.argtypes = [vp, i]
         L.ofk_profile_enable.argtypes = [vp, i]
         L.ofk_profile_read.argtypes = [vp, vp, vp]
+        L.ofk_comm_unique_id.argtypes = [vp, i]; L.ofk_comm_init.argtypes = [vp, vp, i, i, i]; L.ofk_comm_destroy.argtypes = [vp]
+        L.ofk_comm_rank.argtypes = [vp]; L.ofk_comm_world.argtypes = [vp]
+        L.ofk_comm_gather_records.argtypes = [vp, i, i]; L.ofk_comm_fetch_records.argtypes = [vp, i, i, vp]
+        L.ofk_comm_allreduce_f64.argtypes = [vp, vp, i, i]
         for s in SYMBOLS:
             if s != "ofk_last_error":
                 getattr(L, s).restype = i
@@ -471,7 +477,7 @@ class Context:
         n = len(pos)
         if pos.shape != (n, 2) or true_flow.shape != (n, 2):
             raise ValueError("feas_simulation: pos and true_flow must be [n, 2]")
-        z = _arr(z, np.float64).reshape(-1, 14 + 4 * n)
+        z = _arr(z, np.float64).reshape(-1, 12 + 4 * n)
         trials = len(z)
         mean = np.empty((6, n), np.float64); v = np.empty((trials, 3), np.float64)
         per = np.empty((trials, 6, n), np.float64) if per_trial else None
@@ -605,6 +611,36 @@ class Context:
                                                   _p(rec), _p(tracks), _p(counts)))
         return rec, tracks, counts
 
+    # ------------------------------------------------------------------ multi-GPU exchange (RCCL through the library, no torch)
+    def comm_init(self, unique_id, rank, world):
+        uid = np.frombuffer(bytes(unique_id), np.uint8).copy()
+        if uid.size == 0 or uid.size % 128:
+            raise ValueError("RCCL unique ids have 128 bytes each")
+        with self._lock:
+            self._ck(self._L.ofk_comm_init(self._h, _p(uid), uid.size // 128, int(rank), int(world)))
+        self.comm_rank, self.comm_world = int(rank), int(world)
+
+    def comm_destroy(self):
+        with self._lock:
+            self._ck(self._L.ofk_comm_destroy(self._h))
+
+    def comm_gather_records(self, batch, slot=0):
+        """Queues the all-gather of the latest step's [batch, 8] f32 records behind that step; returns at once."""
+        with self._lock:
+            self._ck(self._L.ofk_comm_gather_records(self._h, int(batch), int(slot)))
+
+    def comm_fetch_records(self, batch, slot=0):
+        out = np.empty((self.comm_world, int(batch), 8), np.float32)
+        with self._lock:
+            self._ck(self._L.ofk_comm_fetch_records(self._h, int(slot), int(batch), _p(out)))
+        return out
+
+    def comm_allreduce(self, values, op="sum"):
+        v = np.ascontiguousarray(np.atleast_1d(values), np.float64).copy()
+        with self._lock:
+            self._ck(self._L.ofk_comm_allreduce_f64(self._h, _p(v), v.size, {"sum": 0, "max": 1, "min": 2}[op]))
+        return v
+
     def set_overlap(self, on):
         self._ck(self._L.ofk_set_overlap(self._h, 1 if on else 0))
 
@@ -627,6 +663,15 @@ class Context:
         with self._lock:
             self._ck(self._L.ofk_profile_read(self._h, _p(ms), _p(n)))
         return {s: (float(ms[i]), int(n[i])) for i, s in enumerate(STAGES)}
+
+
+def comm_unique_id(n_ids=1):
+    """n_ids x 128-byte RCCL unique ids (call on rank 0, hand to every rank): one communicator per free-running slice."""
+    uid = np.zeros(128 * int(n_ids), np.uint8)
+    rc = load_library().ofk_comm_unique_id(_p(uid), int(n_ids))
+    if rc != OK:
+        raise OfkError(rc, load_library().ofk_last_error(None).decode())
+    return uid.tobytes()
 
 
 def make_sensors(batch, d=1.0, normal=(0, 0, 1), omega=(0, 0, 0), rotation=None, offset=(0, 0, 0.1), scaling=0.01,

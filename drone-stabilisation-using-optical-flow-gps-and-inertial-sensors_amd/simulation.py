@@ -1,8 +1,8 @@
 """simulation.py — drop-in for the functions of numerical_simulation/simulation.py, batched on the GPU.
 
 Same names and positional signatures: generate_test_data (:7-12), solve_lgs (:15-30), feasibility (:108-120),
-of_simulation (:36-66).  The reference's module-level globals `iterations` and `true_flow` (read by
-of_simulation) are module attributes here as well.  Noise: the reference draws from an unseeded np.random; here
+of_simulation (:36-66), feas_simulation (:70-104), overlap (:124-136).  The reference's module-level globals `iterations`,
+`true_flow`, `normal_sig` and `velocity_sig` (read by of_simulation / feas_simulation) are module attributes here as well.  Noise: the reference draws from an unseeded np.random; here
 the standard-normal tensor is drawn on the host in the reference's draw order (optionally seeded, or passed in)
 and all `iterations` trials are solved by one launch of k_of_simulation.
 """
@@ -15,6 +15,8 @@ except ImportError:
 
 iterations = 100
 true_flow = None
+normal_sig = 0.00065      # simulation.py:171 (feas_simulation reads it as a global; its parameter is misspelt `normal_sigi`, :70)
+velocity_sig = 0.01       # simulation.py:172
 rng = None            # set to np.random.default_rng(seed) for reproducible sweeps
 
 
@@ -72,17 +74,66 @@ def of_simulation(linear_velocity, angular_velocity, height_above_gr, normal_vec
     return v_obs, feas, bound
 
 
+def draw_feas_noise(n_points, trials, generator=None):
+    """Standard normals for feas_simulation in the reference's draw order: 3 + 3 + 1 + 2N + 2N + 3 + 1 + 1 per trial."""
+    g = generator or rng or np.random.default_rng()
+    return g.standard_normal((trials, 12 + 4 * n_points))
+
+
+def feas_simulation(linear_velocity, angular_velocity, height_above_gr, normal_vector, translation, pos, ang_vel_sig, translation_sig,
+                    height_sig, flow_sig, position_sig, normal_sigi, true_vel, z=None):
+    """simulation.py:70-104: per trial perturbed inputs -> solve -> backward / forward feasibility -> per-point residual norms;
+    returns the six per-point means (backward_para, backward_dist, forward_para, forward_dist, backward_res, forward_res).
+    All `iterations` trials run in one launch of k_feas_simulation.  Like the reference, the function reads `true_flow`,
+    `iterations`, `normal_sig` and `velocity_sig` from the module (its `normal_sigi` parameter is unused there too) and does not
+    use `linear_velocity`; unlike the reference it takes any number of points (the reference hard-codes 200, :83-84)."""
+    pos = np.asarray(pos, np.float64)
+    tf = np.asarray(true_flow, np.float64)
+    if z is None:
+        z = draw_feas_noise(len(pos), iterations)
+    z = np.asarray(z, np.float64).reshape(-1, 12 + 4 * len(pos))
+    truth = np.concatenate([np.asarray(linear_velocity, np.float64), np.asarray(angular_velocity, np.float64), [float(np.ravel(height_above_gr)[0])],
+                            np.asarray(normal_vector, np.float64), np.asarray(translation, np.float64), np.asarray(true_vel, np.float64)])
+    sig = np.array([ang_vel_sig, translation_sig, height_sig, flow_sig, position_sig, normal_sig, velocity_sig], np.float64)
+    mean, _ = ofk.default_context().feas_simulation(truth, sig, pos, tf, z)
+    return tuple(mean[k].copy() for k in range(6))
+
+
+def overlap(data1, data2):
+    """simulation.py:124-136: 100 common bins over both samples, sum of the bin-wise minimum counts."""
+    return ofk.default_context().hist_overlap(data1, data2, 100)
+
+
 def sweep_flow_errors(data, linear_velocity, angular_velocity, height_above_gr, normal_vector, translation, sigmas,
-                      k=100, trials=100, generator=None):
+                      k=100, trials=100, generator=None, comm=None):
     """The "Effect of flow errors" driver (simulation.py:183-202): k sigma-steps, flow_sig = 0.001 i,
-    position_sig = sqrt(2)/1000 i; returns np.append(v_mean, v_std) laid out like the saved .npy files."""
+    position_sig = sqrt(2)/1000 i; returns np.append(v_mean, v_std) laid out like the saved .npy files.
+
+    With `comm` (sharding.Comm) the trials of every step are sharded over the ranks: rank r solves the contiguous slice
+    shard_range(trials, r, world) of the step's trials on its own GPU and the per-step statistics come from one all-reduce of
+    (sum v, sum v^2, count) = 7 doubles - trials never travel.  Every rank draws the step's full noise
+    tensor from the same generator and keeps its slice, so the result does not depend on the number of ranks."""
     global true_flow, iterations
+    try:
+        from . import sharding
+    except ImportError:
+        import sharding
     true_flow = generate_test_data(data, linear_velocity, angular_velocity, height_above_gr, normal_vector, translation)
-    iterations = trials
+    rank, world = (comm.rank, comm.world) if comm is not None else (0, 1)
+    lo, hi = sharding.shard_range(trials, rank, world)
     v_mean = np.zeros((k, 3)); v_std = np.zeros((k, 3))
     for i in range(k):
-        v_obs, _, _ = of_simulation(linear_velocity, angular_velocity, height_above_gr, normal_vector, translation, data,
-                                    sigmas["ang_vel_sig"], sigmas["translation_sig"], sigmas["height_sig"], 0.001 * i,
-                                    np.sqrt(2) / 1000 * i, sigmas["normal_sig"], z=draw_noise(len(data), trials, generator))
-        v_mean[i] = v_obs.mean(axis=0); v_std[i] = v_obs.std(axis=0)
+        z = draw_noise(len(data), trials, generator)[lo:hi]
+        if hi > lo:
+            iterations = hi - lo
+            v_obs, _, _ = of_simulation(linear_velocity, angular_velocity, height_above_gr, normal_vector, translation, data,
+                                        sigmas["ang_vel_sig"], sigmas["translation_sig"], sigmas["height_sig"], 0.001 * i,
+                                        np.sqrt(2) / 1000 * i, sigmas["normal_sig"], z=z)
+        else:
+            v_obs = np.zeros((0, 3))
+        if comm is None:
+            v_mean[i] = v_obs.mean(axis=0); v_std[i] = v_obs.std(axis=0)
+        else:
+            v_mean[i], v_std[i], _ = sharding.combine_moments(v_obs.sum(0), (v_obs * v_obs).sum(0), len(v_obs), comm.allreduce)
+    iterations = trials
     return np.append(v_mean, v_std)

@@ -178,7 +178,7 @@ int ofk_of_simulation(ofk_ctx *ctx, const double *truth, const double *sig, cons
 
 /* feas_simulation(...) - simulation.py:70-104 (driven by the live experiment simulation.py:753-812: three ground planes, the
  * second one with randomly rotated flow), with the np.random.normal draws supplied by the caller:
- * z [trials][14+4n] standard normals in the reference's draw order (omega 3, t 3, height 1, flow 2n, position 2n,
+ * z [trials][12+4n] standard normals in the reference's draw order (omega 3, t 3, height 1, flow 2n, position 2n,
  * velocity 3, orient 1, orient2 1).  truth = v[3] (unused by the reference's function body), omega[3], height, normal[3],
  * t[3], true_vel[3] (16); sig = ang_vel, translation, height, flow, position, normal, velocity (7; the reference reads the
  * last two from module globals).  pos, true_flow [n][2].  Per trial: perturbed inputs -> solve_lgs -> feasibility with the
@@ -274,6 +274,29 @@ int ofk_stream_step_jpeg(ofk_ctx *ctx, const uint8_t *const *jpeg, const size_t 
  * decoders); truncated or corrupt entropy data is an error, not a partially grey picture. */
 int ofk_jpeg_info(const uint8_t *jpeg, size_t nbytes, int *h, int *w, int *components);
 int ofk_jpeg_decode_bgr8(ofk_ctx *ctx, const uint8_t *const *jpeg, const size_t *nbytes, int batch, uint8_t *bgr);
+
+/* ------------------------------------------------- multi-GPU exchange: RCCL over xGMI, no PyTorch
+ * The reference has no distributed code; frame pairs (and Monte-Carlo trials) are independent, so each rank (one process per
+ * GPU) owns its own pairs and the only exchange is an all-gather of the per-pair velocity records.  librccl.so is bound at run
+ * time (dlopen) by the first ofk_comm_* call; a single-GPU program never needs it.
+ *   ofk_comm_unique_id     rank 0: n_ids x ncclGetUniqueId -> n_ids x 128 bytes the caller hands to every rank (file, socket ...)
+ *   ofk_comm_init          n_ids x ncclCommInitRank on the context's device (one communicator per free-running slice of
+ *                          ofk_set_streams, so that every slice gathers its own records on its own stream; one is enough for
+ *                          correctness); allocates the gather buffers
+ *   ofk_comm_gather_records  k_records_f32 of the latest ofk_pairs_run + ncclAllGather of [batch][8] f32 {vx,vy,vz,residual,
+ *                          n_used,s_min,rank,corners} into the context's receive buffer `slot` (0/1), queued behind the step on
+ *                          the library's own stream: no host wait, step k+1 can be queued at once
+ *   ofk_comm_fetch_records waits for the gather of `slot`, copies [world][batch][8] f32 (rank-major) to host_out
+ *   ofk_comm_allreduce_f64 in-place all-reduce of n <= 64 doubles (op 0 sum, 1 max, 2 min), synchronous: barriers, max-over-ranks
+ *                          timing, and the Monte-Carlo sweep's per-step (sum v, sum v^2, count) statistics */
+int ofk_comm_unique_id(uint8_t *ids, int n_ids);
+int ofk_comm_init(ofk_ctx *ctx, const uint8_t *ids, int n_ids, int rank, int world);
+int ofk_comm_destroy(ofk_ctx *ctx);
+int ofk_comm_rank(const ofk_ctx *ctx);
+int ofk_comm_world(const ofk_ctx *ctx);
+int ofk_comm_gather_records(ofk_ctx *ctx, int batch, int slot);
+int ofk_comm_fetch_records(ofk_ctx *ctx, int slot, int batch, float *host_out);
+int ofk_comm_allreduce_f64(ofk_ctx *ctx, double *inout, int n, int op);
 
 /* Number of concurrent slices ofk_pairs_run cuts the batch into (1..8, default 1): each slice runs the whole stage chain on
  * its own HIP stream so that latency-bound stages overlap with streaming ones; results do not depend on it.  With more than

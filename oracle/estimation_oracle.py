@@ -232,6 +232,52 @@ def of_simulation(linear_velocity, angular_velocity, height_above_gr, normal_vec
     return v_obs, feas, Rb
 
 
+def feas_simulation(angular_velocity, height_above_gr, normal_vector, translation, pos, true_flow, true_vel, sig, z, iterations,
+                    per_trial=False):
+    """simulation.py:70-104 with the np.random draws replaced by standard normals `z` in the reference's draw order: per
+    iteration 3 (omega), 3 (t), 1 (height), 2N (flow), 2N (position), 3 (velocity), 1 + 1 (the two orientation errors, each
+    normal_sig * N(0, normal_sig), :87-88).  sig = (ang_vel, translation, height, flow, position, normal, velocity) — the
+    reference reads the last two from module globals.  Returns the six per-point means in the reference's order
+    (backward_para, backward_dist, forward_para, forward_dist, backward_res, forward_res) as [6, N] and v_obs [iterations, 3]
+    (with per_trial=True also the [iterations, 6, N] table)."""
+    N = len(pos)
+    per = 12 + 4 * N
+    z = np.asarray(z, dtype=np.float64).reshape(iterations, per)
+    av = np.asarray(angular_velocity, np.float64); nv = np.asarray(normal_vector, np.float64)
+    tr = np.asarray(translation, np.float64); tv = np.asarray(true_vel, np.float64)
+    table = np.zeros((iterations, 6, N)); v_obs = np.zeros((iterations, 3))
+    for i in range(iterations):
+        zi = z[i]; o = 0
+        ang_err = av + sig[0] * zi[o:o + 3]; o += 3
+        tr_err = tr + sig[1] * zi[o:o + 3]; o += 3
+        h_err = height_above_gr + sig[2] * zi[o:o + 1]; o += 1
+        flow_err = true_flow + sig[3] * zi[o:o + 2 * N].reshape(N, 2); o += 2 * N
+        pos_err = pos + sig[4] * zi[o:o + 2 * N].reshape(N, 2); o += 2 * N
+        vel_err = tv + sig[6] * zi[o:o + 3]; o += 3
+        o1 = sig[5] * (sig[5] * zi[o]); o2 = sig[5] * (sig[5] * zi[o + 1])
+        Ry = np.array([[np.cos(o2), 0, np.sin(o2)], [0, 1, 0], [-np.sin(o2), 0, np.cos(o2)]])
+        Rx = np.array([[1, 0, 0], [0, np.cos(o1), -np.sin(o1)], [0, np.sin(o1), np.cos(o1)]])
+        normal_err = Ry @ Rx @ nv
+        v_obs[i], _, _ = solve_lgs_sim(pos_err, flow_err, h_err, normal_err, ang_err, tr_err)
+        table[i, 0], table[i, 1] = feasibility_sim(pos_err, v_obs[i], flow_err, ang_err, tr_err, normal_err)
+        table[i, 2], table[i, 3] = feasibility_sim(pos_err, vel_err, flow_err, ang_err, tr_err, normal_err)
+        # rows of the system (:96-101): A_j = [p]x (n.p), b_j = [p]x (u + [p]x omega)
+        xh = _xhat(pos_err)                                                     # [N,3,3]
+        u3 = np.concatenate([flow_err, np.zeros((N, 1))], axis=1)
+        b = np.einsum("nij,nj->ni", xh, u3 + np.einsum("nij,j->ni", xh, ang_err))
+        A = xh * (_hom(pos_err) @ normal_err)[:, None, None]
+        table[i, 4] = np.linalg.norm(np.einsum("nij,j->ni", A, v_obs[i]) - b, axis=1)
+        table[i, 5] = np.linalg.norm(np.einsum("nij,j->ni", A, vel_err) - b, axis=1)
+    mean = np.mean(table, axis=0)
+    return (mean, v_obs, table) if per_trial else (mean, v_obs)
+
+
+def overlap(data1, data2, bins=100):
+    """simulation.py:124-136 — histogram both samples over the common edges of the stacked sample, sum of the bin-wise minima."""
+    edges = np.histogram(np.hstack((data1, data2)), bins=bins)[1]
+    return int(np.sum(np.minimum(np.histogram(data1, bins=edges)[0], np.histogram(data2, bins=edges)[0])))
+
+
 def associate(t_img, imu_t, imu_q, imu_w, hgt_t, hgt_r):
     """evaluate_exp.py:77-95 for a batch of image times: nearest IMU / range sample (np.argmin of the absolute time
     difference: the first minimum), dist = range, R from the quaternion (same expression as quat_to_rot), normal = R e_z,

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Golden vectors for feas_simulation / overlap (numerical_simulation/simulation.py:70-104, 124-136) from the REFERENCE's own
-code, driven exactly like its one live experiment (simulation.py:753-783: three ground planes, the second one with randomly
+code, driven exactly like its one live experiment (simulation.py:753-774: three ground planes, the second one with randomly
 rotated flow).  Build container only (needs /root/reference); only inputs, the noise that was drawn and the outputs are stored.
 
     python tests/golden/make_golden_feas.py        # rewrites tests/golden/reference_feas.npz
 
 The functions are AST-extracted (make_golden.load_defs); the constants block (simulation.py:154-178) and the experiment set-up
-(:766-783) are exec'd by line range.  np.random is replaced by a seeded generator that logs every normal draw in order
+(:753-754, :762-774) are exec'd by line range.  np.random is replaced by a seeded generator that logs every normal draw in order
 (InjectedNormal of make_golden.py, plus uniform for the experiment's rotation angles), so the device kernel and the oracle can
 be fed the same noise: per trial 3 + 3 + 1 + 2N + 2N + 3 + 1 + 1 standard normals.
 """
@@ -41,7 +41,7 @@ def main():
         g["iterations"] = iters
         if case == 1:                                            # a second case off the experiment's numbers: tilted normal, other sigmas
             g["normal_vector"] = np.array([0.05, -0.03, 1.0]); g["normal_sig"] = 0.02; g["velocity_sig"] = 0.05
-        setup = load_lines(SIM, 766, 783)
+        setup = load_lines(SIM, 753, 754) + "\n" + load_lines(SIM, 762, 774)      # centre the points; planes; feas_simulation(...)
         n_before = len(inj.log)
         exec(setup, g)                                           # planes, rotated second plane, feas_simulation(...)
         assert n_before == 0

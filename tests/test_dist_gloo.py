@@ -1,5 +1,13 @@
-"""CPU-only, world size 2 over gloo: the multi-GPU path's sharding and its single exchange step
-(all_gather of [B,8] f32 velocity records + MAX-over-ranks timing), as bench.py uses them over RCCL."""
+"""CPU-only, world size 2: the multi-GPU path's sharding, its bootstrap and its exchange semantics.
+
+The product's transport is RCCL through libofk.so (ofk_comm_*, no torch).  Without GPUs it cannot run, so two things are
+checked here instead:
+  * test_world2_gloo_gather_and_shard — gloo (torch.distributed) stands in for the transport: shard_range ownership, the
+    rank-major all-gather layout of the [B, 8] records and MAX-over-ranks timing, i.e. the semantics ofk_comm_gather_records /
+    ofk_comm_allreduce_f64 implement on the GPUs;
+  * test_world2_bootstrap_with_fake_collective — sharding.exchange_unique_id + env_ranks + combine_moments with two plain
+    processes and a file-based fake all-reduce: the torch-free bootstrap path bench.py and simulation.sweep_flow_errors take.
+"""
 import os
 import socket
 import subprocess
@@ -17,17 +25,20 @@ WORKER = textwrap.dedent("""
     from of_amd import sharding
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
+    assert sharding.env_ranks() == (rank, world, rank)
     total = 13
     lo, hi = sharding.shard_range(total, rank, world)
     # every rank "solves" its own pairs: record k of the global batch is a pure function of k
     B = 7
     local = torch.tensor([[1000 * rank + k + 0.125 * j for j in range(8)] for k in range(B)], dtype=torch.float32)
-    allrec = sharding.gather_records(dist, local)
+    allrec = torch.empty((world * B, 8), dtype=torch.float32)
+    dist.all_gather_into_tensor(allrec, local)                 # what ncclAllGather does with the ranks' send buffers
     assert allrec.shape == (world * B, 8)
     for r in range(world):
         assert torch.equal(allrec[r * B:(r + 1) * B, 0], torch.arange(B, dtype=torch.float32) + 1000 * r)
-    t = sharding.max_over_ranks(dist, 0.5 + rank)
-    assert t == 0.5 + (world - 1)
+    t = torch.tensor([0.5 + rank], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)                     # Comm.max
+    assert float(t) == 0.5 + (world - 1)
     owned = torch.zeros(total, dtype=torch.int32); owned[lo:hi] = 1
     dist.all_reduce(owned)
     assert bool((owned == 1).all()), owned          # every unit owned exactly once
@@ -35,19 +46,80 @@ WORKER = textwrap.dedent("""
     print("rank", rank, "ok")
 """) % ROOT
 
+BOOT = textwrap.dedent("""
+    import os, sys, time
+    import numpy as np
+    sys.path.insert(0, %r)
+    from __graft_entry__ import load_package
+    load_package()
+    from of_amd import sharding
+    assert "torch" not in sys.modules
+    rank, world, local = sharding.env_ranks()
+    path = os.environ["OFK_TEST_RDV"]
+    made = []
+    def make_id():
+        made.append(1)
+        return bytes((7 * i + 3) %% 256 for i in range(128))
+    uid = sharding.exchange_unique_id(make_id, rank, world, path=path, timeout=60)
+    assert uid == bytes((7 * i + 3) %% 256 for i in range(128)) and len(made) == (1 if rank == 0 else 0)
 
-def test_world2_gloo_gather_and_shard(tmp_path):
+    # a fake all-reduce(sum) over files: each rank publishes its vector, waits for the others', adds them up in rank order
+    def allreduce(v, tag=[0]):
+        tag[0] += 1
+        np.save(f"{path}.red{tag[0]}.{rank}.tmp.npy", v); os.replace(f"{path}.red{tag[0]}.{rank}.tmp.npy", f"{path}.red{tag[0]}.{rank}.npy")
+        parts = []
+        for r in range(world):
+            f = f"{path}.red{tag[0]}.{r}.npy"
+            t0 = time.time()
+            while not os.path.exists(f):
+                assert time.time() - t0 < 60
+                time.sleep(0.002)
+            parts.append(np.load(f))
+        return np.sum(parts, axis=0)
+
+    # Monte-Carlo statistics over sharded trials == statistics over all trials (simulation.py:199-200: np.mean / np.std)
+    rng = np.random.default_rng(11)
+    v_all = 1.0 + 0.02 * rng.standard_normal((101, 3))
+    lo, hi = sharding.shard_range(len(v_all), rank, world)
+    mine = v_all[lo:hi]
+    mean, std, n = sharding.combine_moments(mine.sum(0), (mine * mine).sum(0), len(mine), allreduce)
+    assert n == 101
+    np.testing.assert_allclose(mean, v_all.mean(0), rtol=1e-13)
+    np.testing.assert_allclose(std, v_all.std(0), rtol=1e-9)
+    print("rank", rank, "ok")
+""") % ROOT
+
+
+def _run_world(script_text, tmp_path, extra_env):
     script = tmp_path / "worker.py"
-    script.write_text(WORKER)
+    script.write_text(script_text)
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", **extra_env)
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=240)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"rank {r} ok" in o, o
+
+
+def test_world2_gloo_gather_and_shard(tmp_path):
+    _run_world(WORKER, tmp_path, {})
+
+
+def test_world2_bootstrap_with_fake_collective(tmp_path):
+    _run_world(BOOT, tmp_path, {"OFK_TEST_RDV": str(tmp_path / "rdv")})
+    assert not (tmp_path / "rdv").exists()                      # rank 0 cleaned the rendezvous file up
+
+
+def test_rendezvous_path_is_per_launch():
+    from __graft_entry__ import load_package
+    load_package()
+    from of_amd.sharding import rendezvous_path, env_ranks
+    a = rendezvous_path({"MASTER_PORT": "29500"}, "/tmp"); b = rendezvous_path({"MASTER_PORT": "29501"}, "/tmp")
+    assert a != b and str(os.getppid()) in a
+    assert env_ranks({}) == (0, 1, 0) and env_ranks({"RANK": "3", "WORLD_SIZE": "8", "LOCAL_RANK": "3"}) == (3, 8, 3)
 
 
 def test_shard_range_properties():

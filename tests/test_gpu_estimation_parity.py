@@ -147,3 +147,57 @@ def test_of_simulation_statistics_vs_saved_sweep(gpu_ctx, golden):
     v, _ = gpu_ctx.of_simulation(truth, sig, data, tf, z)
     assert np.all(np.abs(v.mean(0) - mean_s[i]) < 4 * std_s[i] / np.sqrt(100) + 4 * v.std(0) / np.sqrt(2000))
     assert np.all(np.abs(v.std(0) / std_s[i] - 1) < 0.35)
+
+
+# ---- feas_simulation + overlap (simulation.py:70-104, 124-136; the live experiment :753-774), golden from the reference's functions
+@pytest.fixture(scope="module")
+def feas_golden():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_feas.npz"))
+
+
+@pytest.mark.parametrize("case", [0, 1])
+def test_feas_simulation_matches_reference(gpu_ctx, feas_golden, case):
+    g = feas_golden
+    z = g[f"f{case}_z"]
+    mean, v_obs, per = gpu_ctx.feas_simulation(g[f"f{case}_truth"], g[f"f{case}_sig"], g[f"f{case}_pos"], g[f"f{case}_true_flow"], z, per_trial=True)
+    np.testing.assert_allclose(mean, g[f"f{case}_mean"], rtol=1e-9, atol=1e-12)
+    tr = g[f"f{case}_truth"]
+    om, vo, tab = eo.feas_simulation(tr[3:6], tr[6], tr[7:10], tr[10:13], g[f"f{case}_pos"], g[f"f{case}_true_flow"], tr[13:16], g[f"f{case}_sig"], z,
+                                     len(z), per_trial=True)
+    np.testing.assert_allclose(v_obs, vo, rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(per, tab, rtol=1e-9, atol=1e-12)
+    a, b = g[f"f{case}_split"]
+    for q in range(6):                                          # the three planes' histograms of every statistic (:788-810)
+        r = g[f"f{case}_mean"][q]
+        got = [gpu_ctx.hist_overlap(r[:a], r[a:b]), gpu_ctx.hist_overlap(r[a:b], r[b:]), gpu_ctx.hist_overlap(r[:a], r[b:])]
+        assert got == list(g[f"f{case}_overlap"][q]), (q, got)
+
+
+def test_hist_overlap_edges_and_degenerate_samples(gpu_ctx, feas_golden):
+    g = feas_golden
+    assert gpu_ctx.hist_overlap(g["ov_d1"], g["ov_d2"]) == int(g["ov_12"])
+    assert gpu_ctx.hist_overlap(g["ov_d3"], g["ov_d3"]) == int(g["ov_33"]) == 40     # all values equal: numpy widens the range by 0.5
+    assert gpu_ctx.hist_overlap(g["ov_d1"], g["ov_d3"]) == int(g["ov_13"])
+    rng = np.random.default_rng(5)
+    for n1, n2, bins in ((1, 1, 100), (1000, 3, 7), (257, 4096, 1024), (50, 50, 1)):
+        a, b = rng.normal(0, 1, n1), rng.normal(0.3, 2, n2)
+        assert gpu_ctx.hist_overlap(a, b, bins) == eo.overlap(a, b, bins), (n1, n2, bins)
+    with pytest.raises(Exception):
+        gpu_ctx.hist_overlap(a, b, 2000)
+
+
+def test_simulation_facade_feas_simulation_and_sweep_statistics(pkg, feas_golden):
+    """Drop-in call with the reference's positional signature (module globals true_flow / iterations / normal_sig / velocity_sig),
+    noise injected; then the experiment's read-out (:778-779): the forward parallelity separates the rotated-flow plane."""
+    from of_amd import simulation as sim
+    g = feas_golden
+    tr, sg = g["f0_truth"], g["f0_sig"]
+    sim.true_flow = g["f0_true_flow"]; sim.iterations = len(g["f0_z"]); sim.normal_sig = float(sg[5]); sim.velocity_sig = float(sg[6])
+    out = sim.feas_simulation(tr[0:3], tr[3:6], tr[6], tr[7:10], tr[10:13], g["f0_pos"], sg[0], sg[1], sg[2], sg[3], sg[4], sg[5], tr[13:16], z=g["f0_z"])
+    assert len(out) == 6
+    np.testing.assert_allclose(np.stack(out), g["f0_mean"], rtol=1e-9, atol=1e-12)
+    a, b = g["f0_split"]
+    assert sim.overlap(out[2][:a], out[2][a:b]) == int(g["f0_overlap"][2][0])
+    # static planes have forward parallelity near +1, the plane with randomly rotated flow does not
+    assert np.median(out[2][:a]) > 0.9 and np.median(out[2][b:]) > 0.9 and np.mean(out[2][a:b] > 0.88) < 0.35

@@ -1,5 +1,7 @@
 """Pins oracle/estimation_oracle.py against golden vectors produced by the reference's own numpy
 functions (tests/golden/make_golden.py).  CPU only."""
+import os
+
 import numpy as np
 import pytest
 
@@ -130,3 +132,28 @@ def test_kf_scalar_recursion():
         k = ps / (ps + 10); xs = xs + k * (z[0] - xs); ps = (1 - k) * ps
         assert abs(x[0] - xs) < 1e-14 and abs(P[0, 0] - ps) < 1e-15
         assert abs(P[0, 1]) < 1e-18
+
+
+# ---- feas_simulation / overlap (simulation.py:70-104, 124-136): golden vectors from the reference's own functions driven like its
+#      live experiment (simulation.py:753-774), tests/golden/make_golden_feas.py
+@pytest.fixture(scope="module")
+def feas_golden():
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_feas.npz"))
+
+
+@pytest.mark.parametrize("case", [0, 1])
+def test_feas_simulation_oracle_matches_reference(feas_golden, case):
+    g = feas_golden
+    tr, sig, z = g[f"f{case}_truth"], g[f"f{case}_sig"], g[f"f{case}_z"]
+    mean, v_obs = eo.feas_simulation(tr[3:6], tr[6], tr[7:10], tr[10:13], g[f"f{case}_pos"], g[f"f{case}_true_flow"], tr[13:16], sig, z, len(z))
+    np.testing.assert_allclose(mean, g[f"f{case}_mean"], rtol=1e-10, atol=1e-12)
+    a, b = g[f"f{case}_split"]
+    for q in range(6):
+        r = g[f"f{case}_mean"][q]
+        assert [eo.overlap(r[:a], r[a:b]), eo.overlap(r[a:b], r[b:]), eo.overlap(r[:a], r[b:])] == list(g[f"f{case}_overlap"][q])
+
+
+def test_overlap_oracle_matches_reference(feas_golden):
+    g = feas_golden
+    assert eo.overlap(g["ov_d1"], g["ov_d2"]) == int(g["ov_12"]) and eo.overlap(g["ov_d3"], g["ov_d3"]) == int(g["ov_33"]) == 40
+    assert eo.overlap(g["ov_d1"], g["ov_d3"]) == int(g["ov_13"])

@@ -57,7 +57,9 @@ def mnemonics(lines):
         if m:
             name, rest = m.group(1), m.group(2)
             dpp = ("_dpp" in name) or any(k in rest for k in ("wave_shr", "wave_shl", "row_shr", "row_shl", "quad_perm", "row_mirror", "row_half_mirror", "row_bcast"))
-            out.append((name, dpp))
+            ops = rest.split(";")[0].split(",")
+            sgpr = any(re.match(r"^\s*-?\|?s\d+|^\s*s\[", o) for o in ops[1:])      # a source operand in an SGPR
+            out.append((name, dpp, sgpr))
     return out
 
 
@@ -73,8 +75,12 @@ def load_rates(path):
     return rates
 
 
-def cost(name, dpp, rates):
+def cost(name, dpp, rates, sgpr_src=False):
     base = re.sub(r"_(e32|e64|dpp|sdwa|e64_dpp)$", "", name)
+    if base == "v_cndmask_b32":                        # the probe's VCC-only loop reads 10x (nothing in it ever writes VCC); a
+        base = "v_cndmask_b32 (sgpr mask)"             # select behind a compare costs what the SGPR-mask form costs (cmp+cndmask row)
+    if sgpr_src and base in DEFAULT_2CLK:              # an SGPR operand halves the rate of the full-rate VOP2 forms ("v_mul_f32 (sgpr src)")
+        return 4
     if dpp:
         for k in (f"{base}_dpp wave_shr", f"{base}_dpp row_shr"):
             if k in rates:
@@ -94,14 +100,17 @@ def cost(name, dpp, rates):
 def mix(instrs, rates):
     by = collections.Counter()
     cyc = collections.Counter()
-    for name, dpp in instrs:
-        if name.startswith("v_") and not name.startswith(("v_readlane", "v_readfirstlane")) or name.startswith(("v_readlane", "v_readfirstlane")):
+    for name, dpp, sgpr in instrs:
+        if name.startswith("v_"):
             key = re.sub(r"_(e32|e64)$", "", name) + (" (dpp)" if dpp and "_dpp" not in name else "")
+            c = cost(name, dpp, rates, sgpr)
+            if sgpr and c == 4 and re.sub(r"_(e32|e64)$", "", name) in DEFAULT_2CLK:
+                key += " (sgpr src)"
             by[key] += 1
-            cyc[key] += cost(name, dpp, rates)
+            cyc[key] += c
     n = sum(by.values()); c = sum(cyc.values())
     other = collections.Counter()
-    for name, _ in instrs:
+    for name, _, _ in instrs:
         if name.startswith("ds_"):
             other["lds"] += 1
         elif name.startswith("s_"):
