@@ -395,12 +395,10 @@ void ofk_launch_feasibility(hipStream_t s, int variant, const double *x, const d
 }
 
 // ------------------------------------------------------------------------------------------------ IMU propagation
-__global__ void k_imu(double *__restrict__ state, const double *__restrict__ msg, int batch)
+// One message of optical_fusion.call_imu (node:61-89) applied to one stream's state; dv (nullable, 3 doubles) accumulates the
+// dead-reckoning increments R (a - 9.81 n) dt (the control input of the resident filter, pipeline.FilterModel.ekf6).
+__device__ __forceinline__ void imu_apply(double *s, const double *m, double *dv)
 {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= batch) return;
-    double *s = state + (size_t)b * OFK_IMU_STATE;
-    const double *m = msg + (size_t)b * OFK_IMU_MSG;
     const double secs = m[0], nsecs = m[1], qx = m[2], qy = m[3], qz = m[4], qw = m[5];
     double R[9];
     R[0] = 1.0 - 2 * (qy * qy + qz * qz); R[1] = 2 * (qx * qy - qw * qz); R[2] = 2 * (qw * qy + qx * qz);
@@ -413,15 +411,39 @@ __global__ void k_imu(double *__restrict__ state, const double *__restrict__ msg
         const double cur = (secs - s[4]) + nsecs / 1e9;
         const double el = cur - s[3];
         const double a0 = m[12] - 9.81 * n0, a1 = m[13] - 9.81 * n1, a2 = m[14] - 9.81 * n2;
-        s[0] = s[0] + (R[0] * a0 + R[1] * a1 + R[2] * a2) * el;
-        s[1] = s[1] + (R[3] * a0 + R[4] * a1 + R[5] * a2) * el;
-        s[2] = s[2] + (R[6] * a0 + R[7] * a1 + R[8] * a2) * el;
+        const double d0 = (R[0] * a0 + R[1] * a1 + R[2] * a2) * el, d1 = (R[3] * a0 + R[4] * a1 + R[5] * a2) * el,
+                     d2 = (R[6] * a0 + R[7] * a1 + R[8] * a2) * el;
+        s[0] = s[0] + d0; s[1] = s[1] + d1; s[2] = s[2] + d2;
+        if (dv) { dv[0] += d0; dv[1] += d1; dv[2] += d2; }
         s[3] = cur;
     }
     for (int k = 0; k < 9; ++k) s[6 + k] = R[k];
     s[15] = n0; s[16] = n1; s[17] = n2;
     s[18] = m[6]; s[19] = m[7]; s[20] = m[8];
     s[21] = m[9]; s[22] = m[10]; s[23] = m[11];
+}
+
+__global__ void k_imu(double *__restrict__ state, const double *__restrict__ msg, int batch)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    imu_apply(state + (size_t)b * OFK_IMU_STATE, msg + (size_t)b * OFK_IMU_MSG, nullptr);
+}
+
+// The IMU messages a stream received since its last frame, applied in order to the RESIDENT state (one thread per stream; the
+// arithmetic is a handful of operations per message).  msgs [batch][max_msgs][OFK_IMU_MSG], counts [batch].
+__global__ void k_imu_seq(double *__restrict__ state, double *__restrict__ dv, const double *__restrict__ msgs,
+                          const int *__restrict__ counts, int max_msgs, int batch)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    const int n = min(max(counts[b], 0), max_msgs);
+    for (int k = 0; k < n; ++k) imu_apply(state + (size_t)b * OFK_IMU_STATE, msgs + ((size_t)b * max_msgs + k) * OFK_IMU_MSG, dv + 3 * (size_t)b);
+}
+
+void ofk_launch_imu_seq(hipStream_t s, double *state, double *dv, const double *msgs, const int *counts, int max_msgs, int batch)
+{
+    hipLaunchKernelGGL(k_imu_seq, dim3((batch + 63) / 64), dim3(64), 0, s, state, dv, msgs, counts, max_msgs, batch);
 }
 
 void ofk_launch_imu(hipStream_t s, double *state, const double *msg, int batch)
@@ -449,6 +471,51 @@ void ofk_launch_post_solve(hipStream_t s, const double *v_obs, const double *rot
 
 // ------------------------------------------------------------------------------------------------ Kalman filter
 #define KF_MAX 6
+// cv2.KalmanFilter.predict(control) (of_module.py:122): x = F x (+ B u), P = F P F^T + Q.  Row-major matrices, ns <= 6.
+__device__ void kf_predict_dev(int ns, int nc, const double *F, const double *Bm, const double *Q, const double *u, double *x, double (*P)[KF_MAX])
+{
+    double xn[KF_MAX], T[KF_MAX][KF_MAX];
+    for (int i = 0; i < ns; ++i) { double s = 0; for (int j = 0; j < ns; ++j) s += F[i * ns + j] * x[j]; xn[i] = s; }
+    if (Bm && u) for (int i = 0; i < ns; ++i) { double s = 0; for (int j = 0; j < nc; ++j) s += Bm[i * nc + j] * u[j]; xn[i] += s; }
+    for (int i = 0; i < ns; ++i) x[i] = xn[i];
+    for (int i = 0; i < ns; ++i) for (int j = 0; j < ns; ++j) { double s = 0; for (int k = 0; k < ns; ++k) s += F[i * ns + k] * P[k][j]; T[i][j] = s; }
+    for (int i = 0; i < ns; ++i) for (int j = 0; j < ns; ++j) { double s = 0; for (int k = 0; k < ns; ++k) s += T[i][k] * F[j * ns + k]; P[i][j] = s + Q[i * ns + j]; }
+}
+
+// cv2.KalmanFilter.correct(z) (of_module.py:152): K = P H^T (H P H^T + R)^-1, x += K (z - H x), P -= K H P.
+__device__ void kf_correct_dev(int ns, int nm, const double *H, const double *Rm, const double *z, double *x, double (*P)[KF_MAX])
+{
+    double HP[KF_MAX][KF_MAX], S[KF_MAX][KF_MAX], K[KF_MAX][KF_MAX], T[KF_MAX][KF_MAX];      // HP: nm x ns, S: nm x nm, K: ns x nm
+    for (int i = 0; i < nm; ++i) for (int j = 0; j < ns; ++j) { double s = 0; for (int k = 0; k < ns; ++k) s += H[i * ns + k] * P[k][j]; HP[i][j] = s; }
+    for (int i = 0; i < nm; ++i) for (int j = 0; j < nm; ++j) { double s = 0; for (int k = 0; k < ns; ++k) s += HP[i][k] * H[j * ns + k]; S[i][j] = s + Rm[i * nm + j]; }
+    // solve S Y = HP (Y: nm x ns) by Gauss-Jordan with partial pivoting; K = Y^T
+    for (int c = 0; c < nm; ++c) {
+        int piv = c; double best = fabs(S[c][c]);
+        for (int r2 = c + 1; r2 < nm; ++r2) if (fabs(S[r2][c]) > best) { best = fabs(S[r2][c]); piv = r2; }
+        if (piv != c) {
+            for (int j = 0; j < nm; ++j) { const double tmp = S[c][j]; S[c][j] = S[piv][j]; S[piv][j] = tmp; }
+            for (int j = 0; j < ns; ++j) { const double tmp = HP[c][j]; HP[c][j] = HP[piv][j]; HP[piv][j] = tmp; }
+        }
+        const double inv = 1.0 / S[c][c];
+        for (int j = 0; j < nm; ++j) S[c][j] *= inv;
+        for (int j = 0; j < ns; ++j) HP[c][j] *= inv;
+        for (int r2 = 0; r2 < nm; ++r2) if (r2 != c) {
+            const double f = S[r2][c];
+            if (f != 0.0) {
+                for (int j = 0; j < nm; ++j) S[r2][j] -= f * S[c][j];
+                for (int j = 0; j < ns; ++j) HP[r2][j] -= f * HP[c][j];
+            }
+        }
+    }
+    for (int i = 0; i < ns; ++i) for (int j = 0; j < nm; ++j) K[i][j] = HP[j][i];
+    double innov[KF_MAX];
+    for (int i = 0; i < nm; ++i) { double s = 0; for (int k = 0; k < ns; ++k) s += H[i * ns + k] * x[k]; innov[i] = z[i] - s; }
+    for (int i = 0; i < ns; ++i) { double s = 0; for (int j = 0; j < nm; ++j) s += K[i][j] * innov[j]; x[i] += s; }
+    // P = P - K (H P)   (H P recomputed from the prior P)
+    for (int i = 0; i < nm; ++i) for (int j = 0; j < ns; ++j) { double s = 0; for (int k = 0; k < ns; ++k) s += H[i * ns + k] * P[k][j]; T[i][j] = s; }
+    for (int i = 0; i < ns; ++i) for (int j = 0; j < ns; ++j) { double s = 0; for (int k = 0; k < nm; ++k) s += K[i][k] * T[k][j]; P[i][j] -= s; }
+}
+
 __global__ void k_kf(int ns, int nm, int nc, const double *__restrict__ F, const double *__restrict__ Bm,
                      const double *__restrict__ H, const double *__restrict__ Q, const double *__restrict__ Rm,
                      double *__restrict__ xs, double *__restrict__ Ps, const double *__restrict__ us,
@@ -456,47 +523,10 @@ __global__ void k_kf(int ns, int nm, int nc, const double *__restrict__ F, const
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= batch) return;
-    double x[KF_MAX], P[KF_MAX][KF_MAX], T[KF_MAX][KF_MAX];
+    double x[KF_MAX], P[KF_MAX][KF_MAX];
     for (int i = 0; i < ns; ++i) { x[i] = xs[(size_t)b * ns + i]; for (int j = 0; j < ns; ++j) P[i][j] = Ps[((size_t)b * ns + i) * ns + j]; }
-    if (do_predict) {
-        double xn[KF_MAX];
-        for (int i = 0; i < ns; ++i) { double s = 0; for (int j = 0; j < ns; ++j) s += F[i * ns + j] * x[j]; xn[i] = s; }
-        if (Bm && us) for (int i = 0; i < ns; ++i) { double s = 0; for (int j = 0; j < nc; ++j) s += Bm[i * nc + j] * us[(size_t)b * nc + j]; xn[i] += s; }
-        for (int i = 0; i < ns; ++i) x[i] = xn[i];
-        for (int i = 0; i < ns; ++i) for (int j = 0; j < ns; ++j) { double s = 0; for (int k = 0; k < ns; ++k) s += F[i * ns + k] * P[k][j]; T[i][j] = s; }
-        for (int i = 0; i < ns; ++i) for (int j = 0; j < ns; ++j) { double s = 0; for (int k = 0; k < ns; ++k) s += T[i][k] * F[j * ns + k]; P[i][j] = s + Q[i * ns + j]; }
-    }
-    if (zs) {
-        double HP[KF_MAX][KF_MAX], S[KF_MAX][KF_MAX], K[KF_MAX][KF_MAX];      // HP: nm x ns, S: nm x nm, K: ns x nm
-        for (int i = 0; i < nm; ++i) for (int j = 0; j < ns; ++j) { double s = 0; for (int k = 0; k < ns; ++k) s += H[i * ns + k] * P[k][j]; HP[i][j] = s; }
-        for (int i = 0; i < nm; ++i) for (int j = 0; j < nm; ++j) { double s = 0; for (int k = 0; k < ns; ++k) s += HP[i][k] * H[j * ns + k]; S[i][j] = s + Rm[i * nm + j]; }
-        // solve S Y = HP (Y: nm x ns) by Gauss-Jordan with partial pivoting; K = Y^T
-        for (int c = 0; c < nm; ++c) {
-            int piv = c; double best = fabs(S[c][c]);
-            for (int r2 = c + 1; r2 < nm; ++r2) if (fabs(S[r2][c]) > best) { best = fabs(S[r2][c]); piv = r2; }
-            if (piv != c) {
-                for (int j = 0; j < nm; ++j) { const double tmp = S[c][j]; S[c][j] = S[piv][j]; S[piv][j] = tmp; }
-                for (int j = 0; j < ns; ++j) { const double tmp = HP[c][j]; HP[c][j] = HP[piv][j]; HP[piv][j] = tmp; }
-            }
-            const double inv = 1.0 / S[c][c];
-            for (int j = 0; j < nm; ++j) S[c][j] *= inv;
-            for (int j = 0; j < ns; ++j) HP[c][j] *= inv;
-            for (int r2 = 0; r2 < nm; ++r2) if (r2 != c) {
-                const double f = S[r2][c];
-                if (f != 0.0) {
-                    for (int j = 0; j < nm; ++j) S[r2][j] -= f * S[c][j];
-                    for (int j = 0; j < ns; ++j) HP[r2][j] -= f * HP[c][j];
-                }
-            }
-        }
-        for (int i = 0; i < ns; ++i) for (int j = 0; j < nm; ++j) K[i][j] = HP[j][i];
-        double innov[KF_MAX];
-        for (int i = 0; i < nm; ++i) { double s = 0; for (int k = 0; k < ns; ++k) s += H[i * ns + k] * x[k]; innov[i] = zs[(size_t)b * nm + i] - s; }
-        for (int i = 0; i < ns; ++i) { double s = 0; for (int j = 0; j < nm; ++j) s += K[i][j] * innov[j]; x[i] += s; }
-        // P = P - K (H P)   (H P recomputed from the prior P)
-        for (int i = 0; i < nm; ++i) for (int j = 0; j < ns; ++j) { double s = 0; for (int k = 0; k < ns; ++k) s += H[i * ns + k] * P[k][j]; T[i][j] = s; }
-        for (int i = 0; i < ns; ++i) for (int j = 0; j < ns; ++j) { double s = 0; for (int k = 0; k < nm; ++k) s += K[i][k] * T[k][j]; P[i][j] -= s; }
-    }
+    if (do_predict) kf_predict_dev(ns, nc, F, Bm, Q, (Bm && us) ? us + (size_t)b * nc : nullptr, x, P);
+    if (zs) kf_correct_dev(ns, nm, H, Rm, zs + (size_t)b * nm, x, P);
     for (int i = 0; i < ns; ++i) { xs[(size_t)b * ns + i] = x[i]; for (int j = 0; j < ns; ++j) Ps[((size_t)b * ns + i) * ns + j] = P[i][j]; }
 }
 
@@ -505,6 +535,171 @@ void ofk_launch_kf(hipStream_t s, int ns, int nm, int nc, const double *F, const
                    int do_predict)
 {
     hipLaunchKernelGGL(k_kf, dim3((batch + 63) / 64), dim3(64), 0, s, ns, nm, nc, F, Bm, H, Q, Rm, x, P, u, z, batch, do_predict);
+}
+
+// ------------------------------------------------------------------------------------------------ fused stream step
+// One block per video stream, behind LK: everything between calcOpticalFlowPyrLK and the next frame of the reference's loops,
+// with the per-stream filter state RESIDENT on the device —
+//   of_module.py:96-152   centre; (synthetic rotational flow :113-114); kalman.predict(control) :122; legacy r_tilde with the
+//                         predicted velocity :125; keep r - (status - 1) >= T :129-131; A_i = [p]x / dist_i system :136-146;
+//                         kalman.correct(-v_obs) :152; old_pos = new_pos[keep] :166
+//   node:229-261          centre + scale; r_tilde with the dead-reckoned velocity :238-245; solve_lgs :257; lever arm + rotation
+//                         :258; self.vel = v_uav :261 (the IMU state's velocity, dead-reckoned again by the next IMU messages)
+// The keep mask replaces `status` so that k_update_tracks carries exactly the kept points into the next frame.
+__device__ __forceinline__ void legacy_point(double x, double y, double ux, double uy, const double *n, const double *v, double &r, double &dd)
+{
+    double vc0, vc1, vc2, uc0, uc1, uc2;                          // pixhawk_pure_IMU/of_library.py:365-380 (4-arg r_tilde)
+    cross_p(x, y, v[0], v[1], v[2], vc0, vc1, vc2);
+    vc0 = -vc0; vc1 = -vc1; vc2 = -vc2;
+    cross_p(x, y, ux, uy, 0.0, uc0, uc1, uc2);
+    const double vn = sqrt(vc0 * vc0 + vc1 * vc1 + vc2 * vc2), iun = 1.0 / sqrt(uc0 * uc0 + uc1 * uc1 + uc2 * uc2);
+    r = (vc0 * uc0 + vc1 * uc1 + vc2 * uc2) * iun / vn;
+    const double pn = x * n[0] + y * n[1] + n[2];
+    if (pn < 0.0) r = -r;
+    dd = pn * vn * iun;
+}
+
+struct fuse_args {
+    const float *prev_pts, *next_pts; uint8_t *status; const int *counts; int pts_stride;
+    const double *sensors; double *imu_state, *imu_dv;
+    int ns, nm, nc; const double *F, *Bm, *H, *Q, *Rm; double *kf_x, *kf_P;
+    ofk_fusion f; int variant, use_feas; double feas_T;
+    double *records, *fused;
+};
+
+__device__ __forceinline__ bool fuse_point(const fuse_args &g, int i, const float *pp, const float *np_, int st, double cx, double cy,
+                                           double scaling, const double *nrm, const double *om, const double *vp, double d, double &x,
+                                           double &y, double &ux, double &uy, double &wgt)
+{
+    const double X = (double)np_[2 * i], Y = (double)np_[2 * i + 1];
+    x = (X - cx) * scaling; y = (Y - cy) * scaling;
+    if (g.f.flow == OFK_FLOW_ROTATIONAL) {                       // of_module.py:113-114, on the un-centred pixel positions as written there
+        ux = X * Y * om[0] + (1.0 + X * X) * om[1] - Y * om[2];
+        uy = -(1.0 + Y * Y) * om[0] + X * Y * om[1] + X * om[2];
+    } else {
+        ux = (X - (double)pp[2 * i]) * scaling; uy = (Y - (double)pp[2 * i + 1]) * scaling;
+    }
+    wgt = 1.0;
+    if (g.f.keep == OFK_KEEP_LEGACY) {
+        double r;
+        legacy_point(x, y, ux, uy, nrm, vp, r, wgt);
+        return r - (double)(st - 1) >= g.feas_T;                 // of_module.py:129 (a lost point, status 0, passes with r >= T - 1: as written)
+    }
+    if (!st) return false;
+    if (g.use_feas) {
+        double r, dd;
+        rtilde_point(x, y, ux, uy, nrm, vp, d, r, dd);
+        return r <= g.feas_T;                                    // node:241-245
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(256) void k_stream_fuse(fuse_args g)
+{
+    __shared__ double s_red[4];
+    __shared__ double s_v[8];
+    __shared__ double s_pre[12];                                // nrm 0-2, omega 3-5, prior velocity 6-8
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const double *sn = g.sensors + (size_t)b * OFK_SENSOR_DOUBLES;
+    const double d = sn[0], scaling = sn[19], cx = sn[20], cy = sn[21];
+    double *ist = g.f.use_imu && g.imu_state ? g.imu_state + (size_t)b * OFK_IMU_STATE : nullptr;
+    double kx[KF_MAX], kP[KF_MAX][KF_MAX];                      // thread 0 only
+    if (tid == 0) {
+        for (int k = 0; k < 3; ++k) { s_pre[k] = ist ? ist[15 + k] : sn[1 + k]; s_pre[3 + k] = ist ? ist[18 + k] : sn[4 + k]; s_pre[6 + k] = ist ? ist[k] : sn[22 + k]; }
+        if (g.f.filter) {
+            for (int i = 0; i < g.ns; ++i) { kx[i] = g.kf_x[(size_t)b * g.ns + i]; for (int j = 0; j < g.ns; ++j) kP[i][j] = g.kf_P[((size_t)b * g.ns + i) * g.ns + j]; }
+            double u[KF_MAX] = {0, 0, 0, 0, 0, 0};
+            if (g.f.control == OFK_CONTROL_IMU && g.imu_dv) for (int k = 0; k < 3; ++k) u[k] = g.imu_dv[3 * (size_t)b + k];
+            else for (int k = 0; k < 3; ++k) u[k] = sn[25 + k];
+            kf_predict_dev(g.ns, g.nc, g.F, g.nc ? g.Bm : nullptr, g.Q, g.nc ? u : nullptr, kx, kP);
+            if (g.f.keep == OFK_KEEP_LEGACY) for (int k = 0; k < 3; ++k) s_pre[6 + k] = kx[k];      // v_new = kalman.predict(...) (of_module.py:122,125)
+        }
+        if (g.imu_dv) for (int k = 0; k < 3; ++k) g.imu_dv[3 * (size_t)b + k] = 0.0;       // "increments since the last step": a step starts a new interval
+    }
+    __syncthreads();
+    const double nrm[3] = {s_pre[0], s_pre[1], s_pre[2]}, om[3] = {s_pre[3], s_pre[4], s_pre[5]}, vp[3] = {s_pre[6], s_pre[7], s_pre[8]};
+    const int n = g.counts[b];
+    const float *pp = g.prev_pts + (size_t)b * g.pts_stride * 2, *np_ = g.next_pts + (size_t)b * g.pts_stride * 2;
+    uint8_t *st = g.status + (size_t)b * g.pts_stride;
+    Acc a; acc_zero(a);
+    double tracked = 0.0;
+    for (int i = tid; i < n; i += 256) {
+        const int s0 = st[i];
+        tracked += s0 ? 1.0 : 0.0;
+        double x, y, ux, uy, wgt;
+        const bool keep = fuse_point(g, i, pp, np_, s0, cx, cy, scaling, nrm, om, vp, d, x, y, ux, uy, wgt);
+        st[i] = keep ? 1 : 0;
+        if (!keep) continue;
+        double q0, q1, q2, sA, sB;
+        point_terms(g.variant, x, y, ux, uy, nrm, om, d, wgt, q0, q1, q2, sA, sB);
+        acc_point(a, x, y, q0, q1, q2, sA, sB);
+    }
+    acc_block_sum(a, s_red);
+    tracked = block_sum(tracked, s_red);
+    const bool solved = a.cnt > (double)g.f.min_solve;          // of_module.py:138: more than 3 points; node:256: at least 3
+    if (tid == 0) {
+        double v[3] = {0, 0, 0}, s3[3] = {0, 0, 0};
+        const int rank = solved ? solve_from_acc(a, v, s3) : 0;
+        s_v[0] = v[0]; s_v[1] = v[1]; s_v[2] = v[2]; s_v[3] = (double)rank; s_v[4] = s3[0]; s_v[5] = s3[1]; s_v[6] = s3[2];
+    }
+    __syncthreads();                                            // the keep flags written above are visible to the whole block from here on
+    const double v[3] = {s_v[0], s_v[1], s_v[2]};
+    double r = 0.0;
+    if (solved)
+        for (int i = tid; i < n; i += 256) {
+            if (!st[i]) continue;
+            const double X = (double)np_[2 * i], Y = (double)np_[2 * i + 1];
+            const double x = (X - cx) * scaling, y = (Y - cy) * scaling;
+            double ux, uy, wgt = 1.0;
+            if (g.f.flow == OFK_FLOW_ROTATIONAL) { ux = X * Y * om[0] + (1.0 + X * X) * om[1] - Y * om[2]; uy = -(1.0 + Y * Y) * om[0] + X * Y * om[1] + X * om[2]; }
+            else { ux = (X - (double)pp[2 * i]) * scaling; uy = (Y - (double)pp[2 * i + 1]) * scaling; }
+            if (g.f.keep == OFK_KEEP_LEGACY) { double rr; legacy_point(x, y, ux, uy, nrm, vp, rr, wgt); }
+            double q0, q1, q2, sA, sB;
+            point_terms(g.variant, x, y, ux, uy, nrm, om, d, wgt, q0, q1, q2, sA, sB);
+            r += resid_point(x, y, q0, q1, q2, sA, sB, v);
+        }
+    r = block_sum(r, s_red);
+    if (tid == 0) {
+        double *o = g.records + (size_t)b * OFK_RECORD_DOUBLES;
+        const double *R = ist ? ist + 6 : sn + 7, *off = sn + 16;
+        const double e0 = v[0] - (om[1] * off[2] - om[2] * off[1]);                 // v_obs - [w]x offset, then rotate (node:258)
+        const double e1 = v[1] - (om[2] * off[0] - om[0] * off[2]);
+        const double e2 = v[2] - (om[0] * off[1] - om[1] * off[0]);
+        const double vu[3] = {R[0] * e0 + R[1] * e1 + R[2] * e2, R[3] * e0 + R[4] * e1 + R[5] * e2, R[6] * e0 + R[7] * e1 + R[8] * e2};
+        o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = r; o[4] = s_v[3]; o[5] = s_v[4]; o[6] = s_v[5]; o[7] = s_v[6];
+        o[8] = vu[0]; o[9] = vu[1]; o[10] = vu[2];
+        o[11] = a.cnt; o[12] = (double)n; o[13] = tracked; o[14] = 0.0; o[15] = solved ? 1.0 : 0.0;
+        double *fu = g.fused + (size_t)b * 8;
+        if (g.f.filter) {
+            if (solved) {
+                double z[KF_MAX] = {0, 0, 0, 0, 0, 0};
+                for (int k = 0; k < 3; ++k) z[k] = g.f.z_sign * (g.f.z_source ? vu[k] : v[k]);
+                for (int k = 3; k < g.nm; ++k) z[k] = sn[22 + (k - 3)];               // a second velocity measurement (FilterModel.ekf6(gps=True)): the sensors' prior slot
+                kf_correct_dev(g.ns, g.nm, g.H, g.Rm, z, kx, kP);
+            }
+            double tr = 0.0;
+            for (int i = 0; i < g.ns; ++i) { g.kf_x[(size_t)b * g.ns + i] = kx[i]; tr += kP[i][i]; for (int j = 0; j < g.ns; ++j) g.kf_P[((size_t)b * g.ns + i) * g.ns + j] = kP[i][j]; }
+            for (int k = 0; k < 6; ++k) fu[k] = k < g.ns ? kx[k] : 0.0;
+            fu[6] = tr; fu[7] = solved ? 1.0 : 0.0;
+        } else {
+            for (int k = 0; k < 3; ++k) fu[k] = solved ? vu[k] : (ist ? ist[k] : 0.0);
+            fu[3] = fu[4] = fu[5] = fu[6] = 0.0; fu[7] = solved ? 1.0 : 0.0;
+        }
+        if (g.f.vel_overwrite && solved && ist) { ist[0] = vu[0]; ist[1] = vu[1]; ist[2] = vu[2]; }   // node:261
+    }
+}
+
+void ofk_launch_stream_fuse(hipStream_t s, const float *prev_pts, const float *next_pts, uint8_t *status, const int *counts, int pts_stride,
+                            const double *sensors, double *imu_state, double *imu_dv, int ns, int nm, int nc, const double *kf_mats,
+                            double *kf_x, double *kf_P, const ofk_fusion *f, int variant, int use_feas, double feas_T, double *records,
+                            double *fused, int batch)
+{
+    fuse_args g;
+    g.prev_pts = prev_pts; g.next_pts = next_pts; g.status = status; g.counts = counts; g.pts_stride = pts_stride; g.sensors = sensors;
+    g.imu_state = imu_state; g.imu_dv = imu_dv; g.ns = ns; g.nm = nm; g.nc = nc;
+    g.F = kf_mats; g.Bm = kf_mats + 36; g.H = kf_mats + 72; g.Q = kf_mats + 108; g.Rm = kf_mats + 144; g.kf_x = kf_x; g.kf_P = kf_P;
+    g.f = *f; g.variant = variant; g.use_feas = use_feas; g.feas_T = feas_T; g.records = records; g.fused = fused;
+    hipLaunchKernelGGL(k_stream_fuse, dim3(batch), dim3(256), 0, s, g);
 }
 
 // ------------------------------------------------------------------------------------------------ Monte-Carlo error simulation

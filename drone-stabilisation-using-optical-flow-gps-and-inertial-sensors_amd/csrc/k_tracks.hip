@@ -86,3 +86,22 @@ void ofk_launch_update_tracks(hipStream_t s, const float *next_pts, const uint8_
     hipLaunchKernelGGL(k_update_tracks, dim3(batch), dim3(256), 0, s, next_pts, status, counts_in, pts_stride, new_pts, new_counts, tracks,
                        counts_out, max_total);
 }
+
+// of_module.py:83-86: a stream that was left with <= min_feat tracks REPLACES them by a fresh detection (maxCorners = max_feat -
+// count, no mask) on its previous frame.  One block per stream; streams whose budget (limit) is 0 keep their tracks.
+__global__ __launch_bounds__(256) void k_replace_tracks(const int *__restrict__ limit, const float *__restrict__ new_pts,
+                                                        const int *__restrict__ new_counts, int pts_stride, float *__restrict__ tracks,
+                                                        int *__restrict__ counts)
+{
+    const int b = blockIdx.x;
+    if (limit[b] <= 0) return;
+    const int n = max(new_counts[b], 0);
+    for (int i = threadIdx.x; i < 2 * n; i += 256) tracks[(size_t)b * pts_stride * 2 + i] = new_pts[(size_t)b * pts_stride * 2 + i];
+    if (threadIdx.x == 0) counts[b] = n;
+}
+
+void ofk_launch_replace_tracks(hipStream_t s, const int *limit, const float *new_pts, const int *new_counts, int pts_stride, float *tracks,
+                               int *counts, int batch)
+{
+    hipLaunchKernelGGL(k_replace_tracks, dim3(batch), dim3(256), 0, s, limit, new_pts, new_counts, pts_stride, tracks, counts);
+}

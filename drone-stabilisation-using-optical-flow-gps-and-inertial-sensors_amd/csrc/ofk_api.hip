@@ -147,7 +147,8 @@ extern "C" int ofk_destroy(ofk_ctx *c)
     ofk_comm_destroy(c);
     for (int k = 0; k < 2; ++k) { if (c->bgr[k]) hipFree(c->bgr[k]); if (c->pyr[k]) hipFree(c->pyr[k]); }
     void *ptrs[] = {c->eig, c->mask, c->deriv, c->cand, c->cand_seg, c->seg_count, c->cand_count, c->maxbits, c->pts_prev, c->pts_next, c->status, c->err,
-                    c->counts, c->sensors, c->records, c->dev_flags, c->scratch, c->pts_new, c->new_counts, c->limit};
+                    c->counts, c->sensors, c->records, c->dev_flags, c->scratch, c->pts_new, c->new_counts, c->limit,
+                    c->imu_state, c->imu_dv, c->kf_mats, c->kf_x, c->kf_P, c->fused, c->imu_msgs, c->imu_counts};
     for (void *p : ptrs) if (p) hipFree(p);
     if (c->hstage) hipHostFree(c->hstage);
     if (c->ev) { for (int i = 0; i < c->ev_cap; ++i) if (c->ev[i]) hipEventDestroy(c->ev[i]); free(c->ev); }
@@ -1063,27 +1064,141 @@ extern "C" int ofk_stream_begin_jpeg(ofk_ctx *c, const uint8_t *const *jpeg, con
 }
 
 // next_bgr == NULL: the new frames are in bgr[1] already (ofk_stream_step_jpeg)
-static int stream_step_impl(ofk_ctx *c, const uint8_t *next_bgr, const double *sensors, const ofk_params *p, int min_features,
-                            int mask_radius, double *records, float *tracks, int *counts)
+static int filters_alloc(ofk_ctx *c)
+{
+    const size_t B = (size_t)c->max_batch;
+    if (!c->imu_state) {
+        OFK_HIP(c, hipMalloc((void **)&c->imu_state, B * OFK_IMU_STATE * 8)); OFK_HIP(c, hipMalloc((void **)&c->imu_dv, B * 24));
+        OFK_HIP(c, hipMalloc((void **)&c->kf_mats, 5 * 36 * 8)); OFK_HIP(c, hipMalloc((void **)&c->kf_x, B * 6 * 8));
+        OFK_HIP(c, hipMalloc((void **)&c->kf_P, B * 36 * 8)); OFK_HIP(c, hipMalloc((void **)&c->fused, B * 8 * 8));
+        OFK_HIP(c, hipMemsetAsync(c->imu_dv, 0, B * 24, c->stream)); OFK_HIP(c, hipMemsetAsync(c->fused, 0, B * 64, c->stream));
+        OFK_HIP(c, hipMemsetAsync(c->kf_mats, 0, 5 * 36 * 8, c->stream));
+        // the node's initial state (node:182-217): vel 0.1, first message pending, rotation I, normal e_z
+        double init[OFK_IMU_STATE] = {0.1, 0.1, 0.1, 0, 0, 1, 1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 1, 0, 0, 0, 0, 0, 0};
+        for (size_t b = 0; b < B; ++b) OFK_HIP(c, hipMemcpyAsync(c->imu_state + b * OFK_IMU_STATE, init, sizeof init, hipMemcpyHostToDevice, c->stream));
+        OFK_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    return OFK_OK;
+}
+
+extern "C" int ofk_imu_reset(ofk_ctx *c, const double *state0, int batch)
+{
+    if (!c || batch < 1 || batch > c->max_batch) return ofk_fail(c, OFK_E_INVALID, "ofk_imu_reset: bad argument");
+    OFK_HIP(c, hipSetDevice(c->device));
+    TRY(join_slices(c));
+    TRY(filters_alloc(c));
+    double init[OFK_IMU_STATE] = {0.1, 0.1, 0.1, 0, 0, 1, 1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 1, 0, 0, 0, 0, 0, 0};
+    const double *src = state0 ? state0 : init;
+    for (int b = 0; b < batch; ++b) OFK_HIP(c, hipMemcpyAsync(c->imu_state + (size_t)b * OFK_IMU_STATE, src, sizeof init, hipMemcpyHostToDevice, c->stream));
+    OFK_HIP(c, hipMemsetAsync(c->imu_dv, 0, (size_t)batch * 24, c->stream));
+    OFK_HIP(c, hipStreamSynchronize(c->stream));
+    return OFK_OK;
+}
+
+extern "C" int ofk_imu_push(ofk_ctx *c, const double *msgs, const int *counts, int max_msgs, int batch)
+{
+    if (!c || !msgs || !counts || max_msgs < 1 || batch < 1 || batch > c->max_batch) return ofk_fail(c, OFK_E_INVALID, "ofk_imu_push: bad argument");
+    OFK_HIP(c, hipSetDevice(c->device));
+    TRY(join_slices(c));
+    TRY(filters_alloc(c));
+    const size_t mb = (size_t)batch * max_msgs * OFK_IMU_MSG * 8;
+    if (mb > c->imu_msgs_bytes) {
+        if (c->imu_msgs) { OFK_HIP(c, hipStreamSynchronize(c->stream)); hipFree(c->imu_msgs); c->imu_msgs = nullptr; c->imu_msgs_bytes = 0; }
+        OFK_HIP(c, hipMalloc((void **)&c->imu_msgs, mb));
+        c->imu_msgs_bytes = mb;
+    }
+    if (!c->imu_counts) OFK_HIP(c, hipMalloc((void **)&c->imu_counts, (size_t)c->max_batch * 4));
+    OFK_HIP(c, hipMemcpyAsync(c->imu_msgs, msgs, mb, hipMemcpyHostToDevice, c->stream));
+    OFK_HIP(c, hipMemcpyAsync(c->imu_counts, counts, (size_t)batch * 4, hipMemcpyHostToDevice, c->stream));
+    ofk_launch_imu_seq(c->stream, c->imu_state, c->imu_dv, c->imu_msgs, c->imu_counts, max_msgs, batch);
+    TRY(check_launch(c, "k_imu_seq"));
+    OFK_HIP(c, hipStreamSynchronize(c->stream));                  // the host buffers are the caller's again
+    return OFK_OK;
+}
+
+extern "C" int ofk_imu_state(ofk_ctx *c, double *state, double *dv, int batch)
+{
+    if (!c || !state || batch < 1 || batch > c->max_batch) return ofk_fail(c, OFK_E_INVALID, "ofk_imu_state: bad argument");
+    OFK_HIP(c, hipSetDevice(c->device));
+    TRY(join_slices(c));
+    TRY(filters_alloc(c));
+    if (dv) OFK_HIP(c, hipMemcpyAsync(dv, c->imu_dv, (size_t)batch * 24, hipMemcpyDeviceToHost, c->stream));
+    return get(c, state, c->imu_state, (size_t)batch * OFK_IMU_STATE * 8);
+}
+
+extern "C" int ofk_filter_configure(ofk_ctx *c, int ns, int nm, int nc, const double *F, const double *Bm, const double *H, const double *Q,
+                                    const double *Rm, const double *x0, const double *P0, int batch)
+{
+    if (!c || ns < 1 || ns > 6 || nm < 1 || nm > 6 || nc < 0 || nc > 6 || !F || !H || !Q || !Rm || !x0 || !P0 || (nc && !Bm) || batch < 1 ||
+        batch > c->max_batch)
+        return ofk_fail(c, OFK_E_INVALID, "ofk_filter_configure: bad argument");
+    OFK_HIP(c, hipSetDevice(c->device));
+    TRY(join_slices(c));
+    TRY(filters_alloc(c));
+    double mats[5 * 36] = {0};
+    memcpy(mats, F, (size_t)ns * ns * 8); if (nc) memcpy(mats + 36, Bm, (size_t)ns * nc * 8);
+    memcpy(mats + 72, H, (size_t)nm * ns * 8); memcpy(mats + 108, Q, (size_t)ns * ns * 8); memcpy(mats + 144, Rm, (size_t)nm * nm * 8);
+    OFK_HIP(c, hipMemcpyAsync(c->kf_mats, mats, sizeof mats, hipMemcpyHostToDevice, c->stream));
+    for (int b = 0; b < batch; ++b) {
+        OFK_HIP(c, hipMemcpyAsync(c->kf_x + (size_t)b * ns, x0, (size_t)ns * 8, hipMemcpyHostToDevice, c->stream));
+        OFK_HIP(c, hipMemcpyAsync(c->kf_P + (size_t)b * ns * ns, P0, (size_t)ns * ns * 8, hipMemcpyHostToDevice, c->stream));
+    }
+    OFK_HIP(c, hipStreamSynchronize(c->stream));
+    c->kf_ns = ns; c->kf_nm = nm; c->kf_nc = nc;
+    return OFK_OK;
+}
+
+extern "C" int ofk_filter_state(ofk_ctx *c, double *x, double *P, int batch)
+{
+    if (!c || !x || !P || batch < 1 || batch > c->max_batch || c->kf_ns < 1) return ofk_fail(c, OFK_E_INVALID, "ofk_filter_state: no filter configured / bad argument");
+    OFK_HIP(c, hipSetDevice(c->device));
+    TRY(join_slices(c));
+    OFK_HIP(c, hipMemcpyAsync(x, c->kf_x, (size_t)batch * c->kf_ns * 8, hipMemcpyDeviceToHost, c->stream));
+    return get(c, P, c->kf_P, (size_t)batch * c->kf_ns * c->kf_ns * 8);
+}
+
+// fu == NULL: the plain step (status filter, node-style solve, no resident filters)
+static int stream_step_impl(ofk_ctx *c, const uint8_t *next_bgr, const double *sensors, const ofk_params *p, const ofk_fusion *fu,
+                            int min_features, int mask_radius, double *records, double *fused, float *tracks, int *counts)
 {
     const int B = c->stream_batch, h = c->stream_h, w = c->stream_w;
     TRY(check_block(c, h, w, p->block_size));
     TRY(check_select(c, p->max_corners, p->quality, p->min_distance));
     TRY(check_lk(c, h, w, p->win, p->max_level));
     if (mask_radius < 0 || mask_radius > 255) return ofk_fail(c, OFK_E_INVALID, "mask_radius outside 0..255");
-    if (p->solve_variant != OFK_SOLVE_NODE && p->solve_variant != OFK_SOLVE_SIM) return ofk_fail(c, OFK_E_INVALID, "solve_variant must be NODE or SIM");
+    if (fu) {
+        if (p->solve_variant < OFK_SOLVE_NODE || p->solve_variant > OFK_SOLVE_OFMODULE) return ofk_fail(c, OFK_E_INVALID, "solve_variant must be NODE, SIM or OFMODULE");
+        if (p->solve_variant == OFK_SOLVE_OFMODULE && fu->keep != OFK_KEEP_LEGACY)
+            return ofk_fail(c, OFK_E_INVALID, "OFK_SOLVE_OFMODULE weights its rows with the legacy r_tilde distances: it needs keep = OFK_KEEP_LEGACY");
+        if (fu->filter && c->kf_ns < 1) return ofk_fail(c, OFK_E_INVALID, "ofk_stream_step_fused: filter requested but ofk_filter_configure was not called");
+        if (fu->flow < 0 || fu->flow > 1 || fu->keep < 0 || fu->keep > 1 || fu->control < 0 || fu->control > 1 || fu->min_solve < 0)
+            return ofk_fail(c, OFK_E_INVALID, "ofk_stream_step_fused: bad ofk_fusion field");
+        TRY(filters_alloc(c));
+    } else if (p->solve_variant != OFK_SOLVE_NODE && p->solve_variant != OFK_SOLVE_SIM) return ofk_fail(c, OFK_E_INVALID, "solve_variant must be NODE or SIM");
     const ofk_levels lv = ofk_make_levels(h, w, p->win, p->max_level);
     OFK_HIP(c, hipMemcpyAsync(c->sensors, sensors, (size_t)B * OFK_SENSOR_DOUBLES * 8, hipMemcpyHostToDevice, c->stream));
+    bool few = false;                                            // the host knows the track counts from the previous call
+    for (int b = 0; b < B; ++b) few = few || (c->h_counts && c->h_counts[b] <= min_features);
+    if (fu && fu->redetect_replace && few) {
+        // of_module.py:83-86: before tracking, streams with few tracks replace them by fresh corners of the PREVIOUS frame (no mask)
+        ofk_launch_redetect_limits(c->stream, c->counts, min_features, p->max_corners, c->limit, B);
+        TRY(stream_detect(c, 0, nullptr, c->limit, B, h, w, p, c->pts_new, c->new_counts));
+        ofk_launch_replace_tracks(c->stream, c->limit, c->pts_new, c->new_counts, c->max_pts, c->pts_prev, c->counts, B);
+    }
     TRY(stream_ingest(c, 1, next_bgr, B, h, w, lv));
     // track (node:133), solve on the tracked points (node:229-258)
     ofk_launch_lk(c->stream, c->pyr[0], c->pyr[1], c->pyr_stride, lv, c->pts_prev, c->counts, c->max_pts, p->win, p->max_count, p->eps,
                   p->min_eig_thr, c->pts_next, c->status, c->err, B);
-    ofk_launch_pairs_solve(c->stream, c->pts_prev, c->pts_next, c->status, c->counts, c->max_pts, c->sensors, p->solve_variant,
-                           p->use_feasibility, p->feas_T, nullptr, c->records, B);
+    if (fu)
+        ofk_launch_stream_fuse(c->stream, c->pts_prev, c->pts_next, c->status, c->counts, c->max_pts, c->sensors, c->imu_state, c->imu_dv,
+                               c->kf_ns, c->kf_nm, c->kf_nc, c->kf_mats, c->kf_x, c->kf_P, fu, p->solve_variant, p->use_feasibility, p->feas_T,
+                               c->records, c->fused, B);
+    else
+        ofk_launch_pairs_solve(c->stream, c->pts_prev, c->pts_next, c->status, c->counts, c->max_pts, c->sensors, p->solve_variant,
+                               p->use_feasibility, p->feas_T, nullptr, c->records, B);
     // re-detection for the streams that had few features (node:157-166): mask = discs around the OLD positions, image = OLD frame.
     // The host knows the track counts from the previous call, so the whole branch is skipped when no stream needs it.
-    bool any = false;
-    for (int b = 0; b < B; ++b) any = any || (c->h_counts && c->h_counts[b] <= min_features);
+    const bool any = few && !(fu && fu->redetect_replace);
     if (any) {
         ofk_launch_redetect_limits(c->stream, c->counts, min_features, p->max_corners, c->limit, B);
         OFK_HIP(c, hipMemsetAsync(c->mask, 1, (size_t)B * c->img_stride, c->stream));
@@ -1095,6 +1210,7 @@ static int stream_step_impl(ofk_ctx *c, const uint8_t *next_bgr, const double *s
                              c->pts_prev, c->counts, p->max_corners, B);
     TRY(check_launch(c, "ofk_stream_step"));
     if (records) OFK_HIP(c, hipMemcpyAsync(records, c->records, (size_t)B * OFK_RECORD_DOUBLES * 8, hipMemcpyDeviceToHost, c->stream));
+    if (fu && fused) OFK_HIP(c, hipMemcpyAsync(fused, c->fused, (size_t)B * 64, hipMemcpyDeviceToHost, c->stream));
     // The tracks on the device already belong to the new frame (k_update_tracks), so the frame swap happens whatever the fetch
     // reports (OFK_E_CAPACITY from a re-detection, a failed copy): the next step must track against THIS frame's pyramid.
     const int rc = stream_fetch_tracks(c, B, p->max_corners, tracks, counts);
@@ -1110,7 +1226,7 @@ extern "C" int ofk_stream_step(ofk_ctx *c, const uint8_t *next_bgr, const double
     if (c->stream_batch < 1) return ofk_fail(c, OFK_E_INVALID, "ofk_stream_step: call ofk_stream_begin first");
     if (hipSetDevice(c->device) != hipSuccess) return ofk_fail(c, OFK_E_HIP, "hipSetDevice failed");
     TRY(join_slices(c));
-    return stream_step_impl(c, next_bgr, sensors, p, min_features, mask_radius, records, tracks, counts);
+    return stream_step_impl(c, next_bgr, sensors, p, nullptr, min_features, mask_radius, records, nullptr, tracks, counts);
 }
 
 extern "C" int ofk_stream_step_jpeg(ofk_ctx *c, const uint8_t *const *jpeg, const size_t *nbytes, const double *sensors, const ofk_params *p,
@@ -1124,7 +1240,32 @@ extern "C" int ofk_stream_step_jpeg(ofk_ctx *c, const uint8_t *const *jpeg, cons
     TRY(ofk_jpeg_decode_device(c, jpeg, nbytes, c->stream_batch, c->bgr[1], c->bgr_stride, c->P, &h, &w, nullptr, nullptr));
     if (h != c->stream_h || w != c->stream_w)
         return ofk_fail(c, OFK_E_INVALID, "ofk_stream_step_jpeg: frames are %dx%d, the streams were begun with %dx%d", w, h, c->stream_w, c->stream_h);
-    return stream_step_impl(c, nullptr, sensors, p, min_features, mask_radius, records, tracks, counts);
+    return stream_step_impl(c, nullptr, sensors, p, nullptr, min_features, mask_radius, records, nullptr, tracks, counts);
+}
+
+extern "C" int ofk_stream_step_fused(ofk_ctx *c, const uint8_t *next_bgr, const double *sensors, const ofk_params *p, const ofk_fusion *f,
+                                     int min_features, int mask_radius, double *records, double *fused, float *tracks, int *counts)
+{
+    if (!c || !next_bgr || !sensors || !p || !f) return ofk_fail(c, OFK_E_INVALID, "ofk_stream_step_fused: NULL argument");
+    if (c->stream_batch < 1) return ofk_fail(c, OFK_E_INVALID, "ofk_stream_step_fused: call ofk_stream_begin first");
+    if (hipSetDevice(c->device) != hipSuccess) return ofk_fail(c, OFK_E_HIP, "hipSetDevice failed");
+    TRY(join_slices(c));
+    return stream_step_impl(c, next_bgr, sensors, p, f, min_features, mask_radius, records, fused, tracks, counts);
+}
+
+extern "C" int ofk_stream_step_fused_jpeg(ofk_ctx *c, const uint8_t *const *jpeg, const size_t *nbytes, const double *sensors, const ofk_params *p,
+                                          const ofk_fusion *f, int min_features, int mask_radius, double *records, double *fused, float *tracks,
+                                          int *counts)
+{
+    if (!c || !jpeg || !nbytes || !sensors || !p || !f) return ofk_fail(c, OFK_E_INVALID, "ofk_stream_step_fused_jpeg: NULL argument");
+    if (c->stream_batch < 1) return ofk_fail(c, OFK_E_INVALID, "ofk_stream_step_fused_jpeg: call ofk_stream_begin / ofk_stream_begin_jpeg first");
+    if (hipSetDevice(c->device) != hipSuccess) return ofk_fail(c, OFK_E_HIP, "hipSetDevice failed");
+    TRY(join_slices(c));
+    int h = 0, w = 0;
+    TRY(ofk_jpeg_decode_device(c, jpeg, nbytes, c->stream_batch, c->bgr[1], c->bgr_stride, c->P, &h, &w, nullptr, nullptr));
+    if (h != c->stream_h || w != c->stream_w)
+        return ofk_fail(c, OFK_E_INVALID, "ofk_stream_step_fused_jpeg: frames are %dx%d, the streams were begun with %dx%d", w, h, c->stream_w, c->stream_h);
+    return stream_step_impl(c, nullptr, sensors, p, f, min_features, mask_radius, records, fused, tracks, counts);
 }
 
 extern "C" int ofk_set_streams(ofk_ctx *c, int nstreams)

@@ -69,6 +69,12 @@ struct ofk_ctx {
     void *scratch; size_t scratch_bytes;          // device scratch for the estimation entry points
     void *hstage; size_t hstage_bytes;            // pinned host staging
 
+    // per-stream filters resident on the device (ofk_imu_*, ofk_filter_*, ofk_stream_step_fused); lazily allocated
+    double *imu_state, *imu_dv;     // [B][OFK_IMU_STATE], [B][3]
+    double *kf_mats, *kf_x, *kf_P;  // 5 x 36 doubles (F, B, H, Q, R), [B][6], [B][36]
+    double *fused;                  // [B][8]
+    double *imu_msgs; int *imu_counts; size_t imu_msgs_bytes;     // upload staging for ofk_imu_push
+    int kf_ns, kf_nm, kf_nc;
     int cur_batch, cur_h, cur_w;    // resident pair geometry (ofk_pairs_upload)
     int prof_mask;
     hipEvent_t *ev; int ev_cap, ev_n; int *ev_stage;   // pairs of events: start/stop
@@ -139,6 +145,13 @@ void ofk_launch_solve(hipStream_t s, int variant, const double *x, const double 
                       int n, const double *d, const double *nrm, const double *omega, const double *t,
                       const double *wgt, double *out);
 void ofk_launch_imu(hipStream_t s, double *state, const double *msg, int batch);
+void ofk_launch_imu_seq(hipStream_t s, double *state, double *dv, const double *msgs, const int *counts, int max_msgs, int batch);
+void ofk_launch_stream_fuse(hipStream_t s, const float *prev_pts, const float *next_pts, uint8_t *status, const int *counts, int pts_stride,
+                            const double *sensors, double *imu_state, double *imu_dv, int ns, int nm, int nc, const double *kf_mats,
+                            double *kf_x, double *kf_P, const ofk_fusion *f, int variant, int use_feas, double feas_T, double *records,
+                            double *fused, int batch);
+void ofk_launch_replace_tracks(hipStream_t s, const int *limit, const float *new_pts, const int *new_counts, int pts_stride, float *tracks,
+                               int *counts, int batch);
 void ofk_launch_post_solve(hipStream_t s, const double *v_obs, const double *rot, const double *ang,
                            const double *offset, int batch, double *v_uav);
 void ofk_launch_kf(hipStream_t s, int ns, int nm, int nc, const double *F, const double *Bm, const double *H,

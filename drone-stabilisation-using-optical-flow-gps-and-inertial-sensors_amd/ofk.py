@@ -30,6 +30,8 @@ SYMBOLS = (
     "ofk_pairs_run", "ofk_pairs_download", "ofk_pairs_export_records_f32", "ofk_stream_begin", "ofk_stream_step",
     "ofk_stream_begin_jpeg", "ofk_stream_step_jpeg",
     "ofk_set_streams", "ofk_set_overlap", "ofk_mark", "ofk_mark_wait", "ofk_profile_enable", "ofk_profile_read",
+    "ofk_imu_reset", "ofk_imu_push", "ofk_imu_state", "ofk_filter_configure", "ofk_filter_state", "ofk_stream_step_fused",
+    "ofk_stream_step_fused_jpeg",
     "ofk_comm_unique_id", "ofk_comm_init", "ofk_comm_destroy", "ofk_comm_rank", "ofk_comm_world", "ofk_comm_gather_records",
     "ofk_comm_fetch_records", "ofk_comm_allreduce_f64",
 )
@@ -45,6 +47,18 @@ class Params(C.Structure):
     _fields_ = [("max_corners", C.c_int), ("quality", C.c_double), ("min_distance", C.c_double), ("block_size", C.c_int),
                 ("win", C.c_int), ("max_level", C.c_int), ("max_count", C.c_int), ("eps", C.c_double),
                 ("min_eig_thr", C.c_double), ("solve_variant", C.c_int), ("use_feasibility", C.c_int), ("feas_T", C.c_double)]
+
+
+FLOW_LK, FLOW_ROTATIONAL = 0, 1
+KEEP_STATUS, KEEP_LEGACY = 0, 1
+CONTROL_SENSORS, CONTROL_IMU = 0, 1
+
+
+class Fusion(C.Structure):
+    """ofk_fusion (include/ofk.h): what ofk_stream_step_fused does between LK and the next frame."""
+    _fields_ = [("use_imu", C.c_int), ("flow", C.c_int), ("keep", C.c_int), ("filter", C.c_int), ("control", C.c_int),
+                ("z_sign", C.c_double), ("z_source", C.c_int), ("vel_overwrite", C.c_int), ("redetect_replace", C.c_int),
+                ("min_solve", C.c_int)]
 
 
 _lib = None
@@ -114,6 +128,10 @@ def load_library():
         L.ofk_stream_step.argtypes = [vp, vp, vp, C.POINTER(Params), i, i, vp, vp, vp]
         L.ofk_stream_begin_jpeg.argtypes = [vp, vp, vp, i, C.POINTER(Params), vp, vp]
         L.ofk_stream_step_jpeg.argtypes = [vp, vp, vp, vp, C.POINTER(Params), i, i, vp, vp, vp]
+        L.ofk_imu_reset.argtypes = [vp, vp, i]; L.ofk_imu_push.argtypes = [vp, vp, vp, i, i]; L.ofk_imu_state.argtypes = [vp, vp, vp, i]
+        L.ofk_filter_configure.argtypes = [vp, i, i, i, vp, vp, vp, vp, vp, vp, vp, i]; L.ofk_filter_state.argtypes = [vp, vp, vp, i]
+        L.ofk_stream_step_fused.argtypes = [vp, vp, vp, C.POINTER(Params), C.POINTER(Fusion), i, i, vp, vp, vp, vp]
+        L.ofk_stream_step_fused_jpeg.argtypes = [vp, vp, vp, vp, C.POINTER(Params), C.POINTER(Fusion), i, i, vp, vp, vp, vp]
         L.ofk_set_streams.argtypes = [vp, i]
         L.ofk_set_overlap.argtypes = [vp, i]
         L.ofk_mark.argtypes = [vp, i]; L.ofk_mark_wait.argtypes = [vp, i]
@@ -610,6 +628,70 @@ class Context:
             self._ck(self._L.ofk_stream_step_jpeg(self._h, ptrs, sizes, _p(sensors), C.byref(params), int(min_features), int(mask_radius),
                                                   _p(rec), _p(tracks), _p(counts)))
         return rec, tracks, counts
+
+    # ------------------------------------------------------------------ resident per-stream filters + fused step
+    def imu_reset(self, batch, state0=None):
+        st = None if state0 is None else _arr(state0, np.float64, (IMU_STATE,))
+        with self._lock:
+            self._ck(self._L.ofk_imu_reset(self._h, _p(st), int(batch)))
+
+    def imu_push(self, msgs, counts=None):
+        """msgs [B, M, 15] (or [B, 15] for one message per stream); counts [B] (default: M each)."""
+        m = _arr(msgs, np.float64)
+        if m.ndim == 2:
+            m = m[:, None, :]
+        B, M, k = m.shape
+        if k != IMU_MSG:
+            raise ValueError(f"an IMU message has {IMU_MSG} fields")
+        cn = np.full(B, M, np.int32) if counts is None else _arr(counts, np.int32, (B,))
+        m = np.ascontiguousarray(m)
+        with self._lock:
+            self._ck(self._L.ofk_imu_push(self._h, _p(m), _p(cn), M, B))
+
+    def imu_state(self, batch):
+        st = np.empty((batch, IMU_STATE), np.float64); dv = np.empty((batch, 3), np.float64)
+        with self._lock:
+            self._ck(self._L.ofk_imu_state(self._h, _p(st), _p(dv), int(batch)))
+        return st, dv
+
+    def filter_configure(self, model, batch):
+        """model: pipeline.FilterModel (F, B, H, Q, R, x0, P0)."""
+        ns, nm, nc = model.ns, model.nm, model.nc
+        F = _arr(model.F, np.float64, (ns, ns)); H = _arr(model.H, np.float64, (nm, ns)); Q = _arr(model.Q, np.float64, (ns, ns))
+        R = _arr(model.R, np.float64, (nm, nm)); Bm = _arr(model.B, np.float64, (ns, nc)) if nc else None
+        x0 = _arr(model.x0, np.float64, (ns,)); P0 = _arr(model.P0, np.float64, (ns, ns))
+        with self._lock:
+            self._ck(self._L.ofk_filter_configure(self._h, ns, nm, nc, _p(F), _p(Bm), _p(H), _p(Q), _p(R), _p(x0), _p(P0), int(batch)))
+        self._kf_ns = ns
+
+    def filter_state(self, batch):
+        ns = self._kf_ns
+        x = np.empty((batch, ns), np.float64); P = np.empty((batch, ns, ns), np.float64)
+        with self._lock:
+            self._ck(self._L.ofk_filter_state(self._h, _p(x), _p(P), int(batch)))
+        return x, P
+
+    def stream_step_fused(self, next_bgr, sensors, params, fusion, min_features, mask_radius):
+        """ofk_stream_step_fused: returns (records [B,16], fused [B,8], tracks [B,mc,2], counts [B])."""
+        B, h, w = self._stream
+        sensors = _arr(sensors, np.float64).reshape(B, SENSOR_DOUBLES)
+        mc = int(params.max_corners)
+        rec = np.zeros((B, RECORD_DOUBLES), np.float64); fused = np.zeros((B, 8), np.float64)
+        tracks = np.zeros((B, mc, 2), np.float32); counts = np.zeros(B, np.int32)
+        if isinstance(next_bgr, (list, tuple)) and isinstance(next_bgr[0], (bytes, bytearray, memoryview)):
+            if len(next_bgr) != B:
+                raise ValueError(f"expected {B} JPEG streams")
+            keep, ptrs, sizes = self._jpeg_args(next_bgr)
+            with self._lock:
+                self._ck(self._L.ofk_stream_step_fused_jpeg(self._h, ptrs, sizes, _p(sensors), C.byref(params), C.byref(fusion), int(min_features),
+                                                            int(mask_radius), _p(rec), _p(fused), _p(tracks), _p(counts)))
+        else:
+            frames, _ = self._batched(next_bgr, 3)
+            frames = _arr(frames, np.uint8, (B, h, w, 3))
+            with self._lock:
+                self._ck(self._L.ofk_stream_step_fused(self._h, _p(frames), _p(sensors), C.byref(params), C.byref(fusion), int(min_features),
+                                                       int(mask_radius), _p(rec), _p(fused), _p(tracks), _p(counts)))
+        return rec, fused, tracks, counts
 
     # ------------------------------------------------------------------ multi-GPU exchange (RCCL through the library, no torch)
     def comm_init(self, unique_id, rank, world):

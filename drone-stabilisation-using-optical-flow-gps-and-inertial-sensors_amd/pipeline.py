@@ -36,8 +36,9 @@ class PipelineConfig:
         return cls(max_corners=100, quality=0.7, min_distance=10, block_size=12, win=15, max_level=3, max_count=20, eps=0.03)
 
     @classmethod
-    def of_module(cls):          # optical_flow_experiments/of_module.py:12-23
-        return cls(max_corners=50, quality=0.3, min_distance=20, block_size=32, win=15, max_level=3, max_count=10, eps=0.5)
+    def of_module(cls):          # optical_flow_experiments/of_module.py:12-23, T = 0.9 (:55), the inline [p]x / dist_i system (:136-146)
+        return cls(max_corners=50, quality=0.3, min_distance=20, block_size=32, win=15, max_level=3, max_count=10, eps=0.5,
+                   solve_variant=ofk.SOLVE_OFMODULE, feas_T=0.9)
 
     @classmethod
     def evaluate_exp(cls):       # flight_experiments/evaluate_exp.py:37-48
@@ -106,6 +107,50 @@ class FilterModel:
         return cls(F=F, B=Bm, H=H, Q=np.diag([q_v] * 3 + [q_b] * 3), R=R, P0=p0 * np.eye(6), x0=np.zeros(6))
 
 
+@dataclass
+class FusionConfig:
+    """What FlowStream.step_fused does between LK and the next frame (ofk_fusion, include/ofk.h)."""
+    use_imu: bool = False
+    flow: int = ofk.FLOW_LK
+    keep: int = ofk.KEEP_STATUS
+    filter: bool = False
+    control: int = ofk.CONTROL_SENSORS
+    z_sign: float = 1.0
+    z_source: int = 0
+    vel_overwrite: bool = False
+    redetect_replace: bool = False
+    min_solve: int = 2
+    model: "FilterModel" = None
+
+    @classmethod
+    def of_module(cls, synthetic_flow=True):
+        """The loop of optical_flow_experiments/of_module.py:78-167: kalman.predict(control) -> legacy r_tilde with the predicted
+        velocity, keep r - (status - 1) >= T -> A_i = [p]x / dist_i system -> kalman.correct(-v_obs); tracks := kept points;
+        <= 10 tracks: replace by fresh corners.  synthetic_flow reproduces :113-114 (the measured flow overwritten by the
+        rotational field of a random omega); False keeps the LK flow the script's TODO asks for.
+        Use with PipelineConfig.of_module() (feas_T = 0.9, solve_variant = OFMODULE) and sensors cx, cy = of.pix_trans((480, 640)),
+        scaling = 1 (the script works in pixels, :96-102)."""
+        return cls(flow=ofk.FLOW_ROTATIONAL if synthetic_flow else ofk.FLOW_LK, keep=ofk.KEEP_LEGACY, filter=True, control=ofk.CONTROL_SENSORS,
+                   z_sign=-1.0, z_source=0, redetect_replace=True, min_solve=3, model=FilterModel.kf3())
+
+    @classmethod
+    def node(cls):
+        """velocity_measurment_node: IMU dead-reckoning between optical fixes (node:61-89), r_tilde filter with the dead-reckoned
+        velocity (:238-245), solve (:257), self.vel = v_uav (:261).  No Kalman filter (the reference node has none)."""
+        return cls(use_imu=True, keep=ofk.KEEP_STATUS, filter=False, vel_overwrite=True, min_solve=2)
+
+    @classmethod
+    def ekf6(cls, dt=1.0 / 30.0, gps=False, **kw):
+        """BASELINE configs[2]/[3]'s "6-state EKF": the node's loop with the build-defined filter FilterModel.ekf6 in place of the
+        hard overwrite: predict with the IMU's velocity increments since the last frame, correct with +v_uav (world frame)."""
+        return cls(use_imu=True, keep=ofk.KEEP_STATUS, filter=True, control=ofk.CONTROL_IMU, z_sign=1.0, z_source=1, vel_overwrite=False,
+                   min_solve=2, model=FilterModel.ekf6(dt=dt, gps=gps, **kw))
+
+    def to_struct(self):
+        return ofk.Fusion(1 if self.use_imu else 0, int(self.flow), int(self.keep), 1 if self.filter else 0, int(self.control), float(self.z_sign),
+                          int(self.z_source), 1 if self.vel_overwrite else 0, 1 if self.redetect_replace else 0, int(self.min_solve))
+
+
 class FlowStream:
     """`batch` independent video streams with persistent tracks on the device: the loop of velocity_measurment_node:92-177
     (commented-out blocks restored) / of_module.py:78-167 / evaluate_exp.py:77-121, one frame per `step`.
@@ -115,12 +160,29 @@ class FlowStream:
         records, tracks, counts = fs.step(frames, sensors)      # LK, velocity, status filter, re-detection, frame swap
     """
 
-    def __init__(self, width, height, batch=1, cfg=None, device=0, min_features=20, mask_radius=30):
+    def __init__(self, width, height, batch=1, cfg=None, device=0, min_features=20, mask_radius=30, fusion=None):
         self.cfg = cfg or PipelineConfig.node()
         self.batch = batch
         self.min_features, self.mask_radius = int(min_features), int(mask_radius)
         self.ctx = ofk.Context(device, width, height, batch, max(1, self.cfg.max_corners), max(0, self.cfg.max_level))
         self._params = self.cfg.to_params()
+        self.fusion = fusion
+        if fusion is not None:                                  # the per-stream filter state lives on the device from here on
+            self._fusion = fusion.to_struct()
+            self.ctx.imu_reset(batch)
+            if fusion.filter:
+                self.ctx.filter_configure(fusion.model or FilterModel.kf3(), batch)
+
+    def push_imu(self, msgs, counts=None):
+        """The IMU messages received since the last frame ([B, M, 15], layout ofk.h OFK_IMU_MSG), applied to the resident state."""
+        self.ctx.imu_push(msgs, counts)
+
+    def step_fused(self, next_frames, sensors):
+        """One frame with the filters in the loop (ofk_stream_step_fused): BGR frames [B,h,w,3] or a list of B JPEG streams.
+        Returns (records, fused [B,8] = filter state x[0..5], trace P, solved, tracks, counts)."""
+        if self.fusion is None:
+            raise ValueError("construct FlowStream(..., fusion=FusionConfig...) for step_fused")
+        return self.ctx.stream_step_fused(next_frames, sensors, self._params, self._fusion, self.min_features, self.mask_radius)
 
     def begin(self, first_bgr):
         return self.ctx.stream_begin(first_bgr, self._params)

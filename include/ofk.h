@@ -206,14 +206,15 @@ typedef struct ofk_params {
     int    max_count;        /* LK criteria COUNT */
     double eps;              /* LK criteria EPS */
     double min_eig_thr;      /* LK minEigThreshold (1e-4) */
-    int    solve_variant;    /* OFK_SOLVE_NODE / OFK_SOLVE_SIM */
+    int    solve_variant;    /* OFK_SOLVE_NODE / OFK_SOLVE_SIM (ofk_pairs_run, ofk_stream_step); also OFK_SOLVE_OFMODULE in ofk_stream_step_fused */
     int    use_feasibility;  /* 1: keep points with r_tilde <= feas_T (node:238-245) using sensors' prior velocity */
     double feas_T;
 } ofk_params;
 
 /* Per-pair sensor record, [batch][OFK_SENSOR_DOUBLES] doubles:
  * 0 d (plane distance)  1-3 normal  4-6 omega  7-15 rotation (row-major)  16-18 offset (lever arm, node:204)
- * 19 scaling (node:182)  20 cx  21 cy (of.pix_trans, node:229)  22-24 prior velocity (feasibility)  25-27 reserved */
+ * 19 scaling (node:182)  20 cx  21 cy (of.pix_trans, node:229)  22-24 prior velocity (feasibility; second measurement of a
+ * 6-row filter)  25-27 filter control input (ofk_stream_step_fused, OFK_CONTROL_SENSORS) */
 #define OFK_SENSOR_DOUBLES 28
 /* Per-pair result record, [batch][OFK_RECORD_DOUBLES] doubles:
  * 0-2 v_obs  3 residual SS  4 rank  5-7 singular values  8-10 v_uav (node:258)  11 points used in the solve
@@ -263,6 +264,57 @@ int ofk_stream_begin_jpeg(ofk_ctx *ctx, const uint8_t *const *jpeg, const size_t
                           int *counts);
 int ofk_stream_step_jpeg(ofk_ctx *ctx, const uint8_t *const *jpeg, const size_t *nbytes, const double *sensors, const ofk_params *p,
                          int min_features, int mask_radius, double *records, float *tracks, int *counts);
+
+/* ---- the per-stream filters, resident on the device ("the only cross-pair state is the per-stream filter,
+ * which stays on the GPU that owns the stream")
+ * IMU dead-reckoning state (velocity_measurment_node:61-89), layout OFK_IMU_STATE as in ofk_imu_propagate:
+ *   ofk_imu_reset   state of `batch` streams := state0 [OFK_IMU_STATE] (NULL: the node's initial values, node:182-217:
+ *                   vel = 0.1, rotation = I, normal = e_z, first message pending)
+ *   ofk_imu_push    the messages each stream received since its last frame, applied in order (k_imu_seq): msgs
+ *                   [batch][max_msgs][OFK_IMU_MSG], counts [batch]; also accumulates the velocity increments (the filter's control)
+ *   ofk_imu_state   download: state [batch][OFK_IMU_STATE], dv (nullable) [batch][3] = increments not yet consumed by a step
+ * Kalman filter (cv2.KalmanFilter of of_module.py:63-76; ns, nm <= 6, nc <= 6; row-major matrices shared by the streams):
+ *   ofk_filter_configure  matrices + every stream's state := x0 [ns], P0 [ns][ns]
+ *   ofk_filter_state      download x [batch][ns], P [batch][ns][ns] */
+int ofk_imu_reset(ofk_ctx *ctx, const double *state0, int batch);
+int ofk_imu_push(ofk_ctx *ctx, const double *msgs, const int *counts, int max_msgs, int batch);
+int ofk_imu_state(ofk_ctx *ctx, double *state, double *dv, int batch);
+int ofk_filter_configure(ofk_ctx *ctx, int ns, int nm, int nc, const double *F, const double *Bm, const double *H, const double *Q,
+                         const double *Rm, const double *x0, const double *P0, int batch);
+int ofk_filter_state(ofk_ctx *ctx, double *x, double *P, int batch);
+
+/* What happens between calcOpticalFlowPyrLK and the next frame (ofk_stream_step_fused). */
+#define OFK_FLOW_LK          0   /* u = new - old (node:235; of_module.py:108) */
+#define OFK_FLOW_ROTATIONAL  1   /* of_module.py:113-114: the flow is overwritten by the rotational field of the sensors' omega */
+#define OFK_KEEP_STATUS      0   /* status == 1, and r_tilde <= feas_T when p->use_feasibility (node:238-245) */
+#define OFK_KEEP_LEGACY      1   /* legacy 4-arg r_tilde with the filter's predicted velocity, keep r - (status - 1) >= feas_T (of_module.py:125-131) */
+#define OFK_CONTROL_SENSORS  0   /* filter control = sensors[25..27] (of_module.py:122 draws it at random) */
+#define OFK_CONTROL_IMU      1   /* filter control = velocity increments accumulated by ofk_imu_push since the last step */
+typedef struct ofk_fusion {
+    int    use_imu;          /* 1: normal, omega, rotation and the prior velocity come from the resident IMU state, not from `sensors` */
+    int    flow;             /* OFK_FLOW_* */
+    int    keep;             /* OFK_KEEP_*; the kept points become the stream's tracks (of_module.py:166) */
+    int    filter;           /* 1: resident Kalman filter: predict(control) before the feasibility test, correct() after the solve */
+    int    control;          /* OFK_CONTROL_* */
+    double z_sign;           /* measurement = z_sign * velocity (of_module.py:152 corrects with -v_obs) */
+    int    z_source;         /* 0: v_obs, 1: v_uav (lever arm + rotation applied, node:258) */
+    int    vel_overwrite;    /* 1: the IMU state's velocity := v_uav after a solve (node:261) */
+    int    redetect_replace; /* 1: streams with <= min_features tracks REPLACE them by maxCorners - count fresh corners of the previous
+                                frame, no mask, before tracking (of_module.py:83-86); 0: append with a disc mask after tracking (node:157-166) */
+    int    min_solve;        /* solve only with MORE than this many kept points (of_module.py:138: 3; node:256: 2) */
+} ofk_fusion;
+/* ofk_stream_step with the filters in the loop: (redetect_replace) -> gray + pyramid of the new frames -> LK -> k_stream_fuse
+ * (centre/scale, flow, filter predict, feasibility, solve with p->solve_variant incl. OFK_SOLVE_OFMODULE, lever arm + rotation,
+ * filter correct, velocity overwrite) -> tracks := kept points -> (masked re-detection) -> frame swap.  records as in
+ * ofk_stream_step (slot 15: 1 if the system was solved); fused [batch][8] = filter state x[0..5] (zero padded), trace(P), solved —
+ * without a filter: v_uav (or the dead-reckoned velocity when nothing was solved).  Deviation from of_module.py:138, which
+ * `continue`s on <= 3 feasible points WITHOUT advancing the frame: a batch of streams shares one frame swap, so the frame always
+ * advances; the filter then keeps its prediction and the record reports rank 0. */
+int ofk_stream_step_fused(ofk_ctx *ctx, const uint8_t *next_bgr, const double *sensors, const ofk_params *p, const ofk_fusion *f,
+                          int min_features, int mask_radius, double *records, double *fused, float *tracks, int *counts);
+int ofk_stream_step_fused_jpeg(ofk_ctx *ctx, const uint8_t *const *jpeg, const size_t *nbytes, const double *sensors, const ofk_params *p,
+                               const ofk_fusion *f, int min_features, int mask_radius, double *records, double *fused, float *tracks,
+                               int *counts);
 
 /* ---- compressed-image ingest (cv2.imdecode of the reference's CompressedImage callback, velocity_measurment_node.py:112) ----
  * ofk_jpeg_info: header fields of a JPEG stream (host only; no context, no GPU).  OFK_E_INVALID if the stream is not one the decoder
