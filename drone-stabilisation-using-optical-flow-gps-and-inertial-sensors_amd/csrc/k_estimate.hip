@@ -530,6 +530,33 @@ __global__ void k_kf(int ns, int nm, int nc, const double *__restrict__ F, const
     for (int i = 0; i < ns; ++i) { xs[(size_t)b * ns + i] = x[i]; for (int j = 0; j < ns; ++j) Ps[((size_t)b * ns + i) * ns + j] = P[i][j]; }
 }
 
+// The per-pair filter of a resident batch (BASELINE configs[2]: "batch of independent frame pairs + per-frame EKF update"): one
+// thread per pair, predict (no control) + correct with z = z_sign * (v_obs | v_uav) read from the pair's record; state resident.
+__global__ void k_kf_records(int ns, int nm, const double *__restrict__ mats, double *__restrict__ xs, double *__restrict__ Ps,
+                             const double *__restrict__ records, double z_sign, int z_source, int batch)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    const double *F = mats, *H = mats + 72, *Q = mats + 108, *Rm = mats + 144;
+    double x[KF_MAX], P[KF_MAX][KF_MAX];
+    for (int i = 0; i < ns; ++i) { x[i] = xs[(size_t)b * ns + i]; for (int j = 0; j < ns; ++j) P[i][j] = Ps[((size_t)b * ns + i) * ns + j]; }
+    kf_predict_dev(ns, 0, F, nullptr, Q, nullptr, x, P);
+    const double *r = records + (size_t)b * OFK_RECORD_DOUBLES;
+    if (r[4] == 3.0) {                                          // a full-rank solve: there is a measurement
+        double z[KF_MAX] = {0, 0, 0, 0, 0, 0};
+        for (int k = 0; k < 3; ++k) z[k] = z_sign * r[(z_source ? 8 : 0) + k];
+        for (int k = 3; k < nm; ++k) z[k] = z[k - 3];
+        kf_correct_dev(ns, nm, H, Rm, z, x, P);
+    }
+    for (int i = 0; i < ns; ++i) { xs[(size_t)b * ns + i] = x[i]; for (int j = 0; j < ns; ++j) Ps[((size_t)b * ns + i) * ns + j] = P[i][j]; }
+}
+
+void ofk_launch_kf_records(hipStream_t s, int ns, int nm, const double *mats, double *x, double *P, const double *records, double z_sign,
+                           int z_source, int batch)
+{
+    hipLaunchKernelGGL(k_kf_records, dim3((batch + 63) / 64), dim3(64), 0, s, ns, nm, mats, x, P, records, z_sign, z_source, batch);
+}
+
 void ofk_launch_kf(hipStream_t s, int ns, int nm, int nc, const double *F, const double *Bm, const double *H,
                    const double *Q, const double *Rm, double *x, double *P, const double *u, const double *z, int batch,
                    int do_predict)

@@ -1157,6 +1157,22 @@ extern "C" int ofk_filter_state(ofk_ctx *c, double *x, double *P, int batch)
     return get(c, P, c->kf_P, (size_t)batch * c->kf_ns * c->kf_ns * 8);
 }
 
+// Per-pair filter update of the resident batch behind the latest ofk_pairs_run (asynchronous, on the stream that ends the step):
+// predict + correct(z_sign * v) for every pair from its own record; the filter states (ofk_filter_configure) never leave the device.
+extern "C" int ofk_pairs_filter_step(ofk_ctx *c, double z_sign, int z_source, int batch)
+{
+    if (!c || batch < 1 || batch > c->cur_batch || c->kf_ns < 1) return ofk_fail(c, OFK_E_INVALID, "ofk_pairs_filter_step: no filter configured / bad batch");
+    OFK_HIP(c, hipSetDevice(c->device));
+    hipStream_t s;
+    TRY(tail_stream(c, &s));
+    ofk_launch_kf_records(s, c->kf_ns, c->kf_nm, c->kf_mats, c->kf_x, c->kf_P, c->records, z_sign, z_source, batch);
+    if (c->slices_open) {                                        // the next solves must not overwrite the records the filter still reads
+        OFK_HIP(c, hipEventRecord(c->ev_x, s));
+        c->x_pending = 1;
+    }
+    return check_launch(c, "k_kf_records");
+}
+
 // fu == NULL: the plain step (status filter, node-style solve, no resident filters)
 static int stream_step_impl(ofk_ctx *c, const uint8_t *next_bgr, const double *sensors, const ofk_params *p, const ofk_fusion *fu,
                             int min_features, int mask_radius, double *records, double *fused, float *tracks, int *counts)
@@ -1241,6 +1257,20 @@ extern "C" int ofk_stream_step_jpeg(ofk_ctx *c, const uint8_t *const *jpeg, cons
     if (h != c->stream_h || w != c->stream_w)
         return ofk_fail(c, OFK_E_INVALID, "ofk_stream_step_jpeg: frames are %dx%d, the streams were begun with %dx%d", w, h, c->stream_w, c->stream_h);
     return stream_step_impl(c, nullptr, sensors, p, nullptr, min_features, mask_radius, records, nullptr, tracks, counts);
+}
+
+// next positions and keep flags of the LATEST stream step (they stay in place until the next step): what a caller needs to form
+// the flow of the kept points, new - old, against the tracks it received before the step (node:134-136)
+extern "C" int ofk_stream_last_points(ofk_ctx *c, float *next_pts, uint8_t *keep, int stride)
+{
+    if (!c || !next_pts || !keep || stride < 1 || stride > c->max_pts) return ofk_fail(c, OFK_E_INVALID, "ofk_stream_last_points: bad argument");
+    if (c->stream_batch < 1) return ofk_fail(c, OFK_E_INVALID, "ofk_stream_last_points: no active streams");
+    OFK_HIP(c, hipSetDevice(c->device));
+    TRY(join_slices(c));
+    OFK_HIP(c, hipMemcpy2DAsync(next_pts, (size_t)stride * 8, c->pts_next, (size_t)c->max_pts * 8, (size_t)stride * 8, c->stream_batch, hipMemcpyDeviceToHost, c->stream));
+    OFK_HIP(c, hipMemcpy2DAsync(keep, stride, c->status, c->max_pts, stride, c->stream_batch, hipMemcpyDeviceToHost, c->stream));
+    OFK_HIP(c, hipStreamSynchronize(c->stream));
+    return OFK_OK;
 }
 
 extern "C" int ofk_stream_step_fused(ofk_ctx *c, const uint8_t *next_bgr, const double *sensors, const ofk_params *p, const ofk_fusion *f,

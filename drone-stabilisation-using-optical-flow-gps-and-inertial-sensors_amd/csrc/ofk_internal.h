@@ -145,6 +145,8 @@ void ofk_launch_solve(hipStream_t s, int variant, const double *x, const double 
                       int n, const double *d, const double *nrm, const double *omega, const double *t,
                       const double *wgt, double *out);
 void ofk_launch_imu(hipStream_t s, double *state, const double *msg, int batch);
+void ofk_launch_kf_records(hipStream_t s, int ns, int nm, const double *mats, double *x, double *P, const double *records, double z_sign,
+                           int z_source, int batch);
 void ofk_launch_imu_seq(hipStream_t s, double *state, double *dv, const double *msgs, const int *counts, int max_msgs, int batch);
 void ofk_launch_stream_fuse(hipStream_t s, const float *prev_pts, const float *next_pts, uint8_t *status, const int *counts, int pts_stride,
                             const double *sensors, double *imu_state, double *imu_dv, int ns, int nm, int nc, const double *kf_mats,

@@ -31,7 +31,7 @@ SYMBOLS = (
     "ofk_stream_begin_jpeg", "ofk_stream_step_jpeg",
     "ofk_set_streams", "ofk_set_overlap", "ofk_mark", "ofk_mark_wait", "ofk_profile_enable", "ofk_profile_read",
     "ofk_imu_reset", "ofk_imu_push", "ofk_imu_state", "ofk_filter_configure", "ofk_filter_state", "ofk_stream_step_fused",
-    "ofk_stream_step_fused_jpeg",
+    "ofk_stream_step_fused_jpeg", "ofk_stream_last_points", "ofk_pairs_filter_step",
     "ofk_comm_unique_id", "ofk_comm_init", "ofk_comm_destroy", "ofk_comm_rank", "ofk_comm_world", "ofk_comm_gather_records",
     "ofk_comm_fetch_records", "ofk_comm_allreduce_f64",
 )
@@ -132,6 +132,8 @@ def load_library():
         L.ofk_filter_configure.argtypes = [vp, i, i, i, vp, vp, vp, vp, vp, vp, vp, i]; L.ofk_filter_state.argtypes = [vp, vp, vp, i]
         L.ofk_stream_step_fused.argtypes = [vp, vp, vp, C.POINTER(Params), C.POINTER(Fusion), i, i, vp, vp, vp, vp]
         L.ofk_stream_step_fused_jpeg.argtypes = [vp, vp, vp, vp, C.POINTER(Params), C.POINTER(Fusion), i, i, vp, vp, vp, vp]
+        L.ofk_stream_last_points.argtypes = [vp, vp, vp, i]
+        L.ofk_pairs_filter_step.argtypes = [vp, d, i, i]
         L.ofk_set_streams.argtypes = [vp, i]
         L.ofk_set_overlap.argtypes = [vp, i]
         L.ofk_mark.argtypes = [vp, i]; L.ofk_mark_wait.argtypes = [vp, i]
@@ -692,6 +694,19 @@ class Context:
                 self._ck(self._L.ofk_stream_step_fused(self._h, _p(frames), _p(sensors), C.byref(params), C.byref(fusion), int(min_features),
                                                        int(mask_radius), _p(rec), _p(fused), _p(tracks), _p(counts)))
         return rec, fused, tracks, counts
+
+    def pairs_filter_step(self, batch, z_sign=-1.0, z_source=0):
+        """Per-pair resident filter update behind the latest pairs_run (asynchronous)."""
+        with self._lock:
+            self._ck(self._L.ofk_pairs_filter_step(self._h, float(z_sign), int(z_source), int(batch)))
+
+    def stream_last_points(self, stride):
+        """(next_pts [B,stride,2] f32, keep [B,stride] u8) of the latest stream step."""
+        B = self._stream[0]
+        nxt = np.zeros((B, stride, 2), np.float32); keep = np.zeros((B, stride), np.uint8)
+        with self._lock:
+            self._ck(self._L.ofk_stream_last_points(self._h, _p(nxt), _p(keep), int(stride)))
+        return nxt, keep
 
     # ------------------------------------------------------------------ multi-GPU exchange (RCCL through the library, no torch)
     def comm_init(self, unique_id, rank, world):

@@ -8,12 +8,15 @@ names and printed output.  Differences, all deliberate:
     `step()` is one iteration of the reference's busy loop (node:226-267).
   * `synthetic_test=True` (default) reproduces the node AS SHIPPED: 4 hard-coded features (node:123), flow
     overwritten by generate_test_data (node:236), feasibility forced to -1 (node:240).  With
-    `synthetic_test=False` the pipeline the reference keeps inside ''' blocks runs instead: goodFeaturesToTrack
-    on the first frame (node:120), calcOpticalFlowPyrLK between frames (node:133-136), re-detection with a
-    circle mask when few features remain (node:157-173), the real flow and the real r_tilde filter.
+    `synthetic_test=False` the pipeline the reference keeps inside ''' blocks runs instead — on the DEVICE-RESIDENT
+    stream loop (pipeline.FlowStream, ofk_stream_step_fused): the CompressedImage payload is decoded on the GPU, gray
+    levels / pyramids / tracks never leave HBM, and one callback = JPEG decode, goodFeaturesToTrack on the first frame
+    (node:120) or calcOpticalFlowPyrLK from the resident tracks (node:133-136), the real flow, the real r_tilde filter,
+    solve_lgs, lever arm (node:229-258) and the re-detection with a circle mask (node:157-173); step() publishes it.
   * callbacks and step() snapshot shared state under one lock (the reference races, node:61-177 vs :226-267).
 """
 import copy
+import os
 import threading
 import time
 
@@ -21,10 +24,12 @@ import numpy as np
 
 try:
     from . import ofk, cv2_hip as cv2, of_library as of
+    from .pipeline import FlowStream, FusionConfig, PipelineConfig
 except ImportError:
     import ofk
     import cv2_hip as cv2
     import of_library as of
+    from pipeline import FlowStream, FusionConfig, PipelineConfig
 
 try:                                    # ROS is optional (absent in this image)
     import rospy
@@ -115,38 +120,88 @@ class optical_fusion:
         return CvBridge().compressed_imgmsg_to_cv2(image_raw, 'bgr8')
 
     def call_optical(self, image_raw):
-        """node:92-177 — image callback."""
+        """node:92-177 - image callback.  As shipped (synthetic_test) it only decodes, converts and stores the frame; with the
+        reference's commented-out pipeline restored the whole frame step runs on the device (_call_optical_resident)."""
         with self._lock:
             if self.got_picture_:
                 return
+            if not self.synthetic_test:
+                return self._call_optical_resident(image_raw)
             image = self._decode(image_raw)
             image_gray = cv2.cvtColor(image, cv2.COLOR_BGR2GRAY)
-            old_pos = np.asarray(self.feat, np.float32).reshape((len(self.feat), 1, 2))
             if self.first:
-                if self.synthetic_test:
-                    first_feat = np.array([[-401, 300], [399, -300], [400, 301], [-400, -299]])       # node:123
-                else:
-                    found = cv2.goodFeaturesToTrack(image_gray, mask=None, maxCorners=self.max_feat, **self.feature_params)
-                    first_feat = np.zeros((0, 2)) if found is None else found
+                first_feat = np.array([[-401, 300], [399, -300], [400, 301], [-400, -299]])           # node:123
                 self.feat = np.asarray(first_feat).reshape((len(first_feat), 2))
                 self.feat_err = np.zeros(len(first_feat))
             else:
-                if not self.synthetic_test and len(old_pos):
-                    new_pos, status, new_pos_err = cv2.calcOpticalFlowPyrLK(self.old_pic, image_gray, old_pos, None, **self.lk_params)
-                    ok = status.reshape(-1) == 1
-                    self.feat = new_pos[ok].reshape((-1, 2))
-                    self.feat_err = new_pos_err[ok]
-                    self.flow = new_pos[ok] - old_pos[ok]
                 self.init = False
                 self.got_picture_ = True
-                if not self.synthetic_test and len(self.feat) <= self.min_feat:                       # node:157-173
-                    ft_mask = np.ones_like(image_gray)
-                    of.circles(self.feat, ft_mask, 30)
-                    new = cv2.goodFeaturesToTrack(image_gray, mask=ft_mask, maxCorners=self.max_feat - len(self.feat), **self.feature_params)
-                    if new is not None:                      # appended features have no flow yet (node:166 appends to feat only)
-                        self.feat = np.append(self.feat, new.reshape(len(new), 2), axis=0)
             self.old_pic = image_gray
             self.first = False
+
+    def _payload(self, image_raw):
+        """The frame as the device wants it: a baseline-JPEG byte string (decoded on the GPU, nothing decoded crosses PCIe) or an
+        HxWx3 BGR array.  Anything the device decoder refuses goes through cv_bridge like in the reference (node:112)."""
+        if isinstance(image_raw, np.ndarray):
+            return image_raw
+        data = image_raw if isinstance(image_raw, (bytes, bytearray, memoryview)) else getattr(image_raw, "data", None)
+        if data is not None:
+            data = bytes(data)
+            try:
+                h, w, _ = ofk.jpeg_info(data)
+                if h <= ofk.MAX_DIM and w <= ofk.MAX_DIM:
+                    return data
+            except ofk.OfkError:
+                pass
+        return self._decode(image_raw)
+
+    def _call_optical_resident(self, image_raw):
+        """node:112-175 with the commented-out blocks restored, on pipeline.FlowStream: the frame (JPEG or BGR) goes to the device
+        once; gray levels, pyramids and the tracks stay in HBM between callbacks.  First frame: goodFeaturesToTrack (:120).  Later
+        frames: calcOpticalFlowPyrLK from the resident tracks (:133-136), centre + scale, r_tilde filter with the dead-reckoned
+        velocity, solve_lgs, lever arm + rotation (:229-258, the main loop's work, one kernel behind LK), status filter,
+        re-detection with a disc mask when <= min_feat tracks are left (:157-166), frame swap (:175).  step() then publishes what
+        was computed."""
+        frame = self._payload(image_raw)
+        is_jpeg = not isinstance(frame, np.ndarray)
+        h, w = ofk.jpeg_info(frame)[:2] if is_jpeg else frame.shape[:2]
+        if self._stream is None or self._stream_dim != (h, w):
+            if self._stream is not None:
+                self._stream.close()
+            cnt, eps = cv2._criteria(self.lk_params["criteria"])
+            cfg = PipelineConfig(max_corners=int(self.max_feat), quality=float(self.feature_params["qualityLevel"]),
+                                 min_distance=float(self.feature_params["minDistance"]), block_size=int(self.feature_params["blockSize"]),
+                                 win=int(self.lk_params["winSize"][0]), max_level=int(self.lk_params["maxLevel"]), max_count=cnt, eps=eps,
+                                 use_feasibility=True, feas_T=float(self.T))
+            self._stream = FlowStream(w, h, batch=1, cfg=cfg, device=int(os.environ.get("OFK_DEVICE", "0")), min_features=int(self.min_feat),
+                                      mask_radius=30, fusion=FusionConfig(keep=ofk.KEEP_STATUS, min_solve=2))
+            self._stream_dim = (h, w)
+            self.first = True
+        fs = self._stream
+        if self.first:
+            tracks, counts = fs.begin_jpeg([frame]) if is_jpeg else fs.begin(frame[None])
+            n = int(counts[0])
+            self.feat = tracks[0, :n].astype(np.float64).reshape(n, 2)
+            self.feat_err = np.zeros(n)
+            self.first = False
+            return
+        old = np.asarray(self.feat, np.float32).reshape(-1, 2)
+        translation = of.pix_trans((320, 240))                   # node:229 (the node centres with (160, 120) whatever the frame size)
+        fs._params.feas_T = float(self.T)
+        sensors = ofk.make_sensors(1, d=self.d, normal=self.normal, omega=self.ang, rotation=np.asarray(self.rotation, np.float64), offset=self.offset,
+                                   scaling=self.scaling, cx=translation[0], cy=translation[1], v_prior=self.vel)
+        rec, fused, tracks, counts = fs.step_fused([frame] if is_jpeg else frame[None], sensors)
+        nxt, keep = fs.ctx.stream_last_points(max(1, len(old)))
+        k = keep[0, :len(old)] != 0
+        n = int(counts[0])
+        self.flow = (nxt[0, :len(old)][k] - old[k]).reshape(-1, 1, 2)                               # node:136
+        self.feat = tracks[0, :n].astype(np.float64).reshape(n, 2)                                   # kept points (+ re-detected ones, node:166)
+        self.feat_err = np.zeros(n)
+        r = rec[0]
+        self._resident_result = (r[0:3].copy(), r[8:11].copy(), (np.array([r[3]]) if (r[4] == 3 and 3 * r[11] > 3) else np.empty(0)), int(r[4]),
+                                 r[5:8].copy()) if r[15] else None
+        self.init = False
+        self.got_picture_ = True
 
     def _ctx(self):
         return ofk.default_context()
@@ -156,28 +211,27 @@ class optical_fusion:
         with self._lock:
             if not (self.got_picture_ and not self.init):
                 return None
+            if not self.synthetic_test:                          # the callback already ran the loop body on the device (node:229-258)
+                res, self._resident_result = self._resident_result, None
+                self.got_picture_ = False
+                if res is None:
+                    return None
+                v_obs, v_uav, R, rank, sv = res
+                print('    '.join(map(str, v_obs)))                                                          # node:259
+                self.vel = v_uav                                                                             # node:261
+                self.last_residual, self.last_rank, self.last_s = R, rank, sv
+                return v_obs
+            # ---- the node as shipped: 4 test features, flow from generate_test_data, feasibility forced to -1
             translation = of.pix_trans((320, 240))
             x = copy.deepcopy(self.feat).astype(float)
             x[:, 0] = (x[:, 0] - translation[0]) * self.scaling
             x[:, 1] = (x[:, 1] - translation[1]) * self.scaling
-            u = np.asarray(self.flow, np.float64).reshape(len(self.flow), 2) * self.scaling
-            if self.synthetic_test:
-                u = generate_test_data(x, np.array([1, 1, 1]), np.array([0, 0, 0]), self.d, np.array([0, 0, 1]))   # node:236
-            n_new = 0
-            if len(u) < len(x):                       # features re-detected this frame sit behind the tracked ones and have no flow:
-                n_new = len(x) - len(u)                # the solve uses the tracked ones only (the reference would fail on the mismatch)
-                x = x[:len(u)]
-            elif len(u) > len(x):
-                self.got_picture_ = False
-                return None
-            feasibility, dummy_d = of.r_tilde(x, u, self.normal, self.vel, self.d)
-            if self.synthetic_test:
-                feasibility = -1 * np.ones(len(x))                                                                  # node:240
+            u = generate_test_data(x, np.array([1, 1, 1]), np.array([0, 0, 0]), self.d, np.array([0, 0, 1]))       # node:236
+            feasibility, dummy_d = of.r_tilde(x, u, self.normal, self.vel, self.d)                                  # node:238
+            feasibility = -1 * np.ones(len(x))                                                                      # node:240
             keep = feasibility <= self.T
             x = x[keep]; u = u[keep]; dummy_d = dummy_d[keep]
-            self.feat = np.concatenate([self.feat[:len(keep)][keep], self.feat[len(keep):]]) if n_new else self.feat[keep]
-            if not self.synthetic_test:
-                self.flow = np.asarray(self.flow).reshape(-1, 1, 2)[keep]
+            self.feat = self.feat[keep]
             v_obs = None
             if len(x) >= 3:
                 v_obs, R, rank, s = solve_lgs(x, u, self.d, self.normal, self.ang)
@@ -191,6 +245,9 @@ class optical_fusion:
     def __init__(self, spin=True, synthetic_test=True):
         self._lock = threading.RLock()
         self.synthetic_test = synthetic_test
+        self._stream = None                                      # pipeline.FlowStream of the restored pipeline (created with the first frame)
+        self._stream_dim = None
+        self._resident_result = None
         self.vel = np.array([0.1, 0.1, 0.1])
         self.vel_err = np.array([0.1, 0.1, 0.1])
         self.feat = np.ones((1, 2))

@@ -283,6 +283,11 @@ int ofk_filter_configure(ofk_ctx *ctx, int ns, int nm, int nc, const double *F, 
                          const double *Rm, const double *x0, const double *P0, int batch);
 int ofk_filter_state(ofk_ctx *ctx, double *x, double *P, int batch);
 
+/* Per-pair filter update of the resident batch, queued behind the latest ofk_pairs_run (asynchronous): every pair's filter
+ * (state from ofk_filter_configure, resident) predicts and corrects with z = z_sign * (z_source ? v_uav : v_obs) of its own record
+ * when the solve had full rank - BASELINE configs[2] "batch of 1024 independent frame pairs + per-frame EKF update". */
+int ofk_pairs_filter_step(ofk_ctx *ctx, double z_sign, int z_source, int batch);
+
 /* What happens between calcOpticalFlowPyrLK and the next frame (ofk_stream_step_fused). */
 #define OFK_FLOW_LK          0   /* u = new - old (node:235; of_module.py:108) */
 #define OFK_FLOW_ROTATIONAL  1   /* of_module.py:113-114: the flow is overwritten by the rotational field of the sensors' omega */
@@ -312,6 +317,9 @@ typedef struct ofk_fusion {
  * advances; the filter then keeps its prediction and the record reports rank 0. */
 int ofk_stream_step_fused(ofk_ctx *ctx, const uint8_t *next_bgr, const double *sensors, const ofk_params *p, const ofk_fusion *f,
                           int min_features, int mask_radius, double *records, double *fused, float *tracks, int *counts);
+/* Next positions [batch][stride][2] and keep flags [batch][stride] of the latest step (valid until the next one): with the tracks
+ * the caller held before the step they give the flow of the kept points, new - old (node:134-136). */
+int ofk_stream_last_points(ofk_ctx *ctx, float *next_pts, uint8_t *keep, int stride);
 int ofk_stream_step_fused_jpeg(ofk_ctx *ctx, const uint8_t *const *jpeg, const size_t *nbytes, const double *sensors, const ofk_params *p,
                                const ofk_fusion *f, int min_features, int mask_radius, double *records, double *fused, float *tracks,
                                int *counts);

@@ -137,4 +137,10 @@ def test_config2_batch_1024_480p_pairs_with_filter(pkg, ofk):
         xr, Pr = eo.kf_predict(x6[b], P6[b], m.F, m.Q); xr, Pr = eo.kf_correct(xr, Pr, m.H, m.R, -v_obs[b])
         np.testing.assert_allclose(gx[b], xr, rtol=1e-11, atol=1e-18); np.testing.assert_allclose(gP[b], Pr, rtol=1e-10, atol=1e-14)
     assert np.all(np.isfinite(gx)) and np.all(np.isfinite(gP))
+    # the same update with the filter states RESIDENT: queued behind the step on the library's stream, nothing but the final
+    # state crosses PCIe (ofk_pairs_filter_step) - bit-identical to the host-buffer entry point
+    pipe.ctx.filter_configure(m, B)
+    pipe.run_async(); pipe.ctx.pairs_filter_step(B, z_sign=-1.0, z_source=0); pipe.sync()
+    rx, rP = pipe.ctx.filter_state(B)
+    assert np.array_equal(rx.view(np.uint64), gx.view(np.uint64)) and np.array_equal(rP.view(np.uint64), gP.view(np.uint64))
     pipe.close()

@@ -4,6 +4,7 @@ C3 = 1024 x 640x480 pairs (+ a 6-state Kalman update per pair), C4 = 1080p camer
 C5 = 3840x2160 pairs, 2000 corners, 5-level pyramid.
   python tools/bench_configs.py [c3] [c4] [c5]
 """
+import json
 import os
 import sys
 import time
@@ -13,6 +14,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from __graft_entry__ import load_package  # noqa: E402
+
+
+RESULTS = []
 
 
 def run(name, w, h, batch, cfg, steps, kf=False):
@@ -34,19 +38,22 @@ def run(name, w, h, batch, cfg, steps, kf=False):
     dt = time.perf_counter() - t0
     prof = pipe.ctx.profile_read()
     out = pipe.ctx.pairs_download(points=False)
-    line = f"{name}: {w}x{h} B={batch} corners={np.mean(out['counts']):.0f}: {batch * steps / dt:.0f} pairs/s ({dt / steps * 1e3:.3f} ms/step)  " + \
-        " ".join(f"{s}={prof[s][0] / steps:.3f}" for s in ofk.STAGES if prof[s][1])
-    if kf:                                                      # of_module.py:63-76 shaped filter with 6 states on every pair's velocity
-        ns, nm = 6, 3
-        F = np.eye(ns); F[:3, 3:] = np.eye(3) / 30.0
-        H = np.zeros((nm, ns)); H[:, :3] = np.eye(3)
-        x = np.zeros((batch, ns)); P = np.tile(np.eye(ns), (batch, 1, 1))
-        z = out["records"][:, 0:3].copy()
+    res = {"config": name, "frame": f"{w}x{h}", "pairs_per_step": batch, "corners_mean": float(np.mean(out["counts"])), "pairs_per_s": round(batch * steps / dt, 1),
+           "ms_per_step": round(dt / steps * 1e3, 4), "stage_ms_per_step_under_overlap": {s: round(prof[s][0] / steps, 4) for s in ofk.STAGES if prof[s][1]}}
+    if kf:                                                      # the 6-state filter of every pair, state resident, queued behind each step
+        from of_amd.pipeline import FilterModel
+        pipe.ctx.filter_configure(FilterModel.ekf6(), batch)
+        for _ in range(2):
+            pipe.run_async(); pipe.ctx.pairs_filter_step(batch)
+        pipe.sync()
         t0 = time.perf_counter()
         for _ in range(steps):
-            x, P = pipe.ctx.kf_predict_update(F, H, 1e-4 * np.eye(ns), 1e-2 * np.eye(nm), x, P, z=z)
-        line += f"  | kalman(6 states, host buffers): {(time.perf_counter() - t0) / steps * 1e3:.3f} ms per {batch} filters"
-    print(line, flush=True)
+            pipe.run_async(); pipe.ctx.pairs_filter_step(batch)
+        pipe.sync()
+        dtk = time.perf_counter() - t0
+        res["with_resident_ekf6_per_pair"] = {"pairs_per_s": round(batch * steps / dtk, 1), "ms_per_step": round(dtk / steps * 1e3, 4)}
+    RESULTS.append(res)
+    print(json.dumps(res), flush=True)
     pipe.close()
 
 
@@ -66,8 +73,8 @@ def run_stream(name, w, h, streams, cfg, frames):
     for k in range(frames):
         rec, tracks, counts = fs.step(f0 if k & 1 else f1, sensors)
     dt = (time.perf_counter() - t0) / frames
-    print(f"{name}: {streams} stream(s) {w}x{h}: {dt * 1e3:.3f} ms per step = {streams / dt:.0f} frames/s, tracks per stream {np.mean(counts):.0f} "
-          f"(a 30 fps camera leaves {1e3 / 30:.1f} ms per frame)", flush=True)
+    res = {"config": name, "frame": f"{w}x{h}", "streams": streams, "ms_per_step_host_bgr_frames": round(dt * 1e3, 4), "frames_per_s": round(streams / dt, 1),
+           "tracks_per_stream": float(np.mean(counts)), "camera_period_ms_at_30fps": round(1e3 / 30, 2)}
     try:                                                        # the same loop on compressed frames (what the node receives), if an encoder is around
         import io
         from PIL import Image
@@ -83,10 +90,27 @@ def run_stream(name, w, h, streams, cfg, frames):
         for k in range(frames):
             rec, tracks, counts = fs.step_jpeg(j0 if k & 1 else j1, sensors)
         dt = (time.perf_counter() - t0) / frames
-        print(f"{name} (JPEG frames, {np.mean([len(s) for s in j0]) / 1e3:.0f} kB each): {dt * 1e3:.3f} ms per step = {streams / dt:.0f} frames/s", flush=True)
+        res["ms_per_step_jpeg_frames"] = round(dt * 1e3, 4); res["jpeg_kB_per_frame"] = round(float(np.mean([len(s) for s in j0])) / 1e3, 1)
     except ImportError:
         pass
     fs.close()
+    # the same loop with the filters resident (IMU dead-reckoning + 6-state filter, ofk_stream_step_fused)
+    from of_amd.pipeline import FusionConfig
+    fs = FlowStream(w, h, batch=streams, cfg=cfg, min_features=cfg.max_corners // 2, mask_radius=10, fusion=FusionConfig.ekf6())
+    fs.begin(f0)
+    msgs = np.zeros((streams, 2, 15)); msgs[:, :, 5] = 1.0; msgs[:, :, 14] = 9.81
+    msgs[:, 0, 0] = 100; msgs[:, 1, 0] = 100; msgs[:, 1, 1] = 2e7
+    fs.push_imu(msgs); fs.step_fused(f1, sensors)
+    t0 = time.perf_counter()
+    for k in range(frames):
+        msgs[:, :, 0] += 1
+        fs.push_imu(msgs)
+        rec, fused, tracks, counts = fs.step_fused(f0 if k & 1 else f1, sensors)
+    dt = (time.perf_counter() - t0) / frames
+    res["ms_per_step_fused_imu_ekf6"] = round(dt * 1e3, 4)
+    fs.close()
+    RESULTS.append(res)
+    print(json.dumps(res), flush=True)
 
 
 def main():
@@ -101,6 +125,11 @@ def main():
         run_stream("C4x8", 1920, 1080, 8, cfg4, 30)
     if "c5" in which:
         run("C5", 3840, 2160, 32, PipelineConfig(max_corners=2000, quality=0.01, min_distance=10, block_size=7, win=15, max_level=5), 10)
+    out = os.environ.get("OFK_CONFIGS_JSON")
+    if out:
+        json.dump({"_note": "tools/bench_configs.py on one MI355X: the other BASELINE.json configurations (bench.py measures configs[1]); "
+                            "two free-running slices like bench.py; C3 = configs[2], C4 = configs[3] (1 and 8 streams in one context), C5 = configs[4]'s pair workload",
+                   "results": RESULTS}, open(out, "w"), indent=1)
 
 
 if __name__ == "__main__":
