@@ -35,11 +35,17 @@ __device__ __forceinline__ int wave_sum_i32(int v)
     return v;
 }
 
+// cvRound of a value in [0, 2^22): adding 1.5 * 2^23 leaves the integer, rounded half to even by the addition itself, in the low
+// mantissa bits — one full-rate f32 add and one integer subtract instead of v_rndne_f32 + v_cvt_i32_f32 (4 clocks each).
+__device__ __forceinline__ int rn_small(float x) { return __float_as_int(x + 12582912.f) - 0x4B400000; }
+
 __device__ __forceinline__ void lk_weights(float a, float b, int &w00, int &w01, int &w10, int &w11)
 {
-    w00 = __float2int_rn((1.f - a) * (1.f - b) * 16384.f);
-    w01 = __float2int_rn(a * (1.f - b) * 16384.f);
-    w10 = __float2int_rn((1.f - a) * b * 16384.f);
+    // fl(fl((1-a)(1-b)) * 2^14) = fl((1-a) * ((1-b) * 2^14)): scaling by a power of two commutes with rounding
+    const float a1 = 1.f - a, b1 = (1.f - b) * 16384.f, b0 = b * 16384.f;
+    w00 = rn_small(a1 * b1);
+    w01 = rn_small(a * b1);
+    w10 = rn_small(a1 * b0);
     w11 = 16384 - w00 - w01 - w10;
 }
 
@@ -264,8 +270,10 @@ __device__ __forceinline__ float wave_sum_rows_scaled(int v)
     // Nearly every sum fits 32 bits (the mismatch sums always do in practice): v_cvt_f32_i32 rounds to nearest even exactly as
     // f64 -> f32 does, and the scaling is a power of two, so one conversion + one multiply replace ten half-rate f64
     // instructions.  S is wave-uniform: the test and the branch run on the scalar unit.
-    const int s32 = (int)S;
-    if (__builtin_expect((long long)s32 == S, 1)) return (float)s32 * 0x1p-20f;
+    const int lo = (int)S, hi = (int)(S >> 32);
+    int sx;                                                      // sign extension of lo, hidden from the optimiser: it would otherwise
+    asm("s_ashr_i32 %0, %1, 31" : "=s"(sx) : "s"(lo));           // fold the test back into a 64-bit range check on the VALU
+    if (__builtin_expect(hi == sx, 1)) return (float)lo * 0x1p-20f;
     return (float)((double)S * 0x1p-20);
 }
 
