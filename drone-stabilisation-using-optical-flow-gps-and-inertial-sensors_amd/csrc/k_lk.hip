@@ -573,6 +573,362 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     }
 }
 
+// ================================================================================================
+// k_lk15q — win == 15, FOUR points per wave: lane = (point g = lane / 16, window row r = lane % 16).
+//
+// k_lk15 spends most of its issue slots on work that is the same for all 64 lanes of a point: interpolation weights, the 2x2
+// solve, convergence tests, 12 cross-lane instructions per window sum.  Here a 16-lane DPP row owns a point and a lane owns one
+// window row of 15 pixels, so that per-point work is shared by four points, a window sum is 4 DPP adds that leave the total in
+// every lane of the row (no v_readlane, no scalar round trip), and the Scharr pass runs on full rows: vertical pass first on
+// 9 packed column pairs, the horizontal pass is then one packed subtract (dx) or one v_alignbit + 3 packed ops (dy) per pair.
+//   * staging: LDS keeps RAW aligned dwords of each staged row (prev: 18 rows x 6 dwords, next: 32 rows x 9 dwords per point);
+//     the byte offset of a row's first pixel goes into the v_perm selectors that expand byte pairs, so nothing is re-aligned.
+//     Columns outside the image: image widths are multiples of 4, so an aligned dword is wholly inside or wholly outside; an
+//     outside dword is ONE v_perm of two inside dwords (reflect-101 reverses bytes), loaded from the mirrored address.
+//   * a lane interpolates its derivative row with both weight rows; the half that belongs to the window row above travels there
+//     inside the add (v_add_u32_dpp row_shl:1).
+//   * the mismatch sums use b = sum(J * Ixy) - sum(I * Ixy): the second term is a per-lane constant of the level; (Ix, Iy) sit
+//     packed in one register per pixel and feed v_mad_i32_i16 (op_sel picks the half).
+//   * exactness: a lane's 15 products and a quad's 60 fit int32 always; a whole window may not (|sum| < 2^33).  With
+//     A11, A22 < 3e8 Cauchy-Schwarz bounds every partial sum of diff * Ix below 2^31 and the plain 32-bit DPP tree is exact;
+//     windows above that (full-contrast noise) reduce the 16-bit halves of the lane sums separately.  A11, A22 < 2^32 always
+//     (225 * 4080^2) and reduce as unsigned; A12 fits int32 when max(A11, A22) < 2^31, else it takes the split path too.
+// The four points of a wave iterate until the last one has converged; finished rows idle.  Results are those of k_lk15 bit for
+// bit (integer sums are order-free, the float operations and their order are the same).
+#define LKQ_IP 28                                  // LDS pitch of a staged prev row: 6 dwords + 1 (odd dword pitch: no bank conflicts between rows)
+#define LKQ_JP 36                                  // LDS pitch of a staged next row: 9 dwords
+#define LKQ_ISZ (18 * LKQ_IP)
+#define LKQ_JSZ (32 * LKQ_JP)
+#define LKQ_SAFE_LIM 300000000u                    // 8160 * sqrt(225 * A) < 2^31  <=>  A < 3.078e8
+
+__device__ __forceinline__ int lkq_reflect(int i, int n)               // one reflection: -n < i < 2n - 1
+{
+    i = max(i, -i);
+    return i >= n ? 2 * (n - 1) - i : i;
+}
+__device__ __forceinline__ int lkq_floor_i(float x)
+{
+    int r;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));               // floor + convert in one instruction
+    return r;
+}
+__device__ __forceinline__ int lkq_mad_lo(int a, unsigned packed, int acc)     // acc + a.lo16 * packed.lo16
+{
+    int d;
+    asm("v_mad_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(packed), "v"(acc));
+    return d;
+}
+__device__ __forceinline__ int lkq_mad_hi(int a, unsigned packed, int acc)     // acc + a.lo16 * packed.hi16
+{
+    int d;
+    asm("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[0,1,0,0]" : "=v"(d) : "v"(a), "v"(packed), "v"(acc));
+    return d;
+}
+// sum over the 16 lanes of a DPP row, total in every lane
+__device__ __forceinline__ int lkq_row_sum(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);      // quad_perm(1,0,3,2)
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);      // quad_perm(2,3,0,1)
+    v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xF, 0xF, true);     // row_ror:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, true);     // row_ror:8
+    return v;
+}
+// exact sum of 16 int32 lane values as f32(sum * 2^-20): halves reduced separately (|sum of halves| < 2^21)
+__device__ __forceinline__ float lkq_row_sum_split(int v)
+{
+    const int lo = lkq_row_sum(v & 0xffff), hi = lkq_row_sum(v >> 16);
+    return (float)((double)(((long long)hi << 16) + lo) * 0x1p-20);
+}
+__device__ __forceinline__ float lkq_row_sum_split_u(unsigned v)
+{
+    const int lo = lkq_row_sum((int)(v & 0xffffu)), hi = lkq_row_sum((int)(v >> 16));
+    return (float)((double)(((long long)hi << 16) + lo) * 0x1p-20);
+}
+// ND aligned dwords of one image row starting at column A (multiple of 4, any sign): reflect-101 columns
+template <int ND>
+__device__ __forceinline__ void lkq_load_row(const uint8_t *rowp, int lw, int A, bool border, unsigned (&d)[ND])
+{
+    if (!border) {                                                      // wave-uniform
+        const unsigned *g = reinterpret_cast<const unsigned *>(rowp + A);
+#pragma unroll
+        for (int i = 0; i < ND; ++i) d[i] = g[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int X = A + 4 * i;
+            int lo = X, hi = X;
+            unsigned sel = 0x03020100u;
+            if (X < 0) { lo = -X - 4; hi = -X; sel = 0x01020304u; }                        // bytes n[-X], n[-X-1], n[-X-2], n[-X-3]
+            else if (X >= lw) { hi = 2 * lw - 4 - X; lo = hi - 4; sel = 0x03040506u; }     // bytes n[c], n[c-1], n[c-2], n[c-3], c = 2 lw - 2 - X
+            const unsigned vlo = *reinterpret_cast<const unsigned *>(rowp + lo), vhi = *reinterpret_cast<const unsigned *>(rowp + hi);
+            d[i] = __builtin_amdgcn_perm(vhi, vlo, sel);
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_lk15q(const uint8_t *__restrict__ prev, const uint8_t *__restrict__ next, size_t pyr_stride,
+                                              ofk_levels lv, const float *__restrict__ prev_pts, const int *__restrict__ counts,
+                                              int pts_stride, int max_count, double eps2, float eps2_lo, float eps2_hi,
+                                              double min_eig_thr, float *__restrict__ next_pts, uint8_t *__restrict__ status,
+                                              float *__restrict__ err)
+{
+    constexpr int win = 15, ww = 225;
+    constexpr float half = 7.f;
+    __shared__ __attribute__((aligned(16))) uint8_t s_I[4 * LKQ_ISZ];
+    __shared__ __attribute__((aligned(16))) uint8_t s_J[4 * LKQ_JSZ];
+
+    const int lane = threadIdx.x, g = lane >> 4, r = lane & 15;
+    int b = blockIdx.y, chunk = blockIdx.x;                        // XCD-aware map as in k_lk15: the points of an image stay on one XCD
+    if ((gridDim.y & 7) == 0) {
+        const unsigned n = blockIdx.y * gridDim.x + blockIdx.x, k = n >> 3;
+        b = 8 * (int)(k / gridDim.x) + (int)(n & 7);
+        chunk = (int)(k % gridDim.x);
+    }
+    const int cnt = counts[b];
+    if (chunk * 4 >= cnt) return;
+    const int p = chunk * 4 + g;
+    const bool live = p < cnt;
+    const size_t pi = (size_t)b * pts_stride + min(p, cnt - 1);
+    const float ptx = prev_pts[2 * pi], pty = prev_pts[2 * pi + 1];
+    const uint8_t *Pb = prev + (size_t)b * pyr_stride, *Nb = next + (size_t)b * pyr_stride;
+    uint8_t *sI = s_I + g * LKQ_ISZ, *sJ = s_J + g * LKQ_JSZ;
+    const bool rowact = r < win;                                   // lane 15 of a row only stages and computes derivative row 15
+
+    int st = 1;
+    float errv = 0.f, nx = 0.f, ny = 0.f;
+    unsigned pxy[15];                                              // (Ix, Iy) of the lane's pixels, int16 pairs
+    int pI[15];
+
+    for (int l = lv.n; l >= 0; --l) {
+        const int lh = lv.h[l], lw = lv.w[l];
+        const uint8_t *I = Pb + lv.off[l], *J = Nb + lv.off[l];
+        const float sc = __int_as_float((127 - l) << 23);
+        float px = ptx * sc, py = pty * sc, qx, qy;
+        if (l == lv.n) { qx = px; qy = py; } else { qx = nx * 2.f; qy = ny * 2.f; }
+        nx = qx; ny = qy;
+        px -= half; py -= half;
+        const int ipx = lkq_floor_i(px), ipy = lkq_floor_i(py);
+        const bool lev = live && !(ipx < -win || ipx >= lw || ipy < -win || ipy >= lh);
+        if (live && !lev && l == 0) { st = 0; errv = 0.f; }
+        if (__builtin_amdgcn_ballot_w64(lev) == 0) continue;
+        qx -= half; qy -= half;
+
+        int jx0 = 0, jy0 = 0, jA = 0;
+        bool jvalid = false;
+        unsigned jd[2][9];
+        auto J_issue = [&](int iqx, int iqy, bool on) {
+            if (on) { jx0 = iqx - LK_M; jy0 = iqy - LK_M; jA = jx0 & ~3; }
+            const bool border = __builtin_amdgcn_ballot_w64(on && (jA < 0 || jA + 36 > lw)) != 0;
+            if (on) {
+                lkq_load_row<9>(J + (size_t)lkq_reflect(jy0 + r, lh) * lw, lw, jA, border, jd[0]);
+                lkq_load_row<9>(J + (size_t)lkq_reflect(jy0 + r + 16, lh) * lw, lw, jA, border, jd[1]);
+            }
+        };
+        auto J_commit = [&](bool on) {
+            LDS_FENCE();                                                  // earlier readers of s_J are done
+            if (on) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    unsigned *o = reinterpret_cast<unsigned *>(sJ + (r + 16 * h) * LKQ_JP);
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) o[i] = jd[h][i];
+                }
+                jvalid = true;
+            }
+            LDS_FENCE();
+        };
+        // ---- staging: prev neighbourhood rows ipy-1 .. ipy+16 (lane r: row r; lanes 0, 1 also rows 16, 17), columns from
+        //      iA = (ipx-1) & ~3; then the next-frame region around the start position.  All loads are issued before the first wait.
+        const int iA = (ipx - 1) & ~3;
+        {
+            const bool iborder = __builtin_amdgcn_ballot_w64(lev && (iA < 0 || iA + 24 > lw)) != 0;
+            unsigned id0[6], id1[6];
+            if (lev) {
+                lkq_load_row<6>(I + (size_t)lkq_reflect(ipy - 1 + r, lh) * lw, lw, iA, iborder, id0);
+                if (r < 2) lkq_load_row<6>(I + (size_t)lkq_reflect(ipy + 15 + r, lh) * lw, lw, iA, iborder, id1);
+            }
+            const int iqx = lkq_floor_i(qx), iqy = lkq_floor_i(qy);
+            const bool doJ = lev && !(iqx < -win || iqx >= lw || iqy < -win || iqy >= lh);
+            J_issue(iqx, iqy, doJ);
+            LDS_FENCE();                                                  // the previous level's readers of s_I are done
+            if (lev) {
+                unsigned *o = reinterpret_cast<unsigned *>(sI + r * LKQ_IP);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) o[i] = id0[i];
+                if (r < 2) {
+                    unsigned *o1 = reinterpret_cast<unsigned *>(sI + (r + 16) * LKQ_IP);
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) o1[i] = id1[i];
+                }
+            }
+            J_commit(doJ);
+        }
+        // ---- patch.  Neighbourhood rows r, r+1, r+2 -> derivative row r (16 columns); window row r = derivative rows r, r+1.
+        int w00, w01, w10, w11;
+        lk_weights(px - (float)ipx, py - (float)ipy, w00, w01, w10, w11);
+        const unsigned W0 = (unsigned)w00 | ((unsigned)w01 << 16), W1 = (unsigned)w10 | ((unsigned)w11 << 16);
+        unsigned a11 = 0, a22 = 0;
+        int a12 = 0, c1 = 0, c2 = 0;
+        {
+            const unsigned ishs = (unsigned)((ipx - 1) & 3) * 0x00010001u;
+            const unsigned sel0 = LK_PAIR_SEL(0) + ishs, sel1 = LK_PAIR_SEL(1) + ishs, sel2 = LK_PAIR_SEL(2) + ishs, sel3 = LK_PAIR_SEL(3) + ishs;
+            unsigned R[3][6];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const unsigned *q = reinterpret_cast<const unsigned *>(sI + (r + j) * LKQ_IP);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) R[j][i] = q[i];
+            }
+            // pair (n[c], n[c+1]) of neighbourhood row j: bytes c + ish, c + 1 + ish of the row's dwords
+            auto pair = [&](int j, int c) {
+                const unsigned sel = (c & 3) == 0 ? sel0 : (c & 3) == 1 ? sel1 : (c & 3) == 2 ? sel2 : sel3;
+                return __builtin_amdgcn_perm(R[j][(c >> 2) + 1], R[j][c >> 2], sel);
+            };
+            lk_s2 VS[9], VD[9];
+#pragma unroll
+            for (int s = 0; s < 9; ++s) {
+                const lk_s2 e0 = lk_as_s2(pair(0, 2 * s)), e1 = lk_as_s2(pair(1, 2 * s)), e2 = lk_as_s2(pair(2, 2 * s));
+                VS[s] = (e0 + e2) * (short)3 + e1 * (short)10;
+                VD[s] = e2 - e0;
+            }
+            unsigned DX[8], DY[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                DX[s] = lk_as_u(VS[s + 1] - VS[s]);
+                const lk_s2 m = lk_as_s2(__builtin_amdgcn_alignbit(lk_as_u(VD[s + 1]), lk_as_u(VD[s]), 16));
+                DY[s] = lk_as_u((VD[s] + VD[s + 1]) * (short)3 + m * (short)10);
+            }
+            // constant-0 border of the derivative image: taps (ipx + x, ipy + r) outside the level are zero
+            if (__builtin_amdgcn_ballot_w64(lev && !(ipx >= 0 && ipx + win < lw && ipy >= 0 && ipy + win < lh)) != 0) {
+                const int Y = ipy + r;
+                const bool rowok = Y >= 0 && Y < lh;
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    const int X = ipx + 2 * s;
+                    const unsigned keep = ((rowok && X >= 0 && X < lw) ? 0x0000ffffu : 0u) | ((rowok && X + 1 >= 0 && X + 1 < lw) ? 0xffff0000u : 0u);
+                    DX[s] &= keep; DY[s] &= keep;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 15; ++k) {
+                const unsigned qx_ = (k & 1) ? __builtin_amdgcn_alignbit(DX[(k + 1) >> 1], DX[k >> 1], 16) : DX[k >> 1];
+                const unsigned qy_ = (k & 1) ? __builtin_amdgcn_alignbit(DY[(k + 1) >> 1], DY[k >> 1], 16) : DY[k >> 1];
+                // own derivative row with the upper weights; the lower-weight half comes from the lane below (row r + 1)
+                const int hx = lk_dot2(qx_, W0, 1 << 13), gx = lk_dot2(qx_, W1, 0);
+                const int hy = lk_dot2(qy_, W0, 1 << 13), gy = lk_dot2(qy_, W1, 0);
+                const int ix = (hx + __builtin_amdgcn_update_dpp(0, gx, 0x101, 0xF, 0xF, true)) >> 14;     // row_shl:1
+                const int iy = (hy + __builtin_amdgcn_update_dpp(0, gy, 0x101, 0xF, 0xF, true)) >> 14;
+                const int iv = lk_dot2(pair(1, k + 1), W0, lk_dot2(pair(2, k + 1), W1, 1 << 8)) >> 9;
+                const bool on = lev && rowact;
+                pI[k] = iv;
+                pxy[k] = on ? __builtin_amdgcn_perm((unsigned)iy, (unsigned)ix, 0x05040100u) : 0u;
+                a11 += (unsigned)__mul24(ix, ix); a12 += __mul24(ix, iy); a22 += (unsigned)__mul24(iy, iy);
+                c1 += __mul24(iv, ix); c2 += __mul24(iv, iy);
+            }
+            if (!(lev && rowact)) { a11 = 0; a12 = 0; a22 = 0; c1 = 0; c2 = 0; }
+        }
+        const unsigned A11u = (unsigned)lkq_row_sum((int)a11), A22u = (unsigned)lkq_row_sum((int)a22);
+        float A12 = (float)lkq_row_sum(a12) * 0x1p-20f;
+        if (__builtin_amdgcn_ballot_w64(lev && max(A11u, A22u) >= 0x80000000u) != 0) {
+            const float A12x = lkq_row_sum_split(a12);
+            if (max(A11u, A22u) >= 0x80000000u) A12 = A12x;
+        }
+        const float A11 = (float)A11u * 0x1p-20f, A22 = (float)A22u * 0x1p-20f;
+        const bool safe = A11u < LKQ_SAFE_LIM && A22u < LKQ_SAFE_LIM;
+        float D = A11 * A22 - A12 * A12;
+        const float dd = A11 - A22;
+        const float minEig = (A22 + A11 - sqrtf(dd * dd + 4.f * A12 * A12)) / (float)(2 * ww);
+        const bool solv = lev && !((double)minEig < min_eig_thr || D < FLT_EPSILON);
+        if (lev && !solv && l == 0) st = 0;
+        D = 1.f / D;
+
+        // taps of the lane's window row at integer position (ix_, iy_): 2 x 5 raw dwords and the byte-pair selectors
+        unsigned jr0[5], jr1[5], jsel[4];
+        auto J_read = [&](int ix_, int iy_, bool on) {
+            const int off = on && rowact ? (iy_ - jy0 + r) * LKQ_JP + (ix_ - jA) : 0;
+            const unsigned *q = reinterpret_cast<const unsigned *>(sJ + (off & ~3));
+#pragma unroll
+            for (int i = 0; i < 5; ++i) { jr0[i] = q[i]; jr1[i] = q[i + LKQ_JP / 4]; }
+            const unsigned shs = ((unsigned)off & 3u) * 0x00010001u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) jsel[i] = LK_PAIR_SEL(i) + shs;
+        };
+        auto J_value = [&](int k, unsigned W0_, unsigned W1_) {       // interpolated next-frame pixel k, 5 fractional bits
+            return lk_dot2(__builtin_amdgcn_perm(jr0[(k >> 2) + 1], jr0[k >> 2], jsel[k & 3]), W0_,
+                           lk_dot2(__builtin_amdgcn_perm(jr1[(k >> 2) + 1], jr1[k >> 2], jsel[k & 3]), W1_, 1 << 8)) >> 9;
+        };
+
+        bool act = solv;
+        float pdx = 0.f, pdy = 0.f;
+        for (int j = 0; j < max_count; ++j) {
+            if (__builtin_amdgcn_ballot_w64(act) == 0) break;
+            const int iqx = lkq_floor_i(qx), iqy = lkq_floor_i(qy);
+            if (act && (iqx < -win || iqx >= lw || iqy < -win || iqy >= lh)) {
+                if (l == 0) st = 0;
+                act = false;
+            }
+            const bool need = act && (!jvalid || (unsigned)(iqx - jx0) > 2u * LK_M || (unsigned)(iqy - jy0) > 2u * LK_M);
+            if (__builtin_amdgcn_ballot_w64(need) != 0) { J_issue(iqx, iqy, need); J_commit(need); }
+            lk_weights(qx - (float)iqx, qy - (float)iqy, w00, w01, w10, w11);
+            const unsigned V0 = (unsigned)w00 | ((unsigned)w01 << 16), V1 = (unsigned)w10 | ((unsigned)w11 << 16);
+            J_read(iqx, iqy, act);
+            int b1 = -c1, b2 = -c2;
+#pragma unroll
+            for (int k = 0; k < 15; ++k) {
+                const int jv = J_value(k, V0, V1);
+                b1 = lkq_mad_lo(jv, pxy[k], b1); b2 = lkq_mad_hi(jv, pxy[k], b2);
+            }
+            float fb1 = (float)lkq_row_sum(b1) * 0x1p-20f, fb2 = (float)lkq_row_sum(b2) * 0x1p-20f;
+            if (__builtin_amdgcn_ballot_w64(act && !safe) != 0) {
+                const float x1 = lkq_row_sum_split(b1), x2 = lkq_row_sum_split(b2);
+                if (!safe) { fb1 = x1; fb2 = x2; }
+            }
+            const float dx = (A12 * fb2 - A22 * fb1) * D, dy = (A12 * fb1 - A11 * fb2) * D;
+            if (act) {
+                qx += dx; qy += dy;
+                nx = qx + half; ny = qy + half;
+                const float d2 = dx * dx + dy * dy;
+                bool done = d2 < eps2_lo;
+                if (!done && d2 <= eps2_hi && (double)dx * (double)dx + (double)dy * (double)dy <= eps2) done = true;
+                if (!done && j > 0 && fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f) {
+                    nx -= dx * 0.5f; ny -= dy * 0.5f;
+                    done = true;
+                }
+                act = !done;
+                pdx = dx; pdy = dy;
+            }
+        }
+        if (l == 0) {
+            bool eact = solv && st != 0;
+            const float ex = nx - half, ey = ny - half;
+            const int iex = lkq_floor_i(ex), iey = lkq_floor_i(ey);
+            if (eact && (iex < -win || iex >= lw || iey < -win || iey >= lh)) { st = 0; eact = false; }
+            if (__builtin_amdgcn_ballot_w64(eact) != 0) {
+                const bool need = eact && (!jvalid || (unsigned)(iex - jx0) > 2u * LK_M || (unsigned)(iey - jy0) > 2u * LK_M);
+                if (__builtin_amdgcn_ballot_w64(need) != 0) { J_issue(iex, iey, need); J_commit(need); }
+                lk_weights(ex - (float)iex, ey - (float)iey, w00, w01, w10, w11);
+                const unsigned V0 = (unsigned)w00 | ((unsigned)w01 << 16), V1 = (unsigned)w10 | ((unsigned)w11 << 16);
+                J_read(iex, iey, eact);
+                int se = 0;
+#pragma unroll
+                for (int k = 0; k < 15; ++k) {
+                    const int diff = J_value(k, V0, V1) - pI[k];
+                    se += diff < 0 ? -diff : diff;
+                }
+                if (!(eact && rowact)) se = 0;
+                se = lkq_row_sum(se);
+                if (eact) errv = (float)se / (float)(32 * ww);
+            }
+        }
+    }
+    if (live && r == 0) {
+        next_pts[2 * pi] = nx; next_pts[2 * pi + 1] = ny;
+        status[pi] = (uint8_t)st;
+        err[pi] = st ? errv : 0.f;
+    }
+}
+
+
 void ofk_launch_lk(hipStream_t s, const uint8_t *prev, const uint8_t *next, size_t pyr_stride, const ofk_levels &lv,
                    const float *prev_pts, const int *counts, int pts_stride, int win, int max_count, double eps,
                    double min_eig_thr, float *next_pts, uint8_t *status, float *err, int batch)
@@ -583,7 +939,13 @@ void ofk_launch_lk(hipStream_t s, const uint8_t *prev, const uint8_t *next, size
     if (eps > 10) eps = 10;
     const double eps2 = eps * eps;
     dim3 grid(pts_stride, batch);
-    if (win <= 15)
+    // four points per wave when the window is the reference's 15 x 15 and every level allows dword rows with one reflection
+    bool quad = win == 15 && (pyr_stride & 3) == 0;
+    for (int l = 0; l <= lv.n; ++l) quad = quad && (lv.w[l] & 3) == 0 && lv.w[l] >= 64 && lv.h[l] >= 64 && (lv.off[l] & 3) == 0;
+    if (quad)
+        hipLaunchKernelGGL(k_lk15q, dim3((pts_stride + 3) / 4, batch), dim3(64), 0, s, prev, next, pyr_stride, lv, prev_pts, counts, pts_stride,
+                           max_count, eps2, (float)(eps2 * (1.0 - 1e-5)), (float)(eps2 * (1.0 + 1e-5)), min_eig_thr, next_pts, status, err);
+    else if (win <= 15)
         hipLaunchKernelGGL(k_lk15, grid, dim3(64), 0, s, prev, next, pyr_stride, lv, prev_pts, counts, pts_stride, win,
                            max_count, eps2, (float)(eps2 * (1.0 - 1e-5)), (float)(eps2 * (1.0 + 1e-5)), min_eig_thr, next_pts, status, err);
     else if (win <= 21)

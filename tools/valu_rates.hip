@@ -95,6 +95,14 @@
 #define A_PKSUB16(r) "v_pk_sub_i16 " r ", " r ", " r "\n"
 #define A_ADDF64(r) "v_add_f64 v[20:21], v[20:21], v[22:23]\n"
 #define A_CVTF64(r) "v_cvt_f64_i32 v[20:21], " r "\n"
+#define A_MADI16(r) "v_mad_i32_i16 " r ", " r ", " r ", " r " op_sel:[0,1,0,0]\n"
+#define A_CVTFLR(r) "v_cvt_flr_i32_f32 " r ", " r "\n"
+#define A_ADD_DPP_ROR(r) "v_add_u32_dpp " r ", " r ", " r " row_ror:4 row_mask:0xf bank_mask:0xf\n"
+#define A_ADD_DPP_RSHL(r) "v_add_u32_dpp " r ", " r ", " r " row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+#define A_DOT2C(r) "v_dot2c_i32_i16 " r ", " r ", " r "\n"
+#define A_MUL24_SDWA(r) "v_mul_i32_i24_sdwa " r ", " r ", " r " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_0\n"
+#define A_ADD_SDWA(r) "v_add_u32_sdwa " r ", " r ", " r " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n"
+#define A_ALIGNBYTE_V(r) "v_alignbyte_b32 " r ", " r ", " r ", %8\n"
 
 KERNEL(k_add, A_ADD)
 KERNEL(k_add3, A_ADD3)
@@ -160,6 +168,14 @@ KERNEL(k_mulsgpr, A_MULSGPR)
 KERNEL(k_floor, A_FLOOR)
 KERNEL(k_pkmad16, A_PKMAD16)
 KERNEL(k_pksub16, A_PKSUB16)
+KERNEL(k_madi16, A_MADI16)
+KERNEL(k_cvtflr, A_CVTFLR)
+KERNEL(k_add_dpp_ror, A_ADD_DPP_ROR)
+KERNEL(k_add_dpp_rshl, A_ADD_DPP_RSHL)
+KERNEL(k_dot2c, A_DOT2C)
+KERNEL(k_mul24_sdwa, A_MUL24_SDWA)
+KERNEL(k_add_sdwa, A_ADD_SDWA)
+KERNEL(k_alignbyte_v, A_ALIGNBYTE_V)
 
 int main()
 {
@@ -184,7 +200,10 @@ int main()
         {"v_cvt_f32_ubyte0", k_cvtub}, {"v_cvt_f32_u32", k_cvtu}, {"v_cvt_i32_f32", k_cvtrn}, {"v_dot2_i32_i16", k_dot2}, {"v_dot4_u32_u8", k_dot4},
         {"v_readlane_b32", k_readlane}, {"v_mbcnt_lo_u32_b32", k_mbcnt}, {"v_lshl_or_b32", k_lshlor}, {"v_and_or_b32", k_andor}, {"v_med3_i32", k_med3},
         {"v_min_f32", k_minf}, {"v_rsq_f32", k_rsq}, {"v_rcp_f32", k_rcp}, {"v_mul_f32 (sgpr src)", k_mulsgpr}, {"v_floor_f32", k_floor},
-        {"v_pk_mad_u16", k_pkmad16}, {"v_pk_sub_i16", k_pksub16}};
+        {"v_pk_mad_u16", k_pkmad16}, {"v_pk_sub_i16", k_pksub16},
+        {"v_mad_i32_i16 op_sel", k_madi16}, {"v_cvt_flr_i32_f32", k_cvtflr}, {"v_add_u32_dpp row_ror", k_add_dpp_ror},
+        {"v_add_u32_dpp row_shl", k_add_dpp_rshl}, {"v_dot2c_i32_i16 (VOP2)", k_dot2c}, {"v_mul_i32_i24_sdwa", k_mul24_sdwa},
+        {"v_add_u32_sdwa", k_add_sdwa}, {"v_alignbyte_b32 (vgpr shift)", k_alignbyte_v}};
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     double base = 0;
