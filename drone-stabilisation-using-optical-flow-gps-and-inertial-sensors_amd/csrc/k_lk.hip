@@ -939,9 +939,10 @@ void ofk_launch_lk(hipStream_t s, const uint8_t *prev, const uint8_t *next, size
     if (eps > 10) eps = 10;
     const double eps2 = eps * eps;
     dim3 grid(pts_stride, batch);
-    // four points per wave when the window is the reference's 15 x 15 and every level allows dword rows with one reflection
+    // four points per wave when the window is the reference's 15 x 15 and every level allows dword rows with ONE reflection
+    // (staged columns reach 27 past a border, staged rows 23: levels of at least 32 x 32)
     bool quad = win == 15 && (pyr_stride & 3) == 0;
-    for (int l = 0; l <= lv.n; ++l) quad = quad && (lv.w[l] & 3) == 0 && lv.w[l] >= 64 && lv.h[l] >= 64 && (lv.off[l] & 3) == 0;
+    for (int l = 0; l <= lv.n; ++l) quad = quad && (lv.w[l] & 3) == 0 && lv.w[l] >= 32 && lv.h[l] >= 32 && (lv.off[l] & 3) == 0;
     if (quad)
         hipLaunchKernelGGL(k_lk15q, dim3((pts_stride + 3) / 4, batch), dim3(64), 0, s, prev, next, pyr_stride, lv, prev_pts, counts, pts_stride,
                            max_count, eps2, (float)(eps2 * (1.0 - 1e-5)), (float)(eps2 * (1.0 + 1e-5)), min_eig_thr, next_pts, status, err);

@@ -232,3 +232,36 @@ def test_lk_1080p_500_points(gpu_ctx, pkg):
     pts = io.good_features(g0, 500, 0.01, 10, 7)
     gn, gs, ge = lk_equal(gpu_ctx, g0, g1, pts, win=15, max_level=3, max_count=20, eps=0.03)
     assert (gs == 1).mean() > 0.95
+
+
+def test_lk_quad_kernel_borders_and_dead_rows(gpu_ctx, pkg):
+    """k_lk15q (four points per wave): windows and staged regions over every border of a 1080p pair — mirrored columns are built
+    from the mirrored dwords, rows are reflected per lane — with point counts that leave rows of the last wave idle, and a next
+    frame shifted far enough that tracks leave the image and the staged region has to follow the window."""
+    g0 = textured(1080, 1920, 77, pkg)
+    g1 = np.roll(g0, (5, -12), axis=(0, 1))
+    h, w = g0.shape
+    rng = np.random.default_rng(5)
+    edge = []
+    for x in (-14.5, -3.25, 0, 0.5, 3.75, 7, 8.5, 12.25, 16, 23.5, 24, 27.75, 31.5):
+        for y in (-14, 0.25, 7.5, 19, 400.5):
+            edge += [[x, y], [w - 1 - x, y], [x, h - 1 - y], [w - 1 - x, h - 1 - y], [y, x], [w - 1 - y, h - 1 - x]]
+    pts = np.array(edge + rng.uniform([-10, -10], [w + 10, h + 10], (203, 2)).tolist(), np.float32).reshape(-1, 1, 2)
+    for n in (len(pts), 1, 2, 3, 5):
+        lk_equal(gpu_ctx, g0, g1, pts[:n], win=15, max_level=3, max_count=30, eps=0.01)
+    lk_equal(gpu_ctx, g0, np.roll(g0, (-40, 60), axis=(0, 1)), pts, win=15, max_level=1, max_count=30, eps=0.01)   # long walks at a fine level
+
+
+def test_lk_quad_kernel_full_contrast(gpu_ctx):
+    """Window sums beyond int32: binary noise puts A11, A22 above the Cauchy-Schwarz limit of the 32-bit tree (and a step edge
+    pattern puts them above 2^31), so the mismatch sums and A12 go through the split reduction."""
+    rng = np.random.default_rng(9)
+    noise = (rng.integers(0, 2, (256, 320)) * 255).astype(np.uint8)
+    stripes = np.zeros((256, 320), np.uint8); stripes[:, (np.arange(320) // 2) % 2 == 1] = 255; stripes[::9] ^= 255   # |Ix| = 4080 nearly everywhere
+    checker = (((np.add.outer(np.arange(256), np.arange(320)) // 2) & 1) * 255).astype(np.uint8)                      # diagonal: A12 ~ A11 > 2^31
+    pts = rng.uniform([5, 5], [315, 250], (64, 2)).astype(np.float32).reshape(-1, 1, 2)
+    for img in (noise, stripes, checker):
+        for shift in ((0, 0), (1, -1), (0, 2)):
+            gn, gs, ge = lk_equal(gpu_ctx, img, np.roll(img, shift, axis=(0, 1)), pts, win=15, max_level=2, max_count=20, eps=0.03)
+    mixed = noise.copy(); mixed[:, 160:] = (rng.integers(0, 256, (256, 160)) // 4 + 96).astype(np.uint8)      # both paths inside one wave
+    lk_equal(gpu_ctx, mixed, np.roll(mixed, (1, 1), axis=(0, 1)), pts, win=15, max_level=2, max_count=20, eps=0.03)
