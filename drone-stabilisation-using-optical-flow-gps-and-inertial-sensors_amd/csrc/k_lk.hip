@@ -612,6 +612,14 @@ __device__ __forceinline__ int lkq_floor_i(float x)
     asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));               // floor + convert in one instruction
     return r;
 }
+// a.lo * w.lo + a.hi * w.hi + c with the rounding constant c in an SGPR: the VOP2 form the compiler picks (v_dot2c) accumulates in
+// place and needs a v_mov of the constant first
+__device__ __forceinline__ int lkq_dot2_k(unsigned a, unsigned w, int c)
+{
+    int d;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(w), "s"(c));
+    return d;
+}
 __device__ __forceinline__ int lkq_mad_lo(int a, unsigned packed, int acc)     // acc + a.lo16 * packed.lo16
 {
     int d;
@@ -644,24 +652,38 @@ __device__ __forceinline__ float lkq_row_sum_split_u(unsigned v)
     const int lo = lkq_row_sum((int)(v & 0xffffu)), hi = lkq_row_sum((int)(v >> 16));
     return (float)((double)(((long long)hi << 16) + lo) * 0x1p-20);
 }
-// ND aligned dwords of one image row starting at column A (multiple of 4, any sign): reflect-101 columns
+// Staging of one image row into LDS as ND raw aligned dwords from column A (multiple of 4, any sign), reflect-101 columns.
+// The loads always come from inside the row: the strip of ND dwords at Sb = clamp(A, 0, lw - 4 ND).  Interior rows (Sb == A)
+// store dword j at slot j.  A row over a border stores dword j at slot j + (Sb - A) / 4 when that is inside the staged row, and
+// fills the outside slots with mirrored dwords: the dword at virtual column X < 0 is bytes n[-X], n[-X-1], n[-X-2], n[-X-3] — one
+// v_perm of strip dwords j = -X/4 and j-1 — and X >= lw likewise from the strip at the right edge.  Slot positions are per-lane LDS
+// addresses, so no register is indexed by a lane-varying amount; writes that fall outside go to a dump slot.
 template <int ND>
-__device__ __forceinline__ void lkq_load_row(const uint8_t *rowp, int lw, int A, bool border, unsigned (&d)[ND])
+__device__ __forceinline__ void lkq_load_row(const uint8_t *rowp, int lw, int A, unsigned (&d)[ND])
 {
-    if (!border) {                                                      // wave-uniform
-        const unsigned *g = reinterpret_cast<const unsigned *>(rowp + A);
+    const unsigned *g = reinterpret_cast<const unsigned *>(rowp + min(max(A, 0), lw - 4 * ND));
 #pragma unroll
-        for (int i = 0; i < ND; ++i) d[i] = g[i];
-    } else {
+    for (int i = 0; i < ND; ++i) d[i] = g[i];
+}
+template <int ND>
+__device__ __forceinline__ void lkq_store_row(unsigned *o, unsigned *dump, int lw, int A, bool border, const unsigned (&d)[ND])
+{
+    if (!border) {                                                      // wave-uniform: no lane of the wave is over a border
 #pragma unroll
-        for (int i = 0; i < ND; ++i) {
-            const int X = A + 4 * i;
-            int lo = X, hi = X;
-            unsigned sel = 0x03020100u;
-            if (X < 0) { lo = -X - 4; hi = -X; sel = 0x01020304u; }                        // bytes n[-X], n[-X-1], n[-X-2], n[-X-3]
-            else if (X >= lw) { hi = 2 * lw - 4 - X; lo = hi - 4; sel = 0x03040506u; }     // bytes n[c], n[c-1], n[c-2], n[c-3], c = 2 lw - 2 - X
-            const unsigned vlo = *reinterpret_cast<const unsigned *>(rowp + lo), vhi = *reinterpret_cast<const unsigned *>(rowp + hi);
-            d[i] = __builtin_amdgcn_perm(vhi, vlo, sel);
+        for (int i = 0; i < ND; ++i) o[i] = d[i];
+        return;
+    }
+    const bool left = A < 0, right = A + 4 * ND > lw;
+    const int dpos = min(max(A, 0), lw - 4 * ND) - A;                   // byte position of strip dword 0 in the staged row
+    const unsigned msel = left ? 0x01020304u : 0x03040506u;
+    const int mbase = left ? -A : right ? lw + 4 * (ND - 1) - A : -1;   // mirrored dword of strip pair (j, j-1) sits at mbase - 4 j
+#pragma unroll
+    for (int j = 0; j < ND; ++j) {
+        const int pos = dpos + 4 * j;
+        *((unsigned)pos < 4u * ND ? o + (pos >> 2) : dump) = d[j];
+        if (j > 0) {
+            const int mpos = mbase - 4 * j;
+            *((unsigned)mpos < 4u * ND ? o + (mpos >> 2) : dump) = __builtin_amdgcn_perm(d[j], d[j - 1], msel);
         }
     }
 }
@@ -676,8 +698,10 @@ __global__ __launch_bounds__(64) void k_lk15q(const uint8_t *__restrict__ prev, 
     constexpr float half = 7.f;
     __shared__ __attribute__((aligned(16))) uint8_t s_I[4 * LKQ_ISZ];
     __shared__ __attribute__((aligned(16))) uint8_t s_J[4 * LKQ_JSZ];
+    __shared__ unsigned s_dump[64];                                // where the staging writes of slots outside a row go (one word per lane)
 
     const int lane = threadIdx.x, g = lane >> 4, r = lane & 15;
+    unsigned *dump = s_dump + lane;
     int b = blockIdx.y, chunk = blockIdx.x;                        // XCD-aware map as in k_lk15: the points of an image stay on one XCD
     if ((gridDim.y & 7) == 0) {
         const unsigned n = blockIdx.y * gridDim.x + blockIdx.x, k = n >> 3;
@@ -697,7 +721,6 @@ __global__ __launch_bounds__(64) void k_lk15q(const uint8_t *__restrict__ prev, 
     int st = 1;
     float errv = 0.f, nx = 0.f, ny = 0.f;
     unsigned pxy[15];                                              // (Ix, Iy) of the lane's pixels, int16 pairs
-    int pI[15];
 
     for (int l = lv.n; l >= 0; --l) {
         const int lh = lv.h[l], lw = lv.w[l];
@@ -715,26 +738,27 @@ __global__ __launch_bounds__(64) void k_lk15q(const uint8_t *__restrict__ prev, 
 
         int jx0 = 0, jy0 = 0, jA = 0;
         bool jvalid = false;
+        // The next-frame region of the lanes that are `on`: rows jy0 + r and jy0 + r + 16 from column jA.  At the start of a level
+        // both rows are loaded before the first wait (J_issue / J_commit around the prev-frame staging); a re-staging inside the
+        // Newton loop (the window walked out of the region: rare) goes row by row to keep 9 registers fewer alive in the loop.
         unsigned jd[2][9];
-        auto J_issue = [&](int iqx, int iqy, bool on) {
-            if (on) { jx0 = iqx - LK_M; jy0 = iqy - LK_M; jA = jx0 & ~3; }
-            const bool border = __builtin_amdgcn_ballot_w64(on && (jA < 0 || jA + 36 > lw)) != 0;
-            if (on) {
-                lkq_load_row<9>(J + (size_t)lkq_reflect(jy0 + r, lh) * lw, lw, jA, border, jd[0]);
-                lkq_load_row<9>(J + (size_t)lkq_reflect(jy0 + r + 16, lh) * lw, lw, jA, border, jd[1]);
-            }
+        auto J_place = [&](int iqx, int iqy, bool on) {
+            if (on) { jx0 = iqx - LK_M; jy0 = iqy - LK_M; jA = jx0 & ~3; jvalid = true; }
         };
-        auto J_commit = [&](bool on) {
+        auto J_load = [&](int h, bool on) {
+            if (on) lkq_load_row<9>(J + (size_t)lkq_reflect(jy0 + r + 16 * h, lh) * lw, lw, jA, jd[h]);
+        };
+        auto J_store = [&](int h, bool on, bool border) {
+            if (on) lkq_store_row<9>(reinterpret_cast<unsigned *>(sJ + (r + 16 * h) * LKQ_JP), dump, lw, jA, border, jd[h]);
+        };
+        auto J_border = [&](bool on) { return __builtin_amdgcn_ballot_w64(on && (jA < 0 || jA + 36 > lw)) != 0; };
+        auto J_restage = [&](int iqx, int iqy, bool on) {
+            J_place(iqx, iqy, on);
+            const bool border = J_border(on);
             LDS_FENCE();                                                  // earlier readers of s_J are done
-            if (on) {
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    unsigned *o = reinterpret_cast<unsigned *>(sJ + (r + 16 * h) * LKQ_JP);
-#pragma unroll
-                    for (int i = 0; i < 9; ++i) o[i] = jd[h][i];
-                }
-                jvalid = true;
-            }
+            J_load(0, on); J_store(0, on, border);
+            LDS_FENCE();
+            J_load(1, on); J_store(1, on, border);
             LDS_FENCE();
         };
         // ---- staging: prev neighbourhood rows ipy-1 .. ipy+16 (lane r: row r; lanes 0, 1 also rows 16, 17), columns from
@@ -744,25 +768,42 @@ __global__ __launch_bounds__(64) void k_lk15q(const uint8_t *__restrict__ prev, 
             const bool iborder = __builtin_amdgcn_ballot_w64(lev && (iA < 0 || iA + 24 > lw)) != 0;
             unsigned id0[6], id1[6];
             if (lev) {
-                lkq_load_row<6>(I + (size_t)lkq_reflect(ipy - 1 + r, lh) * lw, lw, iA, iborder, id0);
-                if (r < 2) lkq_load_row<6>(I + (size_t)lkq_reflect(ipy + 15 + r, lh) * lw, lw, iA, iborder, id1);
+                lkq_load_row<6>(I + (size_t)lkq_reflect(ipy - 1 + r, lh) * lw, lw, iA, id0);
+                if (r < 2) lkq_load_row<6>(I + (size_t)lkq_reflect(ipy + 15 + r, lh) * lw, lw, iA, id1);
             }
             const int iqx = lkq_floor_i(qx), iqy = lkq_floor_i(qy);
             const bool doJ = lev && !(iqx < -win || iqx >= lw || iqy < -win || iqy >= lh);
-            J_issue(iqx, iqy, doJ);
-            LDS_FENCE();                                                  // the previous level's readers of s_I are done
+            J_place(iqx, iqy, doJ);
+            J_load(0, doJ); J_load(1, doJ);
+            LDS_FENCE();                                                  // the previous level's readers of s_I and s_J are done
             if (lev) {
-                unsigned *o = reinterpret_cast<unsigned *>(sI + r * LKQ_IP);
-#pragma unroll
-                for (int i = 0; i < 6; ++i) o[i] = id0[i];
-                if (r < 2) {
-                    unsigned *o1 = reinterpret_cast<unsigned *>(sI + (r + 16) * LKQ_IP);
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) o1[i] = id1[i];
-                }
+                lkq_store_row<6>(reinterpret_cast<unsigned *>(sI + r * LKQ_IP), dump, lw, iA, iborder, id0);
+                if (r < 2) lkq_store_row<6>(reinterpret_cast<unsigned *>(sI + (r + 16) * LKQ_IP), dump, lw, iA, iborder, id1);
             }
-            J_commit(doJ);
+            const bool jborder = J_border(doJ);
+            J_store(0, doJ, jborder); J_store(1, doJ, jborder);
+            LDS_FENCE();
         }
+        // taps of the lane's window row: two LDS rows (pitch `pitch`) from byte offset `off` of `base`, 5 raw dwords each, and the
+        // byte-pair selectors; value k = interpolated pixel k with 5 fractional bits (descale by 9 of the four weighted taps)
+        unsigned jr0[5], jr1[5], jsel[4];
+        auto taps_read = [&](const uint8_t *base, unsigned off, int pitch) {
+            const unsigned *q = reinterpret_cast<const unsigned *>(base + (off & ~3u));
+#pragma unroll
+            for (int i = 0; i < 5; ++i) { jr0[i] = q[i]; jr1[i] = q[i + pitch / 4]; }
+            const unsigned shs = (off & 3u) | ((off & 3u) << 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) jsel[i] = LK_PAIR_SEL(i) + shs;
+        };
+        auto tap_value = [&](int k, unsigned W0_, unsigned W1_) {
+            return lk_dot2(__builtin_amdgcn_perm(jr0[(k >> 2) + 1], jr0[k >> 2], jsel[k & 3]), W0_,
+                           lkq_dot2_k(__builtin_amdgcn_perm(jr1[(k >> 2) + 1], jr1[k >> 2], jsel[k & 3]), W1_, 1 << 8)) >> 9;
+        };
+        auto J_read = [&](int ix_, int iy_, bool on) {
+            taps_read(sJ, on && rowact ? __umul24((unsigned)(iy_ - jy0 + r), LKQ_JP) + (unsigned)(ix_ - jA) : 0u, LKQ_JP);
+        };
+        // previous-frame window row r: neighbourhood rows r+1, r+2 from column 1
+        auto I_read = [&]() { taps_read(sI, (unsigned)((r + 1) * LKQ_IP + ((ipx - 1) & 3) + 1), LKQ_IP); };
         // ---- patch.  Neighbourhood rows r, r+1, r+2 -> derivative row r (16 columns); window row r = derivative rows r, r+1.
         int w00, w01, w10, w11;
         lk_weights(px - (float)ipx, py - (float)ipy, w00, w01, w10, w11);
@@ -814,18 +855,21 @@ __global__ __launch_bounds__(64) void k_lk15q(const uint8_t *__restrict__ prev, 
                 const unsigned qx_ = (k & 1) ? __builtin_amdgcn_alignbit(DX[(k + 1) >> 1], DX[k >> 1], 16) : DX[k >> 1];
                 const unsigned qy_ = (k & 1) ? __builtin_amdgcn_alignbit(DY[(k + 1) >> 1], DY[k >> 1], 16) : DY[k >> 1];
                 // own derivative row with the upper weights; the lower-weight half comes from the lane below (row r + 1)
-                const int hx = lk_dot2(qx_, W0, 1 << 13), gx = lk_dot2(qx_, W1, 0);
-                const int hy = lk_dot2(qy_, W0, 1 << 13), gy = lk_dot2(qy_, W1, 0);
+                const int hx = lkq_dot2_k(qx_, W0, 1 << 13), gx = lk_dot2(qx_, W1, 0);
+                const int hy = lkq_dot2_k(qy_, W0, 1 << 13), gy = lk_dot2(qy_, W1, 0);
                 const int ix = (hx + __builtin_amdgcn_update_dpp(0, gx, 0x101, 0xF, 0xF, true)) >> 14;     // row_shl:1
                 const int iy = (hy + __builtin_amdgcn_update_dpp(0, gy, 0x101, 0xF, 0xF, true)) >> 14;
-                const int iv = lk_dot2(pair(1, k + 1), W0, lk_dot2(pair(2, k + 1), W1, 1 << 8)) >> 9;
-                const bool on = lev && rowact;
-                pI[k] = iv;
-                pxy[k] = on ? __builtin_amdgcn_perm((unsigned)iy, (unsigned)ix, 0x05040100u) : 0u;
+                pxy[k] = lev && rowact ? __builtin_amdgcn_perm((unsigned)iy, (unsigned)ix, 0x05040100u) : 0u;
                 a11 += (unsigned)__mul24(ix, ix); a12 += __mul24(ix, iy); a22 += (unsigned)__mul24(iy, iy);
-                c1 += __mul24(iv, ix); c2 += __mul24(iv, iy);
             }
-            if (!(lev && rowact)) { a11 = 0; a12 = 0; a22 = 0; c1 = 0; c2 = 0; }
+            if (!(lev && rowact)) { a11 = 0; a12 = 0; a22 = 0; }
+        }
+        // c = sum(I * Ix), sum(I * Iy) over the lane's row: the constant part of the mismatch sums (pxy is zero on idle lanes)
+        I_read();
+#pragma unroll
+        for (int k = 0; k < 15; ++k) {
+            const int iv = tap_value(k, W0, W1);
+            c1 = lkq_mad_lo(iv, pxy[k], c1); c2 = lkq_mad_hi(iv, pxy[k], c2);
         }
         const unsigned A11u = (unsigned)lkq_row_sum((int)a11), A22u = (unsigned)lkq_row_sum((int)a22);
         float A12 = (float)lkq_row_sum(a12) * 0x1p-20f;
@@ -842,22 +886,6 @@ __global__ __launch_bounds__(64) void k_lk15q(const uint8_t *__restrict__ prev, 
         if (lev && !solv && l == 0) st = 0;
         D = 1.f / D;
 
-        // taps of the lane's window row at integer position (ix_, iy_): 2 x 5 raw dwords and the byte-pair selectors
-        unsigned jr0[5], jr1[5], jsel[4];
-        auto J_read = [&](int ix_, int iy_, bool on) {
-            const int off = on && rowact ? (iy_ - jy0 + r) * LKQ_JP + (ix_ - jA) : 0;
-            const unsigned *q = reinterpret_cast<const unsigned *>(sJ + (off & ~3));
-#pragma unroll
-            for (int i = 0; i < 5; ++i) { jr0[i] = q[i]; jr1[i] = q[i + LKQ_JP / 4]; }
-            const unsigned shs = ((unsigned)off & 3u) * 0x00010001u;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) jsel[i] = LK_PAIR_SEL(i) + shs;
-        };
-        auto J_value = [&](int k, unsigned W0_, unsigned W1_) {       // interpolated next-frame pixel k, 5 fractional bits
-            return lk_dot2(__builtin_amdgcn_perm(jr0[(k >> 2) + 1], jr0[k >> 2], jsel[k & 3]), W0_,
-                           lk_dot2(__builtin_amdgcn_perm(jr1[(k >> 2) + 1], jr1[k >> 2], jsel[k & 3]), W1_, 1 << 8)) >> 9;
-        };
-
         bool act = solv;
         float pdx = 0.f, pdy = 0.f;
         for (int j = 0; j < max_count; ++j) {
@@ -868,14 +896,14 @@ __global__ __launch_bounds__(64) void k_lk15q(const uint8_t *__restrict__ prev, 
                 act = false;
             }
             const bool need = act && (!jvalid || (unsigned)(iqx - jx0) > 2u * LK_M || (unsigned)(iqy - jy0) > 2u * LK_M);
-            if (__builtin_amdgcn_ballot_w64(need) != 0) { J_issue(iqx, iqy, need); J_commit(need); }
+            if (__builtin_amdgcn_ballot_w64(need) != 0) J_restage(iqx, iqy, need);
             lk_weights(qx - (float)iqx, qy - (float)iqy, w00, w01, w10, w11);
             const unsigned V0 = (unsigned)w00 | ((unsigned)w01 << 16), V1 = (unsigned)w10 | ((unsigned)w11 << 16);
             J_read(iqx, iqy, act);
             int b1 = -c1, b2 = -c2;
 #pragma unroll
             for (int k = 0; k < 15; ++k) {
-                const int jv = J_value(k, V0, V1);
+                const int jv = tap_value(k, V0, V1);
                 b1 = lkq_mad_lo(jv, pxy[k], b1); b2 = lkq_mad_hi(jv, pxy[k], b2);
             }
             float fb1 = (float)lkq_row_sum(b1) * 0x1p-20f, fb2 = (float)lkq_row_sum(b2) * 0x1p-20f;
@@ -905,14 +933,20 @@ __global__ __launch_bounds__(64) void k_lk15q(const uint8_t *__restrict__ prev, 
             if (eact && (iex < -win || iex >= lw || iey < -win || iey >= lh)) { st = 0; eact = false; }
             if (__builtin_amdgcn_ballot_w64(eact) != 0) {
                 const bool need = eact && (!jvalid || (unsigned)(iex - jx0) > 2u * LK_M || (unsigned)(iey - jy0) > 2u * LK_M);
-                if (__builtin_amdgcn_ballot_w64(need) != 0) { J_issue(iex, iey, need); J_commit(need); }
+                if (__builtin_amdgcn_ballot_w64(need) != 0) J_restage(iex, iey, need);
                 lk_weights(ex - (float)iex, ey - (float)iey, w00, w01, w10, w11);
                 const unsigned V0 = (unsigned)w00 | ((unsigned)w01 << 16), V1 = (unsigned)w10 | ((unsigned)w11 << 16);
+                // the previous-frame values are recomputed from the staged neighbourhood (level 0 is still in s_I): keeping them in
+                // registers through the Newton loop would cost 15 VGPRs for one use per point
+                int pv[15];
+                I_read();
+#pragma unroll
+                for (int k = 0; k < 15; ++k) pv[k] = tap_value(k, W0, W1);
                 J_read(iex, iey, eact);
                 int se = 0;
 #pragma unroll
                 for (int k = 0; k < 15; ++k) {
-                    const int diff = J_value(k, V0, V1) - pI[k];
+                    const int diff = tap_value(k, V0, V1) - pv[k];
                     se += diff < 0 ? -diff : diff;
                 }
                 if (!(eact && rowact)) se = 0;
@@ -940,9 +974,9 @@ void ofk_launch_lk(hipStream_t s, const uint8_t *prev, const uint8_t *next, size
     const double eps2 = eps * eps;
     dim3 grid(pts_stride, batch);
     // four points per wave when the window is the reference's 15 x 15 and every level allows dword rows with ONE reflection
-    // (staged columns reach 27 past a border, staged rows 23: levels of at least 32 x 32)
+    // (staged columns reach 27 past a border, staged rows 23, and the 36-byte strip of a row has to fit: levels of at least 40 x 32)
     bool quad = win == 15 && (pyr_stride & 3) == 0;
-    for (int l = 0; l <= lv.n; ++l) quad = quad && (lv.w[l] & 3) == 0 && lv.w[l] >= 32 && lv.h[l] >= 32 && (lv.off[l] & 3) == 0;
+    for (int l = 0; l <= lv.n; ++l) quad = quad && (lv.w[l] & 3) == 0 && lv.w[l] >= 40 && lv.h[l] >= 32 && (lv.off[l] & 3) == 0;
     if (quad)
         hipLaunchKernelGGL(k_lk15q, dim3((pts_stride + 3) / 4, batch), dim3(64), 0, s, prev, next, pyr_stride, lv, prev_pts, counts, pts_stride,
                            max_count, eps2, (float)(eps2 * (1.0 - 1e-5)), (float)(eps2 * (1.0 + 1e-5)), min_eig_thr, next_pts, status, err);

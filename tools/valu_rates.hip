@@ -102,6 +102,7 @@
 #define A_DOT2C(r) "v_dot2c_i32_i16 " r ", " r ", " r "\n"
 #define A_MUL24_SDWA(r) "v_mul_i32_i24_sdwa " r ", " r ", " r " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_0\n"
 #define A_ADD_SDWA(r) "v_add_u32_sdwa " r ", " r ", " r " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n"
+#define A_DOT2_S(r) "v_dot2_i32_i16 " r ", " r ", " r ", s10\n"
 #define A_ALIGNBYTE_V(r) "v_alignbyte_b32 " r ", " r ", " r ", %8\n"
 
 KERNEL(k_add, A_ADD)
@@ -176,6 +177,7 @@ KERNEL(k_dot2c, A_DOT2C)
 KERNEL(k_mul24_sdwa, A_MUL24_SDWA)
 KERNEL(k_add_sdwa, A_ADD_SDWA)
 KERNEL(k_alignbyte_v, A_ALIGNBYTE_V)
+KERNEL(k_dot2_s, A_DOT2_S)
 
 int main()
 {
@@ -203,7 +205,8 @@ int main()
         {"v_pk_mad_u16", k_pkmad16}, {"v_pk_sub_i16", k_pksub16},
         {"v_mad_i32_i16 op_sel", k_madi16}, {"v_cvt_flr_i32_f32", k_cvtflr}, {"v_add_u32_dpp row_ror", k_add_dpp_ror},
         {"v_add_u32_dpp row_shl", k_add_dpp_rshl}, {"v_dot2c_i32_i16 (VOP2)", k_dot2c}, {"v_mul_i32_i24_sdwa", k_mul24_sdwa},
-        {"v_add_u32_sdwa", k_add_sdwa}, {"v_alignbyte_b32 (vgpr shift)", k_alignbyte_v}};
+        {"v_add_u32_sdwa", k_add_sdwa}, {"v_alignbyte_b32 (vgpr shift)", k_alignbyte_v},
+        {"v_dot2_i32_i16 (sgpr acc)", k_dot2_s}};
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     double base = 0;
