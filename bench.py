@@ -57,11 +57,28 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 from __graft_entry__ import load_package  # noqa: E402
 
+
+class _stdout_to_stderr:
+    """File descriptor 1 points at stderr inside the block (C stdio of loaded libraries included): stdout stays ONE JSON line."""
+
+    def __enter__(self):
+        import ctypes
+        self._libc = ctypes.CDLL(None)
+        sys.stdout.flush(); self._libc.fflush(None)
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush(); self._libc.fflush(None)
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
 H, W = 1080, 1920
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 2.0      # 1228.8 G wave-instr/s: wave64 VALU = 2 clocks on a SIMD-32, 1024 SIMDs, 2.4 GHz
 PROFILE_TAG = "r02"          # profiles/<tag>_traffic_pmc.json, _valu_pmc.json, _isa_mix.json (tools/profile_round.sh)
-KERNEL_OF = {"gray": "k_gray_bgr8", "pyr": "k_pyr3_stream", "eig": "k_mineig_pair<7,false>", "select": "k_select", "lk": "k_lk15",
+KERNEL_OF = {"gray": "k_gray_bgr8", "pyr": "k_pyr3_stream", "eig": "k_mineig_pair<7,false>", "select": "k_select", "lk": "k_lk15q",
              "solve": "k_pairs_solve", "nms": "-"}
 
 
@@ -238,7 +255,8 @@ def main():
     # The exchange: RCCL through the library (no torch in the process).  Step k's records are exported and all-gathered on the
     # library's own stream right behind step k's solve (receive slot k % 2), so the host only queues work: step k+1 is
     # launched while step k's gather travels.  K steps issue K gathers inside the timed region.
-    comm = sharding.Comm(pipe.ctx, rank, world, n_comms=max(1, args.streams)) if launched else None
+    with _stdout_to_stderr():                                    # librccl prints a version banner on stdout at communicator init
+        comm = sharding.Comm(pipe.ctx, rank, world, n_comms=max(1, args.streams)) if launched else None
 
     def sync_all():
         if comm is not None:

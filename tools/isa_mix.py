@@ -6,7 +6,7 @@
 1. hipcc -S (device only, the product's flags) of k_corners.hip and k_lk.hip.
 2. k_mineig_pair<7,false>: the main loop holds 7 unrolled rows twice (border version, interior version; 2 v_sqrt_f32 per row).
    The INTERIOR version (the one almost every row of a 1080p frame runs) is the half of the loop body with fewer instructions;
-   its instructions are counted per mnemonic.  k_lk15: the whole kernel body (level set-up + Newton loop).
+   its instructions are counted per mnemonic.  k_lk15q: the whole kernel body (level set-up + Newton loop).
 3. Every VALU mnemonic is priced with its measured issue cost (tools/valu_rates.hip on the GPU box: ns per wave-instruction
    per SIMD with 8 waves per SIMD, converted to clocks at the clock the probe ran at = cost relative to v_add_u32 x 2).
 4. issue floor per pair = (dynamic wave-level VALU instructions per pair, SQ_INSTS_VALU from the committed PMC pass)
@@ -56,7 +56,7 @@ def mnemonics(lines):
         m = INSTR.match(l)
         if m:
             name, rest = m.group(1), m.group(2)
-            dpp = ("_dpp" in name) or any(k in rest for k in ("wave_shr", "wave_shl", "row_shr", "row_shl", "quad_perm", "row_mirror", "row_half_mirror", "row_bcast"))
+            dpp = ("_dpp" in name) or any(k in rest for k in ("wave_shr", "wave_shl", "row_shr", "row_shl", "quad_perm", "row_mirror", "row_half_mirror", "row_bcast", "row_ror"))
             ops = rest.split(";")[0].split(",")
             sgpr = any(re.match(r"^\s*-?\|?s\d+|^\s*s\[", o) for o in ops[1:])      # a source operand in an SGPR
             out.append((name, dpp, sgpr))
@@ -164,9 +164,10 @@ def main():
     m["valu_issue_cycles_per_pair"] = int(dyn * m["mean_cycles_per_valu_instr"])
     out["stages"]["eig"] = m
     lk = asm_of("k_lk.hip")
-    body = body_of(lk, next(l.split(":")[0] for l in lk if l.startswith("_Z6k_lk15")))
+    body = body_of(lk, next(l.split(":")[0] for l in lk if l.startswith("_Z7k_lk15q")))
     m = mix(mnemonics(body), rates)
-    m["scope"] = "whole body of k_lk15 (level set-up + Newton loop + error pass), static counts"
+    m["scope"] = ("whole body of k_lk15q (level set-up + Newton loop + error pass), static counts; the border-staging and split-reduction "
+                  "blocks are in the count although they rarely run")
     dyn = valu["stages"]["lk"]["SQ_INSTS_VALU_per_launch"] / valu["batch"]
     m["SQ_INSTS_VALU_per_pair"] = int(dyn)
     m["valu_issue_cycles_per_pair"] = int(dyn * m["mean_cycles_per_valu_instr"])
