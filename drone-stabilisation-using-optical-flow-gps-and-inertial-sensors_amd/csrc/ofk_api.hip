@@ -236,6 +236,16 @@ static int drain_all(ofk_ctx *c)
     return OFK_OK;
 }
 
+int ofk_resident_pyramid(ofk_ctx *c, int frame_set, int image, uint8_t *out, size_t bytes)
+{
+    if (!c || !out || frame_set < 0 || frame_set > 1 || image < 0 || image >= c->max_batch || bytes > c->pyr_stride)
+        return ofk_fail(c, OFK_E_INVALID, "resident pyramid: frame set 0/1, image < max_batch, at most one slab (%zu bytes)", c ? c->pyr_stride : (size_t)0);
+    TRY(drain_all(c));
+    const uint8_t *base = (c->pyr_last && c->pyr_alt[frame_set]) ? c->pyr_alt[frame_set] : c->pyr[frame_set];
+    OFK_HIP(c, hipMemcpy(out, base + (size_t)image * c->pyr_stride, bytes, hipMemcpyDeviceToHost));
+    return OFK_OK;
+}
+
 int ofk_need_scratch(ofk_ctx *c, size_t bytes)
 {
     if (bytes <= c->scratch_bytes) return OFK_OK;
@@ -843,6 +853,7 @@ extern "C" int ofk_pairs_run(ofk_ctx *c, const ofk_params *p)
     }
     int set = 0;
     if (overlap) { set = c->pyr_set; c->pyr_set ^= 1; }
+    c->pyr_last = set;
     uint8_t *const P0 = set ? c->pyr_alt[0] : c->pyr[0], *const P1 = set ? c->pyr_alt[1] : c->pyr[1];
     // Slices are forked off the context's stream once and then free-run over consecutive calls: nothing joins them until an
     // entry point needs the context's stream to see their results (join_slices).  On the fork the response kernels are chained
@@ -986,6 +997,7 @@ static int stream_alloc(ofk_ctx *c)
 static int stream_ingest(ofk_ctx *c, int k, const uint8_t *bgr, int batch, int h, int w, const ofk_levels &lv)
 {
     if (bgr) TRY(h2d(c, c->bgr[k], c->bgr_stride, bgr, (size_t)h * w * 3, batch));      // NULL: the frames are in bgr[k] already (JPEG ingest)
+    c->pyr_last = 0;
     ofk_launch_gray(c->stream, c->bgr[k], c->bgr_stride, c->pyr[k], c->pyr_stride, batch, h, w);
     for (int l = ofk_launch_pyr3(c->stream, c->pyr[k], nullptr, c->pyr_stride, lv, batch, batch) ? 4 : 1; l <= lv.n; ++l)
         ofk_launch_pyr_down(c->stream, c->pyr[k] + lv.off[l - 1], c->pyr_stride, lv.h[l - 1], lv.w[l - 1], c->pyr[k] + lv.off[l],

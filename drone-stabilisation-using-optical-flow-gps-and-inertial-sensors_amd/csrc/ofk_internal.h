@@ -29,6 +29,7 @@ struct ofk_ctx {
     hipStream_t aux[OFK_MAX_STREAMS]; int overlap;        // per-slice auxiliary stream: next-frame gray + pyramids beside the response kernel
     hipEvent_t ev_g0[OFK_MAX_STREAMS], ev_aux[OFK_MAX_STREAMS];
     uint8_t *pyr_alt[2]; int pyr_set;                     // second pyramid set: the auxiliary stream runs one call ahead
+    int pyr_last;                                         // the set the latest ofk_pairs_run built its pyramids in (ofk_resident_pyramid)
     hipEvent_t ev_lkdone[2][OFK_MAX_STREAMS];             // LK of the call that last read a set has finished
     hipEvent_t marks[8];                                  // ofk_mark / ofk_mark_wait
     // Slices free-run across consecutive ofk_pairs_run calls (no fork/join per call) and are offset by one response kernel, so

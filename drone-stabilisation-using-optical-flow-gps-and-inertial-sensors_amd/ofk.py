@@ -29,7 +29,7 @@ SYMBOLS = (
     "ofk_post_solve", "ofk_kf_predict_update", "ofk_of_simulation", "ofk_feas_simulation", "ofk_hist_overlap", "ofk_associate_sensors", "ofk_feature_eval", "ofk_d_split", "ofk_pairs_upload", "ofk_pairs_upload_jpeg", "ofk_jpeg_info", "ofk_jpeg_decode_bgr8", "ofk_pairs_set_sensors",
     "ofk_pairs_run", "ofk_pairs_download", "ofk_pairs_export_records_f32", "ofk_stream_begin", "ofk_stream_step",
     "ofk_stream_begin_jpeg", "ofk_stream_step_jpeg",
-    "ofk_set_streams", "ofk_set_overlap", "ofk_mark", "ofk_mark_wait", "ofk_profile_enable", "ofk_profile_read",
+    "ofk_set_streams", "ofk_set_overlap", "ofk_mark", "ofk_mark_wait", "ofk_profile_enable", "ofk_profile_read", "ofk_resident_pyramid",
     "ofk_imu_reset", "ofk_imu_push", "ofk_imu_state", "ofk_filter_configure", "ofk_filter_state", "ofk_stream_step_fused",
     "ofk_stream_step_fused_jpeg", "ofk_stream_last_points", "ofk_pairs_filter_step",
     "ofk_comm_unique_id", "ofk_comm_init", "ofk_comm_destroy", "ofk_comm_rank", "ofk_comm_world", "ofk_comm_gather_records",
@@ -139,6 +139,7 @@ def load_library():
         L.ofk_mark.argtypes = [vp, i]; L.ofk_mark_wait.argtypes = [vp, i]
         L.ofk_profile_enable.argtypes = [vp, i]
         L.ofk_profile_read.argtypes = [vp, vp, vp]
+        L.ofk_resident_pyramid.argtypes = [vp, i, i, vp, C.c_size_t]
         L.ofk_comm_unique_id.argtypes = [vp, i]; L.ofk_comm_init.argtypes = [vp, vp, i, i, i]; L.ofk_comm_destroy.argtypes = [vp]
         L.ofk_comm_rank.argtypes = [vp]; L.ofk_comm_world.argtypes = [vp]
         L.ofk_comm_gather_records.argtypes = [vp, i, i]; L.ofk_comm_fetch_records.argtypes = [vp, i, i, vp]
@@ -754,6 +755,19 @@ class Context:
 
     def profile_enable(self, mask):
         self._ck(self._L.ofk_profile_enable(self._h, int(mask)))
+
+    def resident_pyramid(self, frame_set, image, h, w, levels):
+        """The resident pyramid of one image (frame set 0 = previous, 1 = next frames of the latest pairs batch, or the stream
+        loop's slot): list of uint8 arrays, level 0 = the gray frame."""
+        shapes, offs, off = [], [], 0
+        for l in range(levels + 1):
+            shapes.append((h, w)); offs.append(off)
+            off += (h * w + 255) // 256 * 256
+            h, w = (h + 1) // 2, (w + 1) // 2
+        buf = np.empty(off, np.uint8)
+        with self._lock:
+            self._ck(self._L.ofk_resident_pyramid(self._h, int(frame_set), int(image), _p(buf), buf.size))
+        return [buf[o:o + a * b].reshape(a, b).copy() for (a, b), o in zip(shapes, offs)]
 
     def profile_read(self):
         ms = np.zeros(len(STAGES), np.float64); n = np.zeros(len(STAGES), np.int32)

@@ -388,6 +388,12 @@ int ofk_profile_enable(ofk_ctx *ctx, int stage_mask);   /* bit s set: bracket st
 /* Sums the events recorded since the last call (synchronises the stream). ms_total and launches have OFK_N_STAGES entries. */
 int ofk_profile_read(ofk_ctx *ctx, double *ms_total, int *launches);
 
+/* Inspection: the resident pyramid slab of one image — frame set 0 (previous frames) or 1 (next frames) of the latest
+ * ofk_pairs_run / ofk_pairs_upload batch, or pyramid slot 0/1 of the stream loop — copied to the host: level 0 (the gray image
+ * cvtColor would return, of_module.py:86) at offset 0, level l at the offset ofk_pyramid_u8 reports (256-byte aligned levels,
+ * tight rows), `bytes` bytes from the start of the slab.  Synchronises every stream of the context. */
+int ofk_resident_pyramid(ofk_ctx *ctx, int frame_set, int image, uint8_t *out, size_t bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -224,3 +224,28 @@ def test_profile_and_export(pkg, ofk):
     # once per frame of the pair (the two conversions are separate launches on the auxiliary stream)
     assert all(prof[s][1] == (6 if s == "gray" else 3) and prof[s][0] > 0 for s in ofk.STAGES if s != "nms") and prof["nms"][1] == 0
     pipe.close()
+
+
+@pytest.mark.parametrize("h,w,streams", [(1080, 1920, 1), (1080, 1920, 2), (480, 640, 1), (264, 2064, 1), (270, 480, 1)])
+def test_resident_pyramids_after_a_pairs_run(pkg, ofk, h, w, streams):
+    """The gray level and every pyramid level ofk_pairs_run leaves in HBM, byte for byte against cvtColor + pyrDown of the oracle:
+    the three-levels-in-one-pass kernel (w % 16 == 0, h % 8 == 0; one, two and three strips; several chunks) and the per-level path
+    (270 x 480), with one stream and with two free-running slices (double-buffered pyramid sets), twice in a row."""
+    from of_amd.pipeline import FlowPipeline, PipelineConfig
+    rng = np.random.default_rng(h + w)
+    batch = 4
+    cfg = PipelineConfig.baseline_1080p()
+    prev = rng.integers(0, 256, (batch, h, w, 3), dtype=np.uint8)
+    nxt = rng.integers(0, 256, (batch, h, w, 3), dtype=np.uint8)
+    prev[1, :, : w // 2] = 255; nxt[2, h // 3:] = 0                                    # saturated and black regions
+    sensors = ofk.make_sensors(batch, d=1.0, normal=(0, 0, 1), omega=(0, 0, 0), scaling=1e-3, cx=w / 2, cy=h / 2)
+    pipe = FlowPipeline(w, h, batch, cfg, streams=streams)
+    pipe.upload(prev, nxt, sensors)
+    for _ in range(2):
+        pipe.run()
+        for b in range(batch):
+            for fs, frames in ((0, prev), (1, nxt)):
+                ref = io.pyramid(io.gray_bgr8(frames[b]), cfg.win, cfg.max_level)
+                got = pipe.ctx.resident_pyramid(fs, b, h, w, len(ref) - 1)
+                for l, (g, r) in enumerate(zip(got, ref)):
+                    assert np.array_equal(g, r), f"image {b} frame set {fs} level {l}: {np.argwhere(g != r)[:4]}"
