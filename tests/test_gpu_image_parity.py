@@ -265,3 +265,20 @@ def test_lk_quad_kernel_full_contrast(gpu_ctx):
             gn, gs, ge = lk_equal(gpu_ctx, img, np.roll(img, shift, axis=(0, 1)), pts, win=15, max_level=2, max_count=20, eps=0.03)
     mixed = noise.copy(); mixed[:, 160:] = (rng.integers(0, 256, (256, 160)) // 4 + 96).astype(np.uint8)      # both paths inside one wave
     lk_equal(gpu_ctx, mixed, np.roll(mixed, (1, 1), axis=(0, 1)), pts, win=15, max_level=2, max_count=20, eps=0.03)
+
+
+def test_lk_quad_kernel_smallest_levels(gpu_ctx, pkg):
+    """The four-point kernel at the smallest geometry it accepts (coarsest level 40 x 32: one reflection has to cover staged rows 23
+    and staged columns 27 past the border, and the 36-byte strip of a row nearly spans the level), points on and beyond every border."""
+    g0 = textured(256, 320, 91, pkg)
+    g1 = np.roll(g0, (3, -4), axis=(0, 1))
+    rng = np.random.default_rng(17)
+    h, w = g0.shape
+    grid = np.array([[x, y] for x in (-14, -6.5, 0, 3.25, 9, 40.5, w / 2, w - 41, w - 10.5, w - 4, w - 1, w + 5.5, w + 13)
+                     for y in (-13, -2.5, 0, 7.75, 31, h / 2, h - 33, h - 8.25, h - 1, h + 6, h + 12.5)], np.float32)
+    pts = np.concatenate([grid, rng.uniform([-14, -14], [w + 14, h + 14], (97, 2)).astype(np.float32)]).reshape(-1, 1, 2)
+    lk_equal(gpu_ctx, g0, g1, pts, win=15, max_level=3, max_count=30, eps=0.01)
+    lk_equal(gpu_ctx, g0, np.roll(g0, (-9, 11), axis=(0, 1)), pts, win=15, max_level=3, max_count=30, eps=0.01)
+    # one level narrower than the kernel accepts: the one-wave-per-point kernel takes over, same answers required
+    g2 = textured(256, 312, 92, pkg)
+    lk_equal(gpu_ctx, g2, np.roll(g2, (2, 2), axis=(0, 1)), pts[:64], win=15, max_level=3, max_count=30, eps=0.01)
