@@ -329,17 +329,19 @@ struct p3_args {
     int h, w, batch, steps, nstrips, nchunks;
 };
 
-__global__ __launch_bounds__(256) void k_pyr3_stream(p3_args A)
+// One WAVE per workgroup: beside the response kernel (3 x 168 VGPRs per SIMD) a 256-thread workgroup has to wait until all four
+// SIMDs of a CU have 96 registers free at the same moment; a single wave moves in as soon as one response wave retires
+// (2.28 -> 2.22 ms per step at B = 256; alone on the chip the pass is 10 % slower — tools/experiments/hbm_wg.sh).
+__global__ __launch_bounds__(64) void k_pyr3_stream(p3_args A)
 {
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x;
     int bx = blockIdx.x, z = blockIdx.y;
     if ((gridDim.y & 7) == 0) {                                 // XCD-aware: an image's chunks on one XCD (see k_pyr_down_stream)
         const unsigned n = blockIdx.y * gridDim.x + blockIdx.x, k = n >> 3;
         z = 8 * (int)(k / gridDim.x) + (int)(n & 7);
         bx = (int)(k % gridDim.x);
     }
-    const int wid = __builtin_amdgcn_readfirstlane(bx * 4 + (threadIdx.x >> 6));
-    if (wid >= A.nstrips * A.nchunks) return;
+    const int wid = bx;
     const int strip = wid % A.nstrips, chunk = wid / A.nstrips;
     const int h = A.h, w = A.w, n1 = h >> 1, n2 = h >> 2, n3 = h >> 3, w1 = w >> 1, w2 = w >> 2, w3 = w >> 3;
     const uint8_t *img = (z < A.batch ? A.base0 + (size_t)z * A.stride : A.base1 + (size_t)(z - A.batch) * A.stride);
@@ -430,8 +432,8 @@ bool ofk_launch_pyr3(hipStream_t s, uint8_t *pyr0, uint8_t *pyr1, size_t stride,
     int steps = ((total + nchunks - 1) / nchunks + 3) / 4 * 4;
     nchunks = (total + steps - 1) / steps;
     p3_args A = {pyr0, pyr1 ? pyr1 : pyr0, stride, lv.off[1], lv.off[2], lv.off[3], h, w, batch, steps, nstrips, nchunks};
-    dim3 grid((nstrips * nchunks + 3) / 4, images);
-    hipLaunchKernelGGL(k_pyr3_stream, grid, dim3(256), 0, s, A);
+    dim3 grid(nstrips * nchunks, images);
+    hipLaunchKernelGGL(k_pyr3_stream, grid, dim3(64), 0, s, A);
     return true;
 }
 
