@@ -1,6 +1,8 @@
-// k_lk.hip — pyramidal Lucas-Kanade (cv2.calcOpticalFlowPyrLK semantics), one wavefront per point.  gfx950.
-//
-// A 64-thread workgroup (= one wave) tracks one point through all pyramid levels, coarse to fine:
+// k_lk.hip — pyramidal Lucas-Kanade (cv2.calcOpticalFlowPyrLK semantics).  gfx950.
+//   k_lk15q   the pipeline's kernel: 15 x 15 window, FOUR points per wave (a 16-lane DPP row per point) — see its own header below;
+//   k_lk15    windows <= 15 on levels too small or too oddly sized for k_lk15q: one wave per point, lane = (row, 4-pixel segment);
+//   k_lk<W>   windows up to 21 / 31: one wave per point, generic.
+// Common to all three: a 64-thread workgroup (= one wave) tracks its point(s) through all pyramid levels, coarse to fine:
 //   * the (win+3)^2 neighbourhood of the previous-frame level is staged into LDS, the Scharr derivatives of its
 //     (win+1)^2 core are computed there (never materialised in HBM), and each lane keeps its <= NPL window
 //     pixels (I, Ix, Iy as int16) in registers;
@@ -645,11 +647,6 @@ __device__ __forceinline__ int lkq_row_sum(int v)
 __device__ __forceinline__ float lkq_row_sum_split(int v)
 {
     const int lo = lkq_row_sum(v & 0xffff), hi = lkq_row_sum(v >> 16);
-    return (float)((double)(((long long)hi << 16) + lo) * 0x1p-20);
-}
-__device__ __forceinline__ float lkq_row_sum_split_u(unsigned v)
-{
-    const int lo = lkq_row_sum((int)(v & 0xffffu)), hi = lkq_row_sum((int)(v >> 16));
     return (float)((double)(((long long)hi << 16) + lo) * 0x1p-20);
 }
 // Staging of one image row into LDS as ND raw aligned dwords from column A (multiple of 4, any sign), reflect-101 columns.
