@@ -152,7 +152,7 @@ def main():
                     "dynamic SQ_INSTS_VALU per pair (PMC) x mean issue clocks per instruction of that mix.",
            "rates_source": os.path.relpath(args.rates, ROOT) if rates else "defaults (round-1 measurements, DESIGN.md §4)",
            "valu_source": os.path.relpath(args.valu, ROOT) if os.path.exists(args.valu) else "profiles/r01_valu_pmc.json", "stages": {}}
-    corners = asm_of("k_corners.hip", ["-fno-slp-vectorize"])
+    corners = asm_of("k_corners.hip", ["-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp"])   # the Makefile's flags for this file
     body = body_of(corners, "_Z13k_mineig_pairILi7ELb0EEvPKhmiiiffPjS1_mdPyiPiS4_")
     rows, which = pair_interior_rows(body)
     m = mix(mnemonics(rows), rates)
