@@ -1257,9 +1257,14 @@ __global__ __launch_bounds__(SEL_T) void k_select(unsigned long long *__restrict
         __syncthreads();
         if (tid == 0) s_n = 0;
         __syncthreads();
-        for (int i = tid; i < C; i += SEL_T) {
-            const unsigned long long key = cand[i];
-            if (key >= a && key < T) { const int slot = atomicAdd(&s_n, 1); if (slot < OFK_CHUNK) s_key[slot] = key; }
+        // four independent loads in flight per thread (the loop is latency-bound: 45 trips over 46 k candidates at 1080p)
+        for (int i0 = tid; i0 < C; i0 += 4 * SEL_T) {
+            unsigned long long key[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int i = i0 + q * SEL_T; key[q] = i < C ? cand[i] : ~0ull; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (key[q] >= a && key[q] < T) { const int slot = atomicAdd(&s_n, 1); if (slot < OFK_CHUNK) s_key[slot] = key[q]; }
         }
         __syncthreads();
         const int n = min(s_n, OFK_CHUNK);
@@ -1321,17 +1326,22 @@ __global__ __launch_bounds__(SEL_T) void k_select(unsigned long long *__restrict
                 for (int q = 0; q < SEL_T / 64; ++q) r |= s_rej[q];
                 const unsigned long long alive = __ballot(live) & ~r;   // survivors of the accepted-set test, best first
                 const unsigned long long myconf = use_dist ? s_conf[lane] : 0ull;   // lanes clashing with candidate `lane`
-                // the serial greedy pass over <= 64 candidates runs on the scalar unit
-                unsigned long long acc = 0, al = alive;
-                int room = max_corners - nacc;
-                const unsigned clo = (unsigned)myconf, chi = (unsigned)(myconf >> 32);
-                while (al && room > 0) {
-                    const int i = __ffsll((long long)al) - 1;
-                    acc |= 1ull << i; --room;
-                    const unsigned long long ci_ = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)chi, i) << 32) |
-                                                   (unsigned)__builtin_amdgcn_readlane((int)clo, i);
-                    al &= ~(ci_ | (1ull << i));
+                // Greedy acceptance in rank order, a few parallel sweeps instead of one scalar step per candidate: U = candidates not
+                // decided yet, with everything that clashes with an accepted one already removed.  A lane whose earlier clashing
+                // lanes are all decided is accepted in this sweep (the lowest undecided lane always is); the accepted lanes and
+                // whatever clashes with them (the matrix is symmetric and has its diagonal set) leave U.  Decisions only depend on
+                // earlier lanes, so the result is that of the sequential pass, and its first `room` members are what the sequential
+                // pass would have accepted before running out of room.
+                const unsigned long long lower = (1ull << lane) - 1ull;
+                unsigned long long U = alive, A = 0;
+                while (U) {
+                    const bool join = ((U >> lane) & 1ull) && (myconf & U & lower) == 0ull;
+                    const unsigned long long J = __ballot(join);
+                    A |= J;
+                    U &= ~(__ballot((myconf & J) != 0ull) | J);
                 }
+                const int room = max_corners - nacc;
+                const unsigned long long acc = __ballot(((A >> lane) & 1ull) && __popcll(A & lower) < room);
                 if ((acc >> lane) & 1ull) {                      // accepted candidates store in parallel, in rank order
                     const int pos = nacc + __popcll(acc & ((1ull << lane) - 1));
                     s_acc_xy[pos] = cx | (cy << 16);
