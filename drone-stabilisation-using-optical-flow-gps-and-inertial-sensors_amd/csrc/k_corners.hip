@@ -1367,15 +1367,32 @@ __global__ __launch_bounds__(SEL_T) void k_select(unsigned long long *__restrict
     if (tid == 0) counts[b] = s_nacc;
 }
 
+// Zeroes the three per-image arrays a detection step starts from (response maxima, candidate counters, key histogram) in ONE launch:
+// three hipMemsetAsync calls are three fill kernels with a dependency gap each on the critical chain of a step.
+__global__ __launch_bounds__(256) void k_zero_detect_state(unsigned *__restrict__ a, int na, unsigned *__restrict__ b, int nb, unsigned *__restrict__ c, int nc)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < na) { a[i] = 0u; return; }
+    i -= na;
+    if (i < nb) { b[i] = 0u; return; }
+    i -= nb;
+    if (i < nc) c[i] = 0u;
+}
+void ofk_launch_zero_detect_state(hipStream_t s, unsigned int *maxbits, int *cand_count, unsigned *sel_hist, int batch)
+{
+    const int na = batch * OFK_MAX_STRIDE, nb = batch * OFK_CNT_STRIDE, nc = sel_hist ? batch * SEL_HB : 0;
+    hipLaunchKernelGGL(k_zero_detect_state, dim3((na + nb + nc + 255) / 256), dim3(256), 0, s, maxbits, na, reinterpret_cast<unsigned *>(cand_count), nb, sel_hist, nc);
+}
+
 void ofk_launch_select(hipStream_t s, unsigned long long *cand, int cand_cap, int *cand_count, const unsigned long long *seg,
                        int seg_cap, const int *seg_count, int nseg, const unsigned int *maxbits, double quality, int w,
                        int max_corners, float min_distance, float *pts, int pts_stride, int *counts, const int *limit, int batch,
-                       unsigned *sel_hist)
+                       unsigned *sel_hist, bool hist_is_zero)
 {
     static_assert(SEL_T == SEL_HB, "k_select reads one histogram bin per thread");
     const bool prep = nseg > 0 && sel_hist != nullptr;          // segments from the streaming response kernels: compact + histogram on SEL_G workgroups per image
     if (prep) {
-        hipMemsetAsync(sel_hist, 0, (size_t)batch * SEL_HB * sizeof(unsigned), s);
+        if (!hist_is_zero) hipMemsetAsync(sel_hist, 0, (size_t)batch * SEL_HB * sizeof(unsigned), s);
         hipLaunchKernelGGL(k_select_prep, dim3(SEL_G, batch), dim3(256), 0, s, cand, cand_cap, cand_count, seg, seg_cap, seg_count, nseg, maxbits,
                            quality, sel_hist, limit);
     }

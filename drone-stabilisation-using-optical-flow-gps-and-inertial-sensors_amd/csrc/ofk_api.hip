@@ -903,8 +903,7 @@ extern "C" int ofk_pairs_run(ofk_ctx *c, const ofk_params *p)
         if (fork && k > 0) OFK_HIP(c, hipStreamWaitEvent(st, c->ev_stagger[k - 1], 0));
         {
             StageTimer t(c, OFK_STAGE_EIG, st);                  // response + 3x3 NMS + candidate keys, no map in HBM
-            OFK_HIP(c, hipMemsetAsync(maxbits, 0, (size_t)nb * OFK_MAX_STRIDE * 4, st));
-            OFK_HIP(c, hipMemsetAsync(cand_count, 0, (size_t)nb * OFK_CNT_STRIDE * 4, st));
+            ofk_launch_zero_detect_state(st, maxbits, cand_count, c->sel_hist + (size_t)b0 * 1024, nb);   // one launch, histogram of the selection included
             if (ofk_launch_mineig_cand(st, pyr0, c->pyr_stride, h, w, p->block_size, maxbits, nullptr, 0, p->quality, cand, c->cand_cap,
                                        cand_count, cand_seg, c->seg_keys, seg_count, OFK_SEG_MAX, c->dev_flags, nb, &nseg, &segcap))
                 return ofk_fail(c, OFK_E_INVALID, "corner response: block_size %d does not fit (LDS tile / key segments)", p->block_size);
@@ -913,7 +912,7 @@ extern "C" int ofk_pairs_run(ofk_ctx *c, const ofk_params *p)
         {
             StageTimer t(c, OFK_STAGE_SELECT, st);
             ofk_launch_select(st, cand, c->cand_cap, cand_count, cand_seg, segcap, seg_count, nseg, maxbits, p->quality, w, p->max_corners,
-                              (float)p->min_distance, pts_prev, c->max_pts, counts, nullptr, nb, c->sel_hist + (size_t)b0 * 1024);
+                              (float)p->min_distance, pts_prev, c->max_pts, counts, nullptr, nb, c->sel_hist + (size_t)b0 * 1024, true);
         }
         if (overlap) OFK_HIP(c, hipStreamWaitEvent(st, c->ev_aux[k], 0));    // LK needs both pyramids
         {

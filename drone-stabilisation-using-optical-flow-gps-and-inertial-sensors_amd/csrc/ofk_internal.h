@@ -125,7 +125,8 @@ void ofk_stream_geometry(int h, int w, int block, int batch, int *rows, int *nse
 void ofk_launch_select(hipStream_t s, unsigned long long *cand, int cand_cap, int *cand_count, const unsigned long long *seg,
                        int seg_cap, const int *seg_count, int nseg, const unsigned int *maxbits, double quality, int w,
                        int max_corners, float min_distance, float *pts, int pts_stride, int *counts, const int *limit, int batch,
-                       unsigned *sel_hist);                     // [batch][1024] scratch of the multi-workgroup prefilter (NULL: single-workgroup path)
+                       unsigned *sel_hist, bool hist_is_zero = false);
+void ofk_launch_zero_detect_state(hipStream_t s, unsigned int *maxbits, int *cand_count, unsigned *sel_hist, int batch);                     // [batch][1024] scratch of the multi-workgroup prefilter (NULL: single-workgroup path)
 void ofk_launch_disc_mask(hipStream_t s, uint8_t *mask, size_t mask_stride, int h, int w, const float *pts, const int *counts,
                           int pts_stride, int radius, const int *limit, int batch);
 void ofk_launch_redetect_limits(hipStream_t s, const int *counts, int min_feat, int max_feat, int *limit, int batch);
