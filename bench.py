@@ -272,12 +272,16 @@ def main():
     run_steps(args.warmup, 0)
     sync_all()
     pipe.ctx.profile_read()
-    pipe.ctx.profile_enable(0x7f)
+    pipe.ctx.profile_enable(0)                                   # the timed region runs without stage brackets (two event records per stage and slice)
     sync_all()
     t0 = time.perf_counter()
     run_steps(args.steps, args.warmup)
     sync_all()
     dt = time.perf_counter() - t0
+    # the same K steps once more under the same schedule with every stage bracketed by events: the `stages` object (outside the timed region)
+    pipe.ctx.profile_enable(0x7f)
+    run_steps(args.steps, args.warmup + args.steps)
+    sync_all()
     prof = pipe.ctx.profile_read()
     pipe.ctx.profile_enable(0)
     # Outside the timed region: the same K steps once more with every stage serial on one stream, so that each kernel's
@@ -298,8 +302,8 @@ def main():
 
     if comm is not None:
         dt = comm.max(dt)
-        last = (args.warmup + args.steps - 1) % 2
-        gathered = comm.fetch(B, last)                             # [world, B, 8] f32 of the last timed step, every rank's records
+        last = (args.warmup + 2 * args.steps - 1) % 2
+        gathered = comm.fetch(B, last)                             # [world, B, 8] f32 of the last gathered step, every rank's records
 
     out = pipe.ctx.pairs_download(points=False)
     rec = out["records"]
@@ -365,6 +369,8 @@ def main():
                                  "traffic": (pmc_traffic("pyr", iso_pairs) or 0) + (pmc_traffic("lk", iso_pairs) or 0) or None,
                                  "note": "LK is bound by VALU issue, not HBM (stages_isolated.lk, roofline of stage lk in DESIGN.md §4)"},
             "pipeline_algorithmic_GBps": round(sum(ab.values()) * world * B * args.steps / dt / 1e9, 1),
+            # event brackets of every stage from K more steps of the SAME schedule run right after the timed region (the timed steps
+            # carry no stage events): under overlap a bracket includes the other streams' kernels, it is not a kernel duration
             "stages": stages,
             # every stage alone on the chip (serial pass outside the timed region) and the HBM-bound group BASELINE.json's
             # target names (pyramid construction; LK itself is VALU-bound)
