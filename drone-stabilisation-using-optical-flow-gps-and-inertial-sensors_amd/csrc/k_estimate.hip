@@ -65,12 +65,23 @@ __device__ __forceinline__ double block_minmax(double v, bool want_max, double *
     return want_max ? fmax(a, b) : fmin(a, b);
 }
 
-__device__ void acc_block_sum(Acc &a, double *s_red)
+// All eleven sums at once: the wave reductions are independent shuffle chains the scheduler interleaves, and ONE LDS exchange
+// (two barriers) replaces eleven; the order of the additions is block_sum's, so the results are the same bit for bit.
+__device__ void acc_block_sum(Acc &a, double *)
 {
-    a.m00 = block_sum(a.m00, s_red); a.m01 = block_sum(a.m01, s_red); a.m02 = block_sum(a.m02, s_red);
-    a.m11 = block_sum(a.m11, s_red); a.m12 = block_sum(a.m12, s_red); a.m22 = block_sum(a.m22, s_red);
-    a.g0 = block_sum(a.g0, s_red); a.g1 = block_sum(a.g1, s_red); a.g2 = block_sum(a.g2, s_red);
-    a.bb = block_sum(a.bb, s_red); a.cnt = block_sum(a.cnt, s_red);
+    __shared__ double s_part[4][11];
+    double v[11] = {a.m00, a.m01, a.m02, a.m11, a.m12, a.m22, a.g0, a.g1, a.g2, a.bb, a.cnt};
+#pragma unroll
+    for (int k = 0; k < 11; ++k) v[k] = wave_sum(v[k]);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 11; ++k) s_part[threadIdx.x >> 6][k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 11; ++k) v[k] = (s_part[0][k] + s_part[1][k]) + (s_part[2][k] + s_part[3][k]);
+    a.m00 = v[0]; a.m01 = v[1]; a.m02 = v[2]; a.m11 = v[3]; a.m12 = v[4]; a.m22 = v[5]; a.g0 = v[6]; a.g1 = v[7]; a.g2 = v[8]; a.bb = v[9]; a.cnt = v[10];
 }
 
 // Cyclic Jacobi on a symmetric 3x3; eigenvalues descending in lam[], eigenvectors in columns of V.
