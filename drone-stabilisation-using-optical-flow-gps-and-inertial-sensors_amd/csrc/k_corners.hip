@@ -603,6 +603,21 @@ __device__ __forceinline__ int lambda_min_bits(int vxx, int vxy, int vyy, float 
 // (Measured and dropped: the same formula on float PAIRS — v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 — executes 11 fewer
 //  instructions per row and is 10 % SLOWER: plain f32 add/mul/fma issue at twice the rate of the packed and VOP3 forms,
 //  tools/valu_rates.hip.)
+// Full 64-key chunks of the wave's key buffer to its segment.  At the top of every block of rows and in front of every second row
+// inside one: a row adds at most SW keys, so with fewer than 64 keys held two rows later there are fewer than 64 + 2 SW = NBUF.
+#define OFK_PAIR_SPILL_KEYS()                                                                                          \
+    {                                                                                                                  \
+        const int nchunk = cnt >> 6;                                                                                   \
+        for (int q = 0; q < nchunk; ++q) {                                                                             \
+            const unsigned long long key = buf[q * 64 + lane];                                                         \
+            if (written + q * 64 + lane < seg_cap) myseg[written + q * 64 + lane] = key;                               \
+        }                                                                                                              \
+        written += nchunk * 64;                                                                                        \
+        const unsigned long long rest = buf[nchunk * 64 + lane];                                                       \
+        __builtin_amdgcn_wave_barrier();                                                                               \
+        buf[lane] = rest;                                                                                              \
+        cnt -= nchunk * 64;                                                                                            \
+    }
 // One block of BS rows (expanded twice: IN = true for interior blocks); see OFK_EIG_ROWS for the conventions.
 #define OFK_PAIR_ROWS(IN)                                                                                             \
     _Pragma("unroll") for (int i = 0; i < BS; ++i) {                                                                   \
@@ -611,7 +626,9 @@ __device__ __forceinline__ int lambda_min_bits(int vxx, int vxy, int vyy, float 
         if (!(IN)) {                                                                                                   \
             if (edge_strip) { ge2 = __builtin_amdgcn_ds_bpermute(mir_e, ge2); go2 = __builtin_amdgcn_ds_bpermute(mir_o, go2); } \
         }                                                                                                              \
-        const int oyye = s_ring[(2 * i) * 64 + lane], oyyo = s_ring[(2 * i + 1) * 64 + lane];   /* the yy box sums of BS rows ago (LDS ring) */ \
+        if (i > 0 && (i & 1) == 0 && cnt >= 64) OFK_PAIR_SPILL_KEYS()                                                  \
+        const int oyye = s_ring[(4 * i) * 64 + lane], oyyo = s_ring[(4 * i + 1) * 64 + lane];      /* the yy and xy box sums of BS rows ago (LDS ring) */ \
+        const int oxye = s_ring[(4 * i + 2) * 64 + lane], oxyo = s_ring[(4 * i + 3) * 64 + lane];                      \
         const int r12e = g1e + ge2, r12o = g1o + go2;              /* Sobel column sums from row-pair sums: s = (g0+g1) + (g1+g2), */ \
         const int se = r01e + r12e, so = r01o + r12o, te = r12e - r01e, to = r12o - r01o;   /* t = g2 - g0 = (g1+g2) - (g0+g1): three full-rate adds */ \
         const int nso = -so, nse = -se, tt = te + to;                                                                  \
@@ -632,10 +649,11 @@ __device__ __forceinline__ int lambda_min_bits(int vxx, int vxy, int vyy, float 
         box_pair<BS / 2>(pxxe, pxxo, ad2, ad3, hxxe, hxxo);                                                            \
         box_pair<BS / 2>(pxye, pxyo, ad2, ad3, hxye, hxyo);                                                            \
         box_pair<BS / 2>(pyye, pyyo, ad2, ad3, hyye, hyyo);                                                            \
-        vxxe += hxxe - rxxe[i]; vxye += hxye - rxye[i]; vyye += hyye - oyye;                                           \
-        vxxo += hxxo - rxxo[i]; vxyo += hxyo - rxyo[i]; vyyo += hyyo - oyyo;                                           \
-        rxxe[i] = hxxe; rxye[i] = hxye; rxxo[i] = hxxo; rxyo[i] = hxyo;                                                \
-        s_ring[(2 * i) * 64 + lane] = hyye; s_ring[(2 * i + 1) * 64 + lane] = hyyo;                                    \
+        vxxe += hxxe - rxxe[i]; vxye += hxye - oxye; vyye += hyye - oyye;                                              \
+        vxxo += hxxo - rxxo[i]; vxyo += hxyo - oxyo; vyyo += hyyo - oyyo;                                              \
+        rxxe[i] = hxxe; rxxo[i] = hxxo;                                                                                \
+        s_ring[(4 * i) * 64 + lane] = hyye; s_ring[(4 * i + 1) * 64 + lane] = hyyo;                                    \
+        s_ring[(4 * i + 2) * 64 + lane] = hxye; s_ring[(4 * i + 3) * 64 + lane] = hxyo;                                \
         const int yo = ya - 2 + r - BS;                                                                                \
         const int e2e = lambda_min_bits(vxxe, vxye, vyye, kdv), e2o = lambda_min_bits(vxxo, vxyo, vyyo, kdv);    \
         if ((IN) && !MASK) {                                                                                           \
@@ -677,8 +695,7 @@ template <int BS> struct pair_geom {
     static constexpr int AN = BS / 2, PAD = (2 + AN + 3) & ~3, D = PAD - 2 - AN, SW = (125 - BS) & ~3;
 };
 
-// BS = 7 needs 42 ring values per lane, 28 of them in registers: 150 VGPRs = 3 waves per SIMD (with all 42 in registers: 168; a 4th
-// wave spills 43 dwords and runs 1.65x slower; two waves per SIMD, forced by padding the LDS, 1.35x slower)
+// BS = 7 needs 42 ring values per lane; 14 stay in registers, 28 live in LDS (see s_ring)
 // One WAVE per workgroup.  With four strips per 256-thread workgroup a 1080p frame (17 strips) left every fifth workgroup
 // with one live wave: its three dead waves' register slots could not host another workgroup (4 x 168 VGPRs) until the live wave
 // had marched down its 540 rows, and the 2560 workgroups of a 256-frame launch made 3.33 rounds over the chip's 768 slots.
@@ -693,13 +710,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
     static_assert(BS == 3 || BS == 5 || BS == 7, "pair sums are written for odd boxes up to 7");
     constexpr int AN = pair_geom<BS>::AN, PAD = pair_geom<BS>::PAD, D = pair_geom<BS>::D, SW = pair_geom<BS>::SW;
     constexpr int L0 = (BS + 1) / 2, L1 = (BS + 1 + SW) / 2;    // lanes [L0, L1) hold output columns (both slots)
-    constexpr int NBUF = 64 + BS * SW;                          // keys a wave can hold between two flush points
+    constexpr int NBUF = 64 + 2 * SW;                           // keys a wave can hold: fewer than 64 after a spill check + two rows (OFK_PAIR_SPILL_KEYS)
     __shared__ unsigned long long s_buf[NBUF + 64];             // + 64: a flush reads one whole 64-key chunk past the count
-    // The vertical ring of the yy box-row sums lives in LDS (the xx and xy rings stay in registers): 14 VGPRs fewer = 150 instead of 168,
-    // i.e. 3 x 152 = 456 of a SIMD's 512, so a 32-register gray wave moves in beside three response waves without keeping one of them
-    // out.  The kernel alone is no faster (1.03 ms); the step is 2.4 % shorter.  (A second ring would fit the registers of a pyramid
-    // wave too, but not the LDS: the key buffer takes 7.5 KB of the 13 KB a wave may have at three waves per SIMD.)
-    __shared__ int s_ring[2 * BS * 64];
+    // The vertical rings of the yy and xy box-row sums live in LDS (the xx ring stays in registers) and the key buffer holds two rows'
+    // worth of keys instead of a block's: 125 VGPRs and 10 KB of LDS per wave = FOUR waves per SIMD (all 42 ring values in
+    // registers: 168 VGPRs, three waves).  Alone on the chip 1.03 -> 0.96 ms; with the yy ring only (150 VGPRs, three waves, room
+    // for a gray wave beside them) the kernel alone was no faster but the step 2.4 % shorter — four waves are another 1 % on top.
+    __shared__ int s_ring[4 * BS * 64];
     const int lane = threadIdx.x;
     // XCD-aware block -> (image, chunk, strip block) map: workgroups are dealt round-robin over the 8 XCDs (blocks n and
     // n + 8 share one L2); an image's strips and chunks go to ONE XCD, so the halo columns and rows they share are fetched once.
@@ -762,9 +779,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
     float kdv = kd;
     asm volatile("" : "+v"(kdv));                               // keep the scale factor in a VGPR (see lambda_min_bits)
     int r01e = 0, r01o = 0, g1e = 0, g1o = 0;                   // previous gray row and the sum of the two before it (per slot)
-    int rxxe[BS], rxye[BS], rxxo[BS], rxyo[BS];
+    int rxxe[BS], rxxo[BS];
 #pragma unroll
-    for (int i = 0; i < BS; ++i) { rxxe[i] = rxye[i] = rxxo[i] = rxyo[i] = 0; s_ring[(2 * i) * 64 + lane] = 0; s_ring[(2 * i + 1) * 64 + lane] = 0; }
+    for (int i = 0; i < BS; ++i) { rxxe[i] = rxxo[i] = 0; }
+#pragma unroll
+    for (int i = 0; i < 4 * BS; ++i) s_ring[i * 64 + lane] = 0;
     int vxxe = 0, vxye = 0, vyye = 0, vxxo = 0, vxyo = 0, vyyo = 0;
     int e1e = 0, e1o = 0, hm0e = 0, hm0o = 0, hm1e = 0, hm1o = 0;
     int nextg[NL];
@@ -780,16 +799,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
             thr = (float)((double)__uint_as_float(cur_seen) * quality);
         }
         if (cnt >= 64) {                                        // move full 64-key chunks to this strip's segment, publish the maximum
-            const int nchunk = cnt >> 6;
-            for (int q = 0; q < nchunk; ++q) {
-                const unsigned long long key = buf[q * 64 + lane];
-                if (written + q * 64 + lane < seg_cap) myseg[written + q * 64 + lane] = key;
-            }
-            written += nchunk * 64;
-            const unsigned long long rest = buf[nchunk * 64 + lane];
-            __builtin_amdgcn_wave_barrier();
-            buf[lane] = rest;
-            cnt -= nchunk * 64;
+            OFK_PAIR_SPILL_KEYS()
             const float mw = wave_max_f32(lane_ok ? __int_as_float(lmaxi) : 0.f);
             if (mw > published) {
                 if (lane == 0) (void)atomicMax(maxbits + b * OFK_MAX_STRIDE, __float_as_uint(mw));
@@ -818,6 +828,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
 
 #undef OFK_PAIR_LOAD
 #undef OFK_PAIR_ROWS
+#undef OFK_PAIR_SPILL_KEYS
 #undef OFK_LOAD_BLOCK
 #undef OFK_EIG_ROWS
 

@@ -282,3 +282,24 @@ def test_lk_quad_kernel_smallest_levels(gpu_ctx, pkg):
     # one level narrower than the kernel accepts: the one-wave-per-point kernel takes over, same answers required
     g2 = textured(256, 312, 92, pkg)
     lk_equal(gpu_ctx, g2, np.roll(g2, (2, 2), axis=(0, 1)), pts[:64], win=15, max_level=3, max_count=30, eps=0.01)
+
+
+@pytest.mark.parametrize("bs", [7, 5, 3])
+def test_good_features_plateau_rows_fill_the_key_buffer(gpu_ctx, bs):
+    """A texture whose period equals the box size makes every box sum - and so the response - identical over a whole patch: every
+    pixel of the patch ties with its neighbours and passes the 3x3 test, i.e. a strip of the response kernel produces one key per
+    column for several rows in a row (more would run into the segment capacity, which assumes one key per four pixels of a strip chunk).
+    The wave's key buffer holds two such rows (k_mineig_pair: NBUF = 64 + 2 SW) and has to
+    spill in front of every second row; corners, their order (ties: higher index first) and the count must still be the oracle's."""
+    rng = np.random.default_rng(3 + bs)
+    h, w = 216, 640
+    img = rng.integers(100, 112, (h, w)).astype(np.uint8)                     # faint background: the plateau holds the strongest responses
+    tile = rng.integers(0, 256, (bs, bs)).astype(np.uint8)
+    ph, pw = 6 + 2 * (bs // 2 + 1) + 1, 300                                   # patch: spans three 116-column strips; ~6 rows of plateau
+    img[40:40 + ph, 100:100 + pw] = np.tile(tile, (ph // bs + 1, pw // bs + 1))[:ph, :pw]
+    for mc, q, md in ((300, 0.001, 0.0), (500, 0.01, 3.0)):
+        corners_equal(gpu_ctx, img, mc, q, md, bs)
+    eig = io.mineig(img, bs)
+    m = bs // 2 + 1
+    inner = eig[40 + m:40 + ph - m, 100 + m:100 + pw - m]
+    assert inner.shape[0] >= 5 and np.ptp(inner) == 0 and inner[0, 0] > 0.2 * eig.max()    # one plateau, among the strongest responses
