@@ -156,7 +156,8 @@ def main():
     body = body_of(corners, "_Z13k_mineig_pairILi7ELb0EEvPKhmiiiffPjS1_mdPyiPiS4_")
     rows, which = pair_interior_rows(body)
     m = mix(mnemonics(rows), rates)
-    m["scope"] = f"interior version of the 7 unrolled rows ({which} half of the loop body): per wave-row = these counts / 7"
+    m["scope"] = (f"interior version of the 7 unrolled rows ({which} half of the loop body, the three rarely taken key-spill blocks included): "
+                  "per wave-row = these counts / 7; the issue floor uses the DYNAMIC instruction count (PMC) with this mix's mean cost")
     m["valu_per_wave_row"] = round(m["valu_instructions"] / 7, 1)
     m["issue_cycles_per_wave_row"] = round(m["valu_issue_cycles"] / 7, 1)
     dyn = valu["stages"]["eig"]["SQ_INSTS_VALU_per_launch"] / valu["batch"]
