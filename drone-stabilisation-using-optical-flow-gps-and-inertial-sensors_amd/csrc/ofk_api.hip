@@ -46,6 +46,12 @@ static size_t levels_bytes(int h, int w, int max_level)
     return lv.off[lv.n] + up((size_t)lv.h[lv.n] * lv.w[lv.n], 256);
 }
 
+// The free-running slices keep four HIP streams busy (six to eight with RCCL's); the runtime multiplexes streams onto
+// GPU_MAX_HW_QUEUES hardware queues, 4 by default, and two streams of one queue run in order (-10 % measured).  The variable is
+// read when the HIP runtime initialises, i.e. at the first HIP call of the process: set it when this library is loaded unless the
+// host has chosen a value itself.  A host that initialised HIP before loading libofk.so keeps its setting; ofk_set_streams warns.
+__attribute__((constructor)) static void ofk_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 extern "C" int ofk_version(void) { return OFK_VERSION; }
 
 extern "C" const char *ofk_last_error(const ofk_ctx *ctx) { return ctx ? ctx->errmsg : g_create_err; }
@@ -1318,6 +1324,15 @@ extern "C" int ofk_set_streams(ofk_ctx *c, int nstreams)
     // rewrite.  Changing the schedule is rare (set-up time), so drain everything.
     TRY(drain_all(c));
     c->nstreams = nstreams;
+    if (nstreams > 1) {
+        const char *q = getenv("GPU_MAX_HW_QUEUES");
+        static bool warned = false;
+        if (!warned && q && atoi(q) > 0 && atoi(q) < 2 * nstreams) {
+            fprintf(stderr, "libofk: GPU_MAX_HW_QUEUES=%s, but %d slices keep %d streams busy: streams that share a hardware queue run in order "
+                            "(set GPU_MAX_HW_QUEUES >= %d before the first HIP call)\n", q, nstreams, 2 * nstreams, 2 * nstreams);
+            warned = true;
+        }
+    }
     // Create the slice and auxiliary streams NOW: the runtime deals streams onto its hardware queues in creation order, and a
     // library that creates streams of its own later (RCCL does at ncclCommInitRank) must not get in between - with the
     // pipeline's streams created lazily behind RCCL's, two of them shared a queue and the rate fell by 10 % (99 k -> 87 k).
