@@ -56,8 +56,10 @@ def test_pairs_pipeline_vs_oracle(pkg, ofk, h, w, batch, preset):
         np.testing.assert_allclose(rec[8:11], ref["v_uav"], rtol=1e-9, atol=1e-13)
         assert rec[4] == ref["rank"] and rec[11] == ref["used"] and rec[12] == n and rec[13] == int((ref["status"] == 1).sum())
         np.testing.assert_allclose(rec[3], ref["R"][0], rtol=1e-6, atol=1e-18)
-        # and the estimate is physically right: within 15 % of the rendered per-frame velocity
-        assert np.linalg.norm(rec[0:3] - pairs[b]["v"]) < 0.15 * np.linalg.norm(pairs[b]["v"])
+        # and the estimate is physically right: within 2 % of the rendered per-frame velocity (6 % for the node preset)
+        # measured: 0.4-0.7 % (evaluate, baseline presets), 3.0-4.3 % with the node preset's 100 block-12 corners on this render
+        rel = np.linalg.norm(rec[0:3] - pairs[b]["v"]) / np.linalg.norm(pairs[b]["v"])
+        assert rel < (0.06 if preset == "node" else 0.02), rel
     pipe.close()
 
 

@@ -54,7 +54,7 @@ def test_stream_velocity_is_physical(pkg, ofk):
     fs.begin(frames[0][None])
     for t in range(1, 5):
         rec, tracks, counts = fs.step(frames[t][None], sensors)
-        assert rec[0, 4] == 3 and np.linalg.norm(rec[0, :3] - info["v"]) < 0.15 * np.linalg.norm(info["v"])
+        assert rec[0, 4] == 3 and np.linalg.norm(rec[0, :3] - info["v"]) < 0.05 * np.linalg.norm(info["v"])     # measured: 0.9-2.8 %
     fs.close()
 
 
