@@ -835,8 +835,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
 // The pair kernel takes odd boxes up to 7 on images whose rows are dword multiples and wide enough for one mirror fold.
 static bool pair_ok(int w, int block)
 {
-    static const bool off = getenv("OFK_NO_PAIR") != nullptr;   // tuning knob: one column per lane everywhere
-    return !off && (block == 3 || block == 5 || block == 7) && (w & 3) == 0 && w >= 64;
+    return !g_ofk_tuning.no_pair && (block == 3 || block == 5 || block == 7) && (w & 3) == 0 && w >= 64;
 }
 static void pair_sw(int block, int *sw, int *d)
 {
@@ -858,7 +857,7 @@ void ofk_stream_geometry(int h, int w, int block, int batch, int *rows, int *nse
     // 5.67 at 270), and the last round's tail costs more than the warm-up: isolated 1.126 ms at 540 rows, 1.071 at 270 or 360,
     // 1.08 at 135-216 (profiles/r02_eig_rows_sweep.txt)
     int r = batch >= 64 ? (h + (h + 269) / 270 - 1) / ((h + 269) / 270) : (batch >= 16 ? 128 : 32);
-    if (const char *e = getenv("OFK_EIG_ROWS")) { const int v = atoi(e); if (v >= 8 && v <= 4096) r = v; }   // tuning knob
+    if (g_ofk_tuning.eig_rows >= 8) r = g_ofk_tuning.eig_rows;  // ofk_set_tuning("eig_rows")
     while (strips * ((h + r - 1) / r) > 2048) r *= 2;           // k_select walks at most 2048 segments per image
     *rows = r; *nseg = strips * ((h + r - 1) / r);
     *seg_cap = ((SW * r / 4 + 64 + 63) / 64) * 64;              // strict local maxima fill at most a quarter of the strip

@@ -581,7 +581,7 @@ void ofk_launch_kf(hipStream_t s, int ns, int nm, int nc, const double *F, const
 // One block per video stream, behind LK: everything between calcOpticalFlowPyrLK and the next frame of the reference's loops,
 // with the per-stream filter state RESIDENT on the device —
 //   of_module.py:96-152   centre; (synthetic rotational flow :113-114); kalman.predict(control) :122; legacy r_tilde with the
-//                         predicted velocity :125; keep r - (status - 1) >= T :129-131; A_i = [p]x / dist_i system :136-146;
+//                         predicted velocity :125; keep tracked points with r >= T :129-131 (uint8 status-1 wraps for lost ones); A_i = [p]x / dist_i system :136-146;
 //                         kalman.correct(-v_obs) :152; old_pos = new_pos[keep] :166
 //   node:229-261          centre + scale; r_tilde with the dead-reckoned velocity :238-245; solve_lgs :257; lever arm + rotation
 //                         :258; self.vel = v_uav :261 (the IMU state's velocity, dead-reckoned again by the next IMU messages)
@@ -623,7 +623,9 @@ __device__ __forceinline__ bool fuse_point(const fuse_args &g, int i, const floa
     if (g.f.keep == OFK_KEEP_LEGACY) {
         double r;
         legacy_point(x, y, ux, uy, nrm, vp, r, wgt);
-        return r - (double)(st - 1) >= g.feas_T;                 // of_module.py:129 (a lost point, status 0, passes with r >= T - 1: as written)
+        // of_module.py:129 `feasibility-(status-1)>=T`: status is cv2's uint8 array (:93), so for a lost point status-1 wraps to 255:
+        // r - 255 >= T, which a cosine never reaches for any sensible T; for a tracked point it is r - 0 >= T
+        return r - (st ? 0.0 : 255.0) >= g.feas_T;
     }
     if (!st) return false;
     if (g.use_feas) {

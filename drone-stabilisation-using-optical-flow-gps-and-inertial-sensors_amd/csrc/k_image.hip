@@ -413,7 +413,7 @@ __global__ __launch_bounds__(64) void k_pyr3_stream(p3_args A)
     }
 }
 
-static bool pyr3_ok(int h, int w) { return (w & 15) == 0 && (h & 7) == 0 && w >= 64 && h >= 32 && getenv("OFK_NO_PYR3") == nullptr; }
+static bool pyr3_ok(int h, int w) { return (w & 15) == 0 && (h & 7) == 0 && w >= 64 && h >= 32 && !g_ofk_tuning.no_pyr3; }
 
 // levels 1..3 of both frame sets from level 0; false if the geometry does not fit (the caller then goes level by level)
 bool ofk_launch_pyr3(hipStream_t s, uint8_t *pyr0, uint8_t *pyr1, size_t stride, const ofk_levels &lv, int batch, int images)
@@ -428,7 +428,7 @@ bool ofk_launch_pyr3(hipStream_t s, uint8_t *pyr0, uint8_t *pyr1, size_t stride,
                                                                            // more chunks only add warm-up rows (measured: 2 chunks 71 %, 4 chunks 69 %, 8 chunks 61 % of the HBM roof)
     const int maxchunks = total / 32 > 1 ? total / 32 : 1;                 // chunks of at least 32 steps (12 warm-up steps each)
     nchunks = nchunks < 1 ? 1 : nchunks > maxchunks ? maxchunks : nchunks;
-    if (const char *e = getenv("OFK_PYR3_CHUNKS")) { const int v = atoi(e); if (v >= 1 && v <= maxchunks) nchunks = v; }   // tuning knob
+    if (g_ofk_tuning.pyr3_chunks >= 1 && g_ofk_tuning.pyr3_chunks <= maxchunks) nchunks = g_ofk_tuning.pyr3_chunks;   // ofk_set_tuning("pyr3_chunks")
     int steps = ((total + nchunks - 1) / nchunks + 3) / 4 * 4;
     nchunks = (total + steps - 1) / steps;
     p3_args A = {pyr0, pyr1 ? pyr1 : pyr0, stride, lv.off[1], lv.off[2], lv.off[3], h, w, batch, steps, nstrips, nchunks};
@@ -446,7 +446,7 @@ static void launch_pyr_stream(hipStream_t s, const uint8_t *src0, const uint8_t 
     const int nstrips = (w + PDS_COLS - 1) / PDS_COLS;
     int rows = 32;                                              // long strips re-read fewer halo rows; shorten them until the
     while (rows > 4 && (long long)nstrips * ((dh + rows - 1) / rows) * images < 8192) rows >>= 1;   // launch has >= 8 waves per SIMD
-    if (const char *e = getenv("OFK_PYR_ROWS")) { const int v = atoi(e); if (v >= 1 && v <= 4096) rows = v; }   // tuning knob
+    if (g_ofk_tuning.pyr_rows >= 1) rows = g_ofk_tuning.pyr_rows;   // ofk_set_tuning("pyr_rows")
     const int nchunks = (dh + rows - 1) / rows;
     dim3 grid((nstrips * nchunks + 3) / 4, images);
     hipLaunchKernelGGL(k_pyr_down_stream, grid, dim3(256), 0, s, src0, src1, src_stride, h, w, dst0, dst1, dst_stride, dh, dw, batch,

@@ -715,7 +715,7 @@ int ofk_jpeg_decode_device(ofk_ctx *c, const uint8_t *const *jpeg, const size_t 
     jpeg_geom g = jgeom(jh[0]);
     g.jch = JCH;
     while (g.jch > JCH_MIN && ent_total / (size_t)g.jch < 131072) g.jch >>= 1;   // keep >= 128 k decoder threads if the data allows
-    if (const char *e = getenv("OFK_JPEG_CHUNK")) { const int v = atoi(e); if (v == 64 || v == 128 || v == 256) g.jch = v; }   // tuning knob
+    if (g_ofk_tuning.jpeg_chunk) g.jch = g_ofk_tuning.jpeg_chunk;   // ofk_set_tuning("jpeg_chunk")
     for (int b = 0; b < batch; ++b) {
         const int nch = (int)((jh[b].ent_len + JB0) / (size_t)g.jch) + 1;
         if (nch > nch_max) nch_max = nch;

@@ -46,11 +46,49 @@ static size_t levels_bytes(int h, int w, int max_level)
     return lv.off[lv.n] + up((size_t)lv.h[lv.n] * lv.w[lv.n], 256);
 }
 
-// The free-running slices keep four HIP streams busy (six to eight with RCCL's); the runtime multiplexes streams onto
-// GPU_MAX_HW_QUEUES hardware queues, 4 by default, and two streams of one queue run in order (-10 % measured).  The variable is
-// read when the HIP runtime initialises, i.e. at the first HIP call of the process: set it when this library is loaded unless the
-// host has chosen a value itself.  A host that initialised HIP before loading libofk.so keeps its setting; ofk_set_streams warns.
-__attribute__((constructor)) static void ofk_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+// Hardware queues: the free-running slices keep four HIP streams busy (six to eight with RCCL's) and the runtime multiplexes
+// streams onto GPU_MAX_HW_QUEUES hardware queues, 4 by default; two streams of one queue run in order (-10 % measured).  The
+// variable is read when the HIP runtime initialises, so it is the HOST's to set before its first HIP call (the Python binding and
+// bench.py do; INTEGRATION.md tells C callers): a library that edits its host's environment from a load-time constructor races with
+// getenv on other threads and changes every other HIP user of the process (rounds 1-2 did that).  ofk_set_streams warns when the
+// value in effect is too small.
+
+ofk_tuning g_ofk_tuning = {0, 0, 0, 0, 0, 0};
+
+static int *tuning_slot(const char *knob, int *lo, int *hi)
+{
+    struct { const char *name; int *slot; int lo, hi; } tab[] = {
+        {"eig_rows", &g_ofk_tuning.eig_rows, 8, 4096},        // rows per strip of the streaming response kernels
+        {"no_pair", &g_ofk_tuning.no_pair, 0, 1},             // 1: one column per lane everywhere (k_mineig_stream instead of k_mineig_pair)
+        {"no_pyr3", &g_ofk_tuning.no_pyr3, 0, 1},             // 1: pyramid level by level instead of the three-level pass
+        {"pyr3_chunks", &g_ofk_tuning.pyr3_chunks, 1, 4096},  // row chunks per strip of k_pyr3_stream
+        {"pyr_rows", &g_ofk_tuning.pyr_rows, 1, 4096},        // rows per strip of k_pyr_down_stream
+        {"jpeg_chunk", &g_ofk_tuning.jpeg_chunk, 64, 256},    // bytes of entropy data per decoder thread (64, 128, 256)
+    };
+    for (auto &t : tab)
+        if (knob && strcmp(knob, t.name) == 0) { *lo = t.lo; *hi = t.hi; return t.slot; }
+    return nullptr;
+}
+
+extern "C" int ofk_set_tuning(const char *knob, int value)
+{
+    int lo, hi;
+    int *slot = tuning_slot(knob, &lo, &hi);
+    if (!slot) return ofk_fail(nullptr, OFK_E_INVALID, "ofk_set_tuning: unknown knob '%s'", knob ? knob : "(null)");
+    const bool jpeg_ok = slot != &g_ofk_tuning.jpeg_chunk || value == 64 || value == 128 || value == 256;
+    if (value != 0 && (value < lo || value > hi || !jpeg_ok)) return ofk_fail(nullptr, OFK_E_INVALID, "ofk_set_tuning: %s takes 0 (default) or %d..%d", knob, lo, hi);
+    *slot = value;
+    return OFK_OK;
+}
+
+extern "C" int ofk_get_tuning(const char *knob, int *value)
+{
+    int lo, hi;
+    int *slot = tuning_slot(knob, &lo, &hi);
+    if (!slot || !value) return ofk_fail(nullptr, OFK_E_INVALID, "ofk_get_tuning: unknown knob '%s'", knob ? knob : "(null)");
+    *value = *slot;
+    return OFK_OK;
+}
 
 extern "C" int ofk_version(void) { return OFK_VERSION; }
 

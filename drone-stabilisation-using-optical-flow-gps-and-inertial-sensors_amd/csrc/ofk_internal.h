@@ -83,6 +83,10 @@ struct ofk_ctx {
     char errmsg[512];
 };
 
+// Launch-geometry knobs of ofk_set_tuning (ofk.h): process-wide, 0 = the built-in choice.  Results never depend on them.
+struct ofk_tuning { int eig_rows, no_pair, no_pyr3, pyr3_chunks, pyr_rows, jpeg_chunk; };
+extern ofk_tuning g_ofk_tuning;
+
 // --- helpers (host)
 int ofk_fail(ofk_ctx *ctx, int code, const char *fmt, ...);
 #define OFK_HIP(ctx, call)                                                                       \

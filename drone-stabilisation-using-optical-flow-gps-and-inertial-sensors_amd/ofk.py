@@ -29,7 +29,7 @@ SYMBOLS = (
     "ofk_post_solve", "ofk_kf_predict_update", "ofk_of_simulation", "ofk_feas_simulation", "ofk_hist_overlap", "ofk_associate_sensors", "ofk_feature_eval", "ofk_d_split", "ofk_pairs_upload", "ofk_pairs_upload_jpeg", "ofk_jpeg_info", "ofk_jpeg_decode_bgr8", "ofk_pairs_set_sensors",
     "ofk_pairs_run", "ofk_pairs_download", "ofk_pairs_export_records_f32", "ofk_stream_begin", "ofk_stream_step",
     "ofk_stream_begin_jpeg", "ofk_stream_step_jpeg",
-    "ofk_set_streams", "ofk_set_overlap", "ofk_mark", "ofk_mark_wait", "ofk_profile_enable", "ofk_profile_read", "ofk_resident_pyramid",
+    "ofk_set_streams", "ofk_set_overlap", "ofk_set_tuning", "ofk_get_tuning", "ofk_mark", "ofk_mark_wait", "ofk_profile_enable", "ofk_profile_read", "ofk_resident_pyramid",
     "ofk_imu_reset", "ofk_imu_push", "ofk_imu_state", "ofk_filter_configure", "ofk_filter_state", "ofk_stream_step_fused",
     "ofk_stream_step_fused_jpeg", "ofk_stream_last_points", "ofk_pairs_filter_step",
     "ofk_comm_unique_id", "ofk_comm_init", "ofk_comm_destroy", "ofk_comm_rank", "ofk_comm_world", "ofk_comm_gather_records",
@@ -136,6 +136,7 @@ def load_library():
         L.ofk_pairs_filter_step.argtypes = [vp, d, i, i]
         L.ofk_set_streams.argtypes = [vp, i]
         L.ofk_set_overlap.argtypes = [vp, i]
+        L.ofk_set_tuning.argtypes = [C.c_char_p, i]; L.ofk_get_tuning.argtypes = [C.c_char_p, C.POINTER(i)]
         L.ofk_mark.argtypes = [vp, i]; L.ofk_mark_wait.argtypes = [vp, i]
         L.ofk_profile_enable.argtypes = [vp, i]
         L.ofk_profile_read.argtypes = [vp, vp, vp]
@@ -783,6 +784,21 @@ def comm_unique_id(n_ids=1):
     if rc != OK:
         raise OfkError(rc, load_library().ofk_last_error(None).decode())
     return uid.tobytes()
+
+
+def set_tuning(knob, value):
+    """Launch-geometry knob for measurements (ofk_set_tuning in include/ofk.h); 0 restores the built-in choice.  Process-wide."""
+    L = load_library()
+    if L.ofk_set_tuning(str(knob).encode(), int(value)) != OK:
+        raise OfkError(E_INVALID, L.ofk_last_error(None).decode())
+
+
+def get_tuning(knob):
+    L = load_library()
+    v = C.c_int(0)
+    if L.ofk_get_tuning(str(knob).encode(), C.byref(v)) != OK:
+        raise OfkError(E_INVALID, L.ofk_last_error(None).decode())
+    return v.value
 
 
 def make_sensors(batch, d=1.0, normal=(0, 0, 1), omega=(0, 0, 0), rotation=None, offset=(0, 0, 0.1), scaling=0.01,

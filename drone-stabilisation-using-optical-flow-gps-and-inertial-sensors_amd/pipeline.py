@@ -125,7 +125,7 @@ class FusionConfig:
     @classmethod
     def of_module(cls, synthetic_flow=True):
         """The loop of optical_flow_experiments/of_module.py:78-167: kalman.predict(control) -> legacy r_tilde with the predicted
-        velocity, keep r - (status - 1) >= T -> A_i = [p]x / dist_i system -> kalman.correct(-v_obs); tracks := kept points;
+        velocity, keep r - (status - 1) >= T with cv2's uint8 status (a lost point's status-1 wraps to 255: dropped) -> A_i = [p]x / dist_i system -> kalman.correct(-v_obs); tracks := kept points;
         <= 10 tracks: replace by fresh corners.  synthetic_flow reproduces :113-114 (the measured flow overwritten by the
         rotational field of a random omega); False keeps the LK flow the script's TODO asks for.
         Use with PipelineConfig.of_module() (feas_T = 0.9, solve_variant = OFMODULE) and sensors cx, cy = of.pix_trans((480, 640)),

@@ -77,7 +77,7 @@ int ofk_scharr_s16(ofk_ctx *ctx, const uint8_t *gray, int batch, int h, int w, i
  * block_size 1..45. */
 int ofk_mineig_response(ofk_ctx *ctx, const uint8_t *gray, int batch, int h, int w, int block_size, float *eig);
 
-/* Selection half of cv2.goodFeaturesToTrack: > quality*max, 3x3 local max, sort (value desc, index asc),
+/* Selection half of cv2.goodFeaturesToTrack: > quality*max, 3x3 local max, sort (value desc, linear index desc: OpenCV's greaterThanPtr),
  * greedy min-distance, top max_corners.  mask (nullable) [batch][h][w] u8, 0 = excluded.
  * pts [batch][max_corners][2] f32, counts [batch]. max_corners in 1..ctx max_pts. */
 int ofk_select_corners(ofk_ctx *ctx, const float *eig, const uint8_t *mask, int batch, int h, int w, int max_corners,
@@ -292,7 +292,7 @@ int ofk_pairs_filter_step(ofk_ctx *ctx, double z_sign, int z_source, int batch);
 #define OFK_FLOW_LK          0   /* u = new - old (node:235; of_module.py:108) */
 #define OFK_FLOW_ROTATIONAL  1   /* of_module.py:113-114: the flow is overwritten by the rotational field of the sensors' omega */
 #define OFK_KEEP_STATUS      0   /* status == 1, and r_tilde <= feas_T when p->use_feasibility (node:238-245) */
-#define OFK_KEEP_LEGACY      1   /* legacy 4-arg r_tilde with the filter's predicted velocity, keep r - (status - 1) >= feas_T (of_module.py:125-131) */
+#define OFK_KEEP_LEGACY      1   /* legacy 4-arg r_tilde with the filter's predicted velocity, keep r - (uint8)(status - 1) >= feas_T: tracked points with r >= feas_T, a lost point's status-1 wraps to 255 (of_module.py:93,125-131) */
 #define OFK_CONTROL_SENSORS  0   /* filter control = sensors[25..27] (of_module.py:122 draws it at random) */
 #define OFK_CONTROL_IMU      1   /* filter control = velocity increments accumulated by ofk_imu_push since the last step */
 typedef struct ofk_fusion {
@@ -369,6 +369,14 @@ int ofk_set_streams(ofk_ctx *ctx, int nstreams);
  * of two pyramid buffer sets, alternating per call, so that they overlap the VALU-bound response kernel and LK — of this call
  * and, when calls are queued back to back, of the previous one.  Results identical. */
 int ofk_set_overlap(ofk_ctx *ctx, int on);
+/* Launch-geometry knobs for measurements (process-wide; value 0 restores the built-in choice).  Results are bit-identical for
+ * every setting - the knobs move strip lengths and pick between kernels that compute the same thing (tests/test_gpu_image_parity.py
+ * runs the parity cases under them).  Knobs: "eig_rows" 8..4096 rows per strip of the streaming response kernels; "no_pair" 1 = one
+ * column per lane (k_mineig_stream) where k_mineig_pair would run; "no_pyr3" 1 = pyramid level by level; "pyr3_chunks" row chunks per
+ * strip of the three-level pyramid pass; "pyr_rows" rows per strip of the one-level pass; "jpeg_chunk" 64/128/256 bytes of entropy
+ * data per decoder thread.  (Rounds 1-2 read OFK_* environment variables in the launch code instead.) */
+int ofk_set_tuning(const char *knob, int value);
+int ofk_get_tuning(const char *knob, int *value);
 /* Completion marks (slots 0..7): ofk_mark records one behind everything queued so far on every slice, ofk_mark_wait
  * blocks the host until it has been reached (returns at once for a slot never marked).  They let a caller hand step k's
  * records to another library (an RCCL gather) while step k+1 is already queued, without draining the stream. */

@@ -50,7 +50,7 @@ def oracle_of_module(frames, cfg, normal, controls, omegas, min_feat, cx, cy, mo
     """optical_flow_experiments/of_module.py:78-167 written with the oracle's functions, one stream:
     re-detect (replace) when <= min_feat tracks (:83-86) -> LK (:88) -> x = [new - pix_trans, 1] in pixels (:96-102) -> u = LK flow or
     the synthetic rotational field of omega on the un-centred positions (:107-114) -> kalman.predict(control) (:122) -> legacy
-    r_tilde with the predicted velocity (:125) -> keep r - (status - 1) >= T (:129-131) -> A_i = [p]x / dist_i system, lstsq
+    r_tilde with the predicted velocity (:125) -> keep r - (status - 1) >= T with uint8 status, i.e. tracked and r >= T (:129-131) -> A_i = [p]x / dist_i system, lstsq
     (:136-146) -> kalman.correct(-v_obs) (:152) -> old_pos = new_pos[keep] (:166).
     One deviation, shared with the device (include/ofk.h, ofk_stream_step_fused): on <= 3 feasible points the script `continue`s
     without advancing the frame; here the frame advances and the filter keeps its prediction.
@@ -69,9 +69,9 @@ def oracle_of_module(frames, cfg, normal, controls, omegas, min_feat, cx, cy, mo
         n_old = len(old)
         if n_old:
             new, st, _ = io.lk_pyr(g_prev, g, old, cfg.win, cfg.max_level, cfg.max_count, cfg.eps, cfg.min_eig_thr)
-            new = new.reshape(-1, 2); st = st.ravel().astype(np.float64)
+            new = new.reshape(-1, 2); st = st.ravel().astype(np.uint8)        # cv2 hands out uint8 (of_module.py:93)
         else:
-            new = np.zeros((0, 2), np.float32); st = np.zeros(0)
+            new = np.zeros((0, 2), np.float32); st = np.zeros(0, np.uint8)
         X = new[:, 0].astype(np.float64); Y = new[:, 1].astype(np.float64)
         x3 = np.stack([X - cx, Y - cy, np.ones_like(X)], 1)
         w = np.asarray(omegas[t - 1], np.float64)
@@ -82,7 +82,7 @@ def oracle_of_module(frames, cfg, normal, controls, omegas, min_feat, cx, cy, mo
         xk, P = eo.kf_predict(xk, P, model.F, model.Q, model.B, np.asarray(controls[t - 1], np.float64))
         with np.errstate(divide="ignore", invalid="ignore"):
             r, dist = eo.r_tilde_legacy(x3, u3, n, xk[:3]) if n_old else (np.zeros(0), np.zeros(0))
-            keep = (r - (st - 1)) >= cfg.feas_T
+            keep = (r - (st - np.uint8(1))) >= cfg.feas_T           # of_module.py:129 as written: uint8 status-1 wraps to 255 for a lost point
         v = None
         if keep.sum() > 3:
             v = eo.solve_of_module(x3[keep], u3[keep], dist[keep], n)[0]

@@ -140,3 +140,36 @@ def test_fused_three_state_filter_is_bit_identical_to_the_stand_alone_kernel(pkg
         gx, gP = fs.ctx.filter_state(1)
         assert np.array_equal(gx[0].view(np.uint64), x.view(np.uint64)) and np.array_equal(gP[0].view(np.uint64), P.view(np.uint64)), t
     fs.close()
+
+
+def test_of_module_keep_rule_drops_lost_points(pkg, ofk):
+    """of_module.py:129 `feasibility-(status-1)>=T` with cv2's uint8 status (:93): status-1 wraps to 255 for a lost point, so it is
+    dropped whatever its r, and a tracked point is kept iff r >= T.  With T = -2 every tracked point passes (r is a cosine), hence
+    kept == tracked; the clip moves fast enough that border points are lost (rounds 1-2 kept them: r + 1 >= T)."""
+    from of_amd import synth
+    from of_amd.of_library import pix_trans
+    from of_amd.pipeline import FlowStream, PipelineConfig, FusionConfig
+    h, w, nf = 240, 320, 5
+    cfg = PipelineConfig.of_module()
+    cfg.max_corners = 80; cfg.quality = 0.02; cfg.block_size = 7; cfg.min_distance = 8; cfg.max_level = 2; cfg.feas_T = -2.0
+    frames, info = synth.render_sequence(h, w, 31, nf, v=(0.05, 0.035, 0.0), omega=(0.0, 0.0, 0.0), d=1.0)     # 16 x 11 px per frame: corners leave the image
+    rng = np.random.default_rng(9)
+    controls = rng.normal(0, 0.01, (nf - 1, 3)); omegas = rng.normal(0, 0.01, (nf - 1, 3))
+    cx, cy = pix_trans((240, 320))
+    normal = np.array([0.0, 0.0, 1.0])
+    fusion = FusionConfig.of_module(synthetic_flow=False)
+    fs = FlowStream(w, h, batch=1, cfg=cfg, min_features=5, mask_radius=10, fusion=fusion)
+    tracks, counts = fs.begin(frames[0][None])
+    ref = oracle_of_module(frames, cfg, normal, controls, omegas, 5, cx, cy, fusion.model, False)
+    lost_total = 0
+    for t in range(1, nf):
+        sensors = ofk.make_sensors(1, d=1.0, normal=normal, omega=omegas[t - 1], scaling=1.0, cx=cx, cy=cy)
+        sensors[:, 25:28] = controls[t - 1]
+        rec, fused, tracks, counts = fs.step_fused(frames[t][None], sensors)
+        v, xk, P, tr, n_old, n_keep = ref[1][t - 1]
+        assert rec[0, 12] == n_old and rec[0, 11] == n_keep and counts[0] == len(tr)
+        assert rec[0, 11] == rec[0, 13], "kept == tracked when T is below every cosine"
+        assert np.array_equal(tracks[0, :counts[0]].view(np.uint32), tr.astype(np.float32).view(np.uint32))
+        lost_total += int(rec[0, 12] - rec[0, 13])
+    assert lost_total > 0, "the clip must lose points for this test to mean anything"
+    fs.close()

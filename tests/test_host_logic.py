@@ -91,3 +91,46 @@ def test_read_yaml_imu_safe_loader(of, tmp_path):
 """.replace("- !!python/object/new:sensor_msgs.msg._Imu.Imu\n  state:\n  - !!python/object/new:std_msgs.msg._Header.Header\n    state: [1, {secs: 5, nsecs: 250000000}, base]\n", "- \n"))
     st = of.read_yaml_imu(str(y))
     assert len(st) == 1 and st[0][0] == 5 + 250.0 and st[0][3] == [0.1, 0.2, 9.8] and st[0][1] == [0.0, 0.0, 0.0, 1.0]
+
+
+def test_failed_context_growth_keeps_the_old_default_context(pkg, monkeypatch):
+    """ofk.default_context builds the bigger context FIRST: when that fails (a corrupt JPEG header asking for 65535 x 65535, out of
+    device memory) the old default context must stay installed, open and usable (advisor finding of round 1, fixed in ofk.py)."""
+    import of_amd.ofk as ofk
+
+    class FakeContext:
+        fail = False
+        closed = []
+
+        def __init__(self, device, w, h, batch, pts, lvl):
+            if FakeContext.fail:
+                raise ofk.OfkError(ofk.E_HIP, "hipMalloc failed")
+            self.max_w, self.max_h, self.max_pts, self.max_level = w, h, pts, lvl
+
+        def close(self):
+            FakeContext.closed.append(self)
+
+    monkeypatch.setattr(ofk, "Context", FakeContext)
+    monkeypatch.setattr(ofk, "_default", None)
+    first = ofk.default_context(640, 480, 64, 3)
+    assert ofk.default_context(320, 240) is first                # fits: no rebuild
+    FakeContext.fail = True
+    with pytest.raises(ofk.OfkError):
+        ofk.default_context(65535, 65535)
+    assert ofk._default is first and first not in FakeContext.closed
+    assert ofk.default_context(640, 480) is first                # still served by the old context
+    FakeContext.fail = False
+    bigger = ofk.default_context(4096, 2160)
+    assert bigger is not first and FakeContext.closed == [first] and bigger.max_w >= 4096 and bigger.max_pts >= first.max_pts
+
+
+def test_tuning_knobs_validate(pkg):
+    import of_amd.ofk as ofk
+    assert ofk.get_tuning("eig_rows") == 0
+    ofk.set_tuning("eig_rows", 128)
+    assert ofk.get_tuning("eig_rows") == 128
+    ofk.set_tuning("eig_rows", 0)
+    for knob, bad in (("eig_rows", 4), ("jpeg_chunk", 100), ("no_pair", 2), ("nonsense", 1)):
+        with pytest.raises(ofk.OfkError):
+            ofk.set_tuning(knob, bad)
+    assert ofk.get_tuning("eig_rows") == 0 and ofk.get_tuning("jpeg_chunk") == 0
