@@ -77,8 +77,8 @@ class _stdout_to_stderr:
 H, W = 1080, 1920
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 2.0      # 1228.8 G wave-instr/s: wave64 VALU = 2 clocks on a SIMD-32, 1024 SIMDs, 2.4 GHz
-PROFILE_TAG = "r02"          # profiles/<tag>_traffic_pmc.json, _valu_pmc.json, _isa_mix.json (tools/profile_round.sh)
-KERNEL_OF = {"gray": "k_gray_bgr8", "pyr": "k_pyr3_stream", "eig": "k_mineig_pair<7,false>", "select": "k_select", "lk": "k_lk15q",
+PROFILE_TAG = "r03"          # profiles/<tag>_traffic_pmc.json, _valu_pmc.json, _isa_mix.json (tools/profile_round.sh)
+KERNEL_OF = {"gray": "k_gray_bgr8", "pyr": "k_pyr3_stream", "eig": "k_mineig_pair<7,false>", "select": "k_select_greedy", "lk": "k_lk15q",
              "solve": "k_pairs_solve", "nms": "-"}
 
 
@@ -105,7 +105,7 @@ def algorithmic_bytes(cfg, n_pts, n_cand):
 
 
 def _profile(name):
-    for tag in (PROFILE_TAG, "r01"):
+    for tag in (PROFILE_TAG, "r02", "r01"):
         try:
             return json.load(open(os.path.join(ROOT, "profiles", f"{tag}_{name}.json"))), tag
         except Exception:

@@ -19,13 +19,12 @@
 //       FUSED = true : no map.  The region overlaps its neighbours by one pixel, the block applies the 3x3
 //         local-max test itself and appends the survivors as 64-bit keys (~bits(value) << 32 | ~linear index: ascending key = value desc, index desc, OpenCV's greaterThanPtr order) with
 //         ONE global atomic per block.  The quality threshold needs the image-wide maximum, which is not known yet;
-//         the block prunes with the running maximum (atomicMax so far), a valid lower bound, and k_select applies the
+//         the block prunes with the running maximum (atomicMax so far), a valid lower bound, and k_select_prep applies the
 //         exact threshold.  HBM traffic: P read + O(candidates) written, instead of P + 4P + 4P.
 //   k_nms    : the same threshold / 3x3 test / key list for a response map supplied by the caller
 //              (ofk_select_corners), block-aggregated appends.
-//   k_select : one 1024-thread workgroup per image.  Repeats { pick the next <= 4096 keys in ascending key order
-//              with an 11-bit histogram over (key - lower bound), bitonic sort in LDS, greedy min-distance over the
-//              sorted chunk } until max_corners are accepted or the keys below the threshold key are exhausted.
+//   k_select_prep / k_select_pick / k_select_greedy : exact threshold + key histogram, first cut, then sort + greedy
+//              minimum-distance pass in a 256-thread workgroup per image (described in front of them).
 //              Result identical to a full sort (value desc, index desc) followed by the serial greedy pass.
 #include "ofk_internal.h"
 
@@ -360,6 +359,46 @@ __device__ __forceinline__ int box_row(int a, int ad2, int ad4, int adl)
 //  * Interior blocks take the running maximum over every lane; the columns that do not count are dropped when the maximum
 //    is published.  yo = response row completed by the step (garbage while r <= BS), yn = row whose 3x3 neighbourhood
 //    is complete.
+// Keys inside a strip's SEGMENT are stored raw — (response bits << 32) | linear index — and complemented by k_select_prep when it
+// compacts them into the flat list (ascending key = value desc, index desc): two v_not per candidate row and slot leave the
+// response kernels' row loop, which is bound by VALU issue, for one 64-bit NOT per key in a kernel that waits for memory.
+#define OFK_SEG_KEY(bits, idx) (((unsigned long long)(unsigned)(bits) << 32) | (unsigned)(idx))
+#define OFK_SEG_KEY_DECODE(k) (~(k))
+#ifndef OFK_KEYS_ATOM
+#define OFK_KEYS_ATOM 0
+#endif
+#if OFK_KEYS_ATOM
+// experiment (tools/experiments/eig_keys.sh): the slot of a key comes from a counter in LDS (ds_add_rtn_u32 under the candidate
+// lanes' exec mask) instead of ballot + mbcnt ranks; both slots' atomics are issued before the one wait.  The order of keys inside
+// a segment is irrelevant (k_select_greedy sorts).  Written as ONE asm statement: the compiler's atomic optimizer would turn a
+// uniform-value LDS atomic back into ballot + mbcnt + one atomic per wave.
+#define OFK_PAIR_KEY_STORE()                                                                                           \
+    {                                                                                                                  \
+        const unsigned long long ke_ = OFK_SEG_KEY(e1e, yn * w + xo_e), ko_ = OFK_SEG_KEY(e1o, yn * w + xo_o);         \
+        int se_, so_;                                                                                                  \
+        asm volatile("s_mov_b64 s[30:31], exec\n\t"                                                                    \
+                     "s_mov_b64 exec, %[me]\n\t"                                                                       \
+                     "ds_add_rtn_u32 %[se], %[ca], %[one]\n\t"                                                         \
+                     "s_mov_b64 exec, %[mo]\n\t"                                                                       \
+                     "ds_add_rtn_u32 %[so], %[ca], %[one]\n\t"                                                         \
+                     "s_waitcnt lgkmcnt(0)\n\t"                                                                        \
+                     "v_lshl_add_u32 %[so], %[so], 3, %[ba]\n\t"                                                       \
+                     "ds_write_b64 %[so], %[ko]\n\t"                                                                   \
+                     "s_mov_b64 exec, %[me]\n\t"                                                                       \
+                     "v_lshl_add_u32 %[se], %[se], 3, %[ba]\n\t"                                                       \
+                     "ds_write_b64 %[se], %[ke]\n\t"                                                                   \
+                     "s_mov_b64 exec, s[30:31]"                                                                        \
+                     : [se] "=&v"(se_), [so] "=&v"(so_)                                                                \
+                     : [ca] "v"(cnt_addr), [one] "v"(one_v), [ba] "v"(buf_addr), [ke] "v"(ke_), [ko] "v"(ko_), [me] "s"(bale), [mo] "s"(balo) \
+                     : "memory", "s30", "s31");                                                                        \
+    }
+#else
+#define OFK_PAIR_KEY_STORE()                                                                                           \
+        if (ise) buf[cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bale >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bale, 0u))] =   \
+            OFK_SEG_KEY(e1e, yn * w + xo_e);                                                                           \
+        if (iso) buf[cnt + ne + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(balo >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)balo, 0u))] = \
+            OFK_SEG_KEY(e1o, yn * w + xo_o);
+#endif
 #define OFK_EIG_ROWS(IN)                                                                                               \
     _Pragma("unroll") for (int i = 0; i < BS; ++i) {                                                                   \
         const int r = base + i;                                                                                        \
@@ -397,7 +436,7 @@ __device__ __forceinline__ int box_row(int a, int ad2, int ad4, int adl)
         if (MASK) is = is & (mk[(size_t)min(max(yn, 0), h - 1) * w + xoc] != 0);                                       \
         const unsigned long long bal = __builtin_amdgcn_ballot_w64(is);                                                \
         if (is) buf[cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))] =   \
-            ((unsigned long long)(~(unsigned)e1i) << 32) | (unsigned)~(unsigned)(yn * w + xo);                                   \
+            OFK_SEG_KEY(e1i, yn * w + xo);                                                                              \
         cnt += __popcll(bal);                                                                                          \
         e1i = e2i; hm0 = hm1; hm1 = hm2;                                                                               \
         g0 = g1; g1 = g2;                                                                                              \
@@ -617,7 +656,13 @@ __device__ __forceinline__ int lambda_min_bits(int vxx, int vxy, int vyy, float 
         __builtin_amdgcn_wave_barrier();                                                                               \
         buf[lane] = rest;                                                                                              \
         cnt -= nchunk * 64;                                                                                            \
+        OFK_PAIR_KCNT_SYNC()                                                                                           \
     }
+#if OFK_KEYS_ATOM
+#define OFK_PAIR_KCNT_SYNC() { if (lane == 0) s_kcnt = cnt; __builtin_amdgcn_wave_barrier(); }
+#else
+#define OFK_PAIR_KCNT_SYNC()
+#endif
 // One block of BS rows (expanded twice: IN = true for interior blocks); see OFK_EIG_ROWS for the conventions.
 #define OFK_PAIR_ROWS(IN)                                                                                             \
     _Pragma("unroll") for (int i = 0; i < BS; ++i) {                                                                   \
@@ -682,10 +727,7 @@ __device__ __forceinline__ int lambda_min_bits(int vxx, int vxy, int vyy, float 
         }                                                                                                              \
         const unsigned long long bale = __builtin_amdgcn_ballot_w64(ise), balo = __builtin_amdgcn_ballot_w64(iso);     \
         const int ne = (int)__popcll(bale);                                                                            \
-        if (ise) buf[cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bale >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bale, 0u))] =   \
-            ((unsigned long long)(~(unsigned)e1e) << 32) | (unsigned)~(unsigned)(yn * w + xo_e);                                 \
-        if (iso) buf[cnt + ne + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(balo >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)balo, 0u))] = \
-            ((unsigned long long)(~(unsigned)e1o) << 32) | (unsigned)~(unsigned)(yn * w + xo_o);                                 \
+        OFK_PAIR_KEY_STORE()                                                                                           \
         cnt += ne + (int)__popcll(balo);                                                                               \
         e1e = e2e; e1o = e2o; hm0e = hm1e; hm0o = hm1o; hm1e = hm2e; hm1o = hm2o;                                      \
         r01e = r12e; r01o = r12o; g1e = ge2; g1o = go2;                                                                  \
@@ -717,6 +759,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
     // registers: 168 VGPRs, three waves).  Alone on the chip 1.03 -> 0.96 ms; with the yy ring only (150 VGPRs, three waves, room
     // for a gray wave beside them) the kernel alone was no faster but the step 2.4 % shorter — four waves are another 1 % on top.
     __shared__ int s_ring[4 * BS * 64];
+#if OFK_KEYS_ATOM
+    __shared__ int s_kcnt;                                      // == cnt whenever a row takes key slots from it
+    const unsigned cnt_addr = (unsigned)(size_t)&s_kcnt, buf_addr = (unsigned)(size_t)s_buf;
+    int one_v = 1;
+    asm volatile("" : "+v"(one_v));
+    if (threadIdx.x == 0) s_kcnt = 0;
+#endif
     const int lane = threadIdx.x;
     // XCD-aware block -> (image, chunk, strip block) map: workgroups are dealt round-robin over the 8 XCDs (blocks n and
     // n + 8 share one L2); an image's strips and chunks go to ONE XCD, so the halo columns and rows they share are fetched once.
@@ -858,7 +907,7 @@ void ofk_stream_geometry(int h, int w, int block, int batch, int *rows, int *nse
     // 1.08 at 135-216 (profiles/r02_eig_rows_sweep.txt)
     int r = batch >= 64 ? (h + (h + 269) / 270 - 1) / ((h + 269) / 270) : (batch >= 16 ? 128 : 32);
     if (g_ofk_tuning.eig_rows >= 8) r = g_ofk_tuning.eig_rows;  // ofk_set_tuning("eig_rows")
-    while (strips * ((h + r - 1) / r) > 2048) r *= 2;           // k_select walks at most 2048 segments per image
+    while (strips * ((h + r - 1) / r) > 2048) r *= 2;           // the selection walks at most 2048 segments per image
     *rows = r; *nseg = strips * ((h + r - 1) / r);
     *seg_cap = ((SW * r / 4 + 64 + 63) / 64) * 64;              // strict local maxima fill at most a quarter of the strip
 }
@@ -1025,18 +1074,36 @@ void ofk_launch_nms(hipStream_t s, const float *eig, size_t eig_stride, const ui
 }
 
 // ------------------------------------------------------------------------------------------------ sort + greedy min-distance
-#define SEL_T 1024
-#define SEL_BINS 2048
+#define SEL_T 256                                             // threads of the sort + greedy workgroup (k_select_greedy)
+#define SEL_NB 512                                            // histogram bins per refinement level of its generic path
 
-// Selection, first half, spread over SEL_G workgroups per image (k_select itself is one workgroup per image: sort and the greedy
-// pass are serial by nature).  Every workgroup walks its share of the response kernel's segments, keeps the keys above the exact
-// quality threshold, appends them to the image's flat list (one global atomic per wave-iteration) and counts them into a 1024-bin
-// histogram over [key of the maximum, threshold key) — linear in the float's bit pattern, i.e. about logarithmic in the response.
-// k_select then reads its first cut T straight from that histogram instead of scanning the whole list up to eight times, and
-// never touches the segments.  At 4K / 2000 corners (184 k candidates per image) the single-workgroup compaction and histogram
-// search were most of k_select's 0.67 ms.
+// Selection = three short kernels, none of which needs more of a CU than one retiring wave of the response kernel frees
+// (round 2: ONE 1024-thread workgroup per image with 57 KB of LDS — beside the other slice's response kernel, which rents every
+// VGPR and all 160 KB of LDS of every CU in 128-VGPR / 10 KB wave-sized pieces, it waited for a CU to drain: 61 us alone, 459 us mean /
+// 1.4 ms worst under the schedule, profiles/r02_kernel_stats_slices2.csv):
+//   k_select_prep   SEL_G workgroups per image: keys above the exact quality threshold -> flat list, 1024-bin histogram of their
+//                   bit patterns over [key of the maximum, threshold key);
+//   k_select_pick   SEL_G workgroups per image: the leading histogram bins that hold at most `tgt` ~ 2 maxCorners keys give a cut
+//                   T; every workgroup moves its share of the keys below T into the image's pick list (<= tgt keys);
+//   k_select_greedy one 256-thread workgroup per image, 9 KB of LDS at 500 corners: bitonic sort of the pick list, then the
+//                   greedy minimum-distance pass against a coarse GRID of the accepted corners (cells >= minDistance wide, 3 x 3
+//                   cells probed per candidate — what OpenCV does; round 2 compared every candidate with every accepted corner);
+//                   when the picked keys do not fill the budget (heavy ties, tight distances) it goes on with the generic loop:
+//                   next cut by multi-level histogram over the flat list, gather, sort, greedy.
+// Result identical to a full sort (value desc, index desc) followed by the serial greedy pass.
 #define SEL_G 16
 #define SEL_HB 1024
+
+__host__ __device__ __forceinline__ int sel_tgt(int max_corners)
+{
+    int t = 512;                                                // keys handled per round: about twice the corners wanted
+    while (t < 2 * max_corners && t < OFK_CHUNK) t <<= 1;
+    return t;
+}
+// per-image counter line (OFK_CNT_STRIDE ints): [0] keys in the flat list, [1] keys in the pick list, [2] histogram bins below the cut
+#define SEL_CNT_PICK 1
+#define SEL_CNT_BINS 2
+
 __global__ __launch_bounds__(256) void k_select_prep(unsigned long long *__restrict__ cand_all, int cand_cap, int *__restrict__ cand_count,
                                                      const unsigned long long *__restrict__ seg, int seg_cap,
                                                      const int *__restrict__ seg_count, int nseg,
@@ -1056,33 +1123,48 @@ __global__ __launch_bounds__(256) void k_select_prep(unsigned long long *__restr
     for (int i = tid; i < SEL_HB; i += 256) s_h[i] = 0;
     __syncthreads();
     unsigned long long *cand = cand_all + (size_t)b * cand_cap;
-    const unsigned long long *sbase = seg + (size_t)b * nseg * seg_cap;
-    for (int sg = g; sg < nseg; sg += SEL_G) {
-        const int n = min(seg_count[(size_t)b * nseg + sg], seg_cap);
-        const unsigned long long *sp = sbase + (size_t)sg * seg_cap;
-        for (int i0 = 0; i0 < n; i0 += 1024) {                   // uniform trip count per wave: ballots below need every lane
-            // four keys per thread and trip: the loads are in flight together and one atomic reserves the list slots of all four
-            // (the loop is a chain of load and atomic round trips: ~680 keys per segment at 1080p are one trip now, not three)
-            unsigned long long key[4], bal[4];
-            int cnt4 = 0;
+    if (nseg > 0) {
+        const unsigned long long *sbase = seg + (size_t)b * nseg * seg_cap;
+        for (int sg = g; sg < nseg; sg += SEL_G) {
+            const int n = min(seg_count[(size_t)b * nseg + sg], seg_cap);
+            const unsigned long long *sp = sbase + (size_t)sg * seg_cap;
+            for (int i0 = 0; i0 < n; i0 += 1024) {                   // uniform trip count per wave: ballots below need every lane
+                // four keys per thread and trip: the loads are in flight together and one atomic reserves the list slots of all four
+                // (the loop is a chain of load and atomic round trips: ~680 keys per segment at 1080p are one trip now, not three)
+                unsigned long long key[4], bal[4];
+                int cnt4 = 0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { const int i = i0 + 256 * q + tid; key[q] = i < n ? sp[i] : ~0ull; }
+                for (int q = 0; q < 4; ++q) { const int i = i0 + 256 * q + tid; key[q] = i < n ? OFK_SEG_KEY_DECODE(sp[i]) : ~0ull; }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { bal[q] = __ballot((unsigned)(key[q] >> 32) < kend_hi); cnt4 += __popcll(bal[q]); }
-            if (cnt4) {
-                int base = 0;
-                if (lane == 0) base = atomicAdd(cand_count + b * OFK_CNT_STRIDE, cnt4);
-                base = __builtin_amdgcn_readfirstlane(base);
+                for (int q = 0; q < 4; ++q) { bal[q] = __ballot((unsigned)(key[q] >> 32) < kend_hi); cnt4 += __popcll(bal[q]); }
+                if (cnt4) {
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(cand_count + b * OFK_CNT_STRIDE, cnt4);
+                    base = __builtin_amdgcn_readfirstlane(base);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const unsigned hi = (unsigned)(key[q] >> 32);
-                    if (hi < kend_hi) {
-                        const int pos = base + __popcll(bal[q] & ((1ull << lane) - 1));
-                        if (pos < cand_cap) cand[pos] = key[q];
-                        atomicAdd(&s_h[(hi - a_hi) >> shift], 1u);
+                    for (int q = 0; q < 4; ++q) {
+                        const unsigned hi = (unsigned)(key[q] >> 32);
+                        if (hi < kend_hi) {
+                            const int pos = base + __popcll(bal[q] & ((1ull << lane) - 1));
+                            if (pos < cand_cap) cand[pos] = key[q];
+                            atomicAdd(&s_h[(hi - a_hi) >> shift], 1u);
+                        }
+                        base += __popcll(bal[q]);
                     }
-                    base += __popcll(bal[q]);
                 }
+            }
+        }
+    } else {
+        // the flat list exists already (k_nms, or the LDS-tile response kernel with its running threshold): histogram only
+        const int C = min(cand_count[b * OFK_CNT_STRIDE], cand_cap);
+        for (int i0 = g * 1024; i0 < C; i0 += SEL_G * 1024) {
+            unsigned long long key[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int i = i0 + 256 * q + tid; key[q] = i < C ? cand[i] : ~0ull; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned hi = (unsigned)(key[q] >> 32);
+                if (hi < kend_hi && hi >= a_hi) atomicAdd(&s_h[(hi - a_hi) >> shift], 1u);
             }
         }
     }
@@ -1091,215 +1173,231 @@ __global__ __launch_bounds__(256) void k_select_prep(unsigned long long *__restr
     for (int i = tid; i < SEL_HB; i += 256) if (s_h[i]) atomicAdd(hb + i, s_h[i]);
 }
 
-__global__ __launch_bounds__(SEL_T) void k_select(unsigned long long *__restrict__ cand_all, int cand_cap,
-                                                  int *__restrict__ cand_count, const unsigned long long *__restrict__ seg,
-                                                  int seg_cap, const int *__restrict__ seg_count, int nseg,
-                                                  const unsigned int *__restrict__ maxbits, double quality, int w,
-                                                  int max_corners_all, float min_distance, float *__restrict__ pts, int pts_stride,
-                                                  int *__restrict__ counts, const int *__restrict__ limit, const unsigned *__restrict__ hist)
+// Inclusive prefix over NPT consecutive values per thread of a 256-thread workgroup; returns the inclusive prefix of the thread's
+// LAST value.  s_w: 4 words.  Two barriers.
+__device__ __forceinline__ unsigned block_scan256(unsigned local_sum, unsigned *s_w, unsigned &total)
 {
-    // per-image corner budget (re-detection appends only what a stream is missing); <= 0: nothing to do for this image
-    const int max_corners = limit ? min(max_corners_all, limit[blockIdx.x]) : max_corners_all;
-    if (max_corners <= 0) { if (threadIdx.x == 0) { counts[blockIdx.x] = 0; if (nseg > 0 && !hist) cand_count[blockIdx.x * OFK_CNT_STRIDE] = 0; } return; }
-    __shared__ unsigned long long s_key[OFK_CHUNK];
-    __shared__ unsigned s_hist[SEL_BINS];
-    __shared__ int s_acc_xy[4096];                              // accepted corners, x | y<<16 (max_corners <= 4096)
-    __shared__ unsigned long long s_rej[SEL_T / 64];            // per-wave reject ballots of the current 64-candidate round
-    __shared__ unsigned s_wsum[SEL_T / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned incl = local_sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned n_ = __shfl_up(incl, o); if (lane >= o) incl += n_; }
+    __syncthreads();
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    unsigned woff = 0; total = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const unsigned ws = s_w[q]; if (q < wave) woff += ws; total += ws; }
+    return woff + incl;
+}
+
+__global__ __launch_bounds__(256) void k_select_pick(const unsigned long long *__restrict__ cand_all, int cand_cap, int *__restrict__ cand_count,
+                                                     const unsigned int *__restrict__ maxbits, double quality, const unsigned *__restrict__ hist,
+                                                     const int *__restrict__ limit, int max_corners_all,
+                                                     unsigned long long *__restrict__ sel_keys, int sel_stride)
+{
+    __shared__ unsigned s_w[4];
+    __shared__ int s_D;
+    const int b = blockIdx.y, g = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int mc = limit ? min(max_corners_all, limit[b]) : max_corners_all;
+    if (mc <= 0) return;
+    const unsigned mb = maxbits[b * OFK_MAX_STRIDE];
+    if (mb == 0) return;
+    const float thr = (float)((double)__uint_as_float(mb) * quality);
+    const unsigned a_hi = ~mb, kend_hi = ~__float_as_uint(thr);
+    if (!(a_hi < kend_hi)) return;
+    int *cnt = cand_count + b * OFK_CNT_STRIDE;
+    const int total_keys = cnt[0];
+    if (total_keys > cand_cap || total_keys <= 0) return;        // overflow is reported by k_select_greedy
+    const int tgt = sel_tgt(mc);
+    const unsigned width = kend_hi - a_hi;
+    const int hshift = width <= SEL_HB ? 0 : 32 - __clz((int)(width - 1)) - 10;
+    // the cut: D = number of leading bins whose inclusive prefix fits the budget (prefixes are non-decreasing: a leading run)
+    if (tid == 0) s_D = 0;
+    const uint4 h4 = reinterpret_cast<const uint4 *>(hist + (size_t)b * SEL_HB)[tid];       // bins 4 tid .. 4 tid + 3
+    unsigned tot;
+    const unsigned i3 = block_scan256(h4.x + h4.y + h4.z + h4.w, s_w, tot);
+    const unsigned i2 = i3 - h4.w, i1 = i2 - h4.z, i0 = i1 - h4.y;
+    const int fit = ((int)i0 <= tgt) + ((int)i1 <= tgt) + ((int)i2 <= tgt) + ((int)i3 <= tgt);
+    if (fit) atomicAdd(&s_D, fit);
+    __syncthreads();
+    const int D = s_D;
+    if (g == 0 && tid == 0) cnt[SEL_CNT_BINS] = D;
+    if (D == 0) return;                                          // the first bin alone exceeds the budget (ties): generic path
+    const unsigned long long t64 = (unsigned long long)a_hi + ((unsigned long long)D << hshift);
+    const unsigned T_hi = t64 < (unsigned long long)kend_hi ? (unsigned)t64 : kend_hi;
+    const unsigned long long *cand = cand_all + (size_t)b * cand_cap;
+    unsigned long long *dst = sel_keys + (size_t)b * sel_stride;
+    const int per = ((total_keys + SEL_G - 1) / SEL_G + 255) & ~255;
+    const int ibeg = min(total_keys, g * per), iend = min(total_keys, ibeg + per);
+    for (int i0_ = ibeg; i0_ < iend; i0_ += 8 * 256) {           // eight loads in flight per thread: one trip at 1080p (2.9 k keys per workgroup)
+        unsigned long long key[8], bal[8];
+        int c8 = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const int i = i0_ + 256 * q + tid; key[q] = i < iend ? cand[i] : ~0ull; }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const unsigned hi = (unsigned)(key[q] >> 32); bal[q] = __ballot(hi < T_hi && hi >= a_hi); c8 += __popcll(bal[q]); }
+        if (c8) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(cnt + SEL_CNT_PICK, c8);
+            base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if ((bal[q] >> lane) & 1ull) {
+                    const int pos = base + __popcll(bal[q] & ((1ull << lane) - 1));
+                    if (pos < sel_stride) dst[pos] = key[q];
+                }
+                base += __popcll(bal[q]);
+            }
+        }
+    }
+}
+
+extern __shared__ __attribute__((aligned(16))) uint8_t sel_smem[];
+
+// LDS map (bytes, tgtA = sel_tgt(max_corners_all)):  [0, 8 tgtA) sort buffer of the first round | [0, 4 tgtA) sorted indices,
+// sort buffer of later rounds (tgtA / 2 keys), histogram of the cut search | [4 tgtA, 6 tgtA) grid heads u16 | [6 tgtA, + 4 mc)
+// accepted corners x | y << 16 | then mc u16 chain links.  Total max(8 tgtA, 6 tgtA + 6 mc): 9.1 KB at 500 corners.
+__global__ __launch_bounds__(SEL_T) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_select_greedy(const unsigned long long *__restrict__ cand_all, int cand_cap,
+                                                         const int *__restrict__ cand_count, const unsigned int *__restrict__ maxbits,
+                                                         double quality, int w, int h, int max_corners_all, float min_distance,
+                                                         float *__restrict__ pts, int pts_stride, int *__restrict__ counts,
+                                                         const int *__restrict__ limit, const unsigned long long *__restrict__ sel_keys,
+                                                         int sel_stride, int tgtA, int cs)
+{
+    constexpr int NW = SEL_T / 64;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int max_corners = limit ? min(max_corners_all, limit[b]) : max_corners_all;
+    if (max_corners <= 0) { if (tid == 0) counts[b] = 0; return; }
+    unsigned long long *s_key = reinterpret_cast<unsigned long long *>(sel_smem);
+    unsigned *s_idx = reinterpret_cast<unsigned *>(sel_smem);
+    unsigned *s_hist = reinterpret_cast<unsigned *>(sel_smem);
+    volatile unsigned short *s_grid = reinterpret_cast<volatile unsigned short *>(sel_smem + 4 * (size_t)tgtA);
+    int *s_acc = reinterpret_cast<int *>(sel_smem + 6 * (size_t)tgtA);
+    volatile unsigned short *s_next = reinterpret_cast<volatile unsigned short *>(sel_smem + 6 * (size_t)tgtA + 4 * (size_t)max_corners_all);
     __shared__ unsigned long long s_conf[64];                   // conflict matrix of the current greedy round
+    __shared__ unsigned s_w[NW];
     __shared__ int s_n, s_nacc, s_D, s_cum;
 
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    unsigned long long *cand = cand_all + (size_t)b * cand_cap;
+    const unsigned long long *cand = cand_all + (size_t)b * cand_cap;
     const unsigned mb = maxbits[b * OFK_MAX_STRIDE];
     if (tid == 0) { s_nacc = 0; s_n = 0; counts[b] = 0; }
-    if (mb == 0) { if (tid == 0 && nseg > 0 && !hist) cand_count[b * OFK_CNT_STRIDE] = 0; return; }
+    if (mb == 0) return;
     const float thr = (float)((double)__uint_as_float(mb) * quality);
     // keys of interest: [a, kend);  v > thr  <=>  key < (~bits(thr)) << 32
     const unsigned long long kend = (unsigned long long)(~__float_as_uint(thr)) << 32;
     unsigned long long a = (unsigned long long)(~mb) << 32;     // smallest possible key (value == max)
     const float md2 = min_distance * min_distance;
     const bool use_dist = min_distance >= 1.f;
-    __syncthreads();
-    int C;
-    if (hist) {                                                 // k_select_prep built the flat list and the histogram
-        const int total = cand_count[b * OFK_CNT_STRIDE];
-        if (total > cand_cap) {                                 // flat list overflow (uniform): the host reports OFK_E_CAPACITY
-            if (tid == 0) counts[b] = -1;
-            return;
-        }
-        C = total;
-    } else if (nseg > 0) {
-        // the streaming response kernel left one segment of keys per strip, pruned with a running threshold only:
-        // compact the keys that pass the exact threshold into the flat list (one LDS atomic per wave-iteration)
-        const unsigned long long *sbase = seg + (size_t)b * nseg * seg_cap;
-        // flat index over all segments: counts -> LDS, inclusive prefix (2 entries per thread), then every thread fetches
-        // independent keys (binary search for its segment), so the loads of a whole pass are in flight together
-        int *s_cnt = reinterpret_cast<int *>(s_hist);           // [SEL_BINS >= nseg]
-        int *s_pre = reinterpret_cast<int *>(s_key);            // aliases the sort buffer (unused until the first gather)
-        for (int i = tid; i < SEL_BINS; i += SEL_T) s_cnt[i] = i < nseg ? min(seg_count[(size_t)b * nseg + i], seg_cap) : 0;
-        __syncthreads();
-        int N;
-        {
-            const int h0 = s_cnt[2 * tid], h1 = s_cnt[2 * tid + 1];
-            int incl = h0 + h1;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const int n_ = __shfl_up(incl, o); if (lane >= o) incl += n_; }
-            if (lane == 63) s_wsum[wave] = (unsigned)incl;
-            __syncthreads();
-            int woff = 0, total = 0;
-            for (int q = 0; q < SEL_T / 64; ++q) { const int ws = (int)s_wsum[q]; if (q < wave) woff += ws; total += ws; }
-            s_pre[2 * tid + 1] = woff + incl; s_pre[2 * tid] = woff + incl - h1;
-            N = total;
-        }
-        __syncthreads();
-        // each wave owns a contiguous range of the flat index and walks it 4 x 64 keys at a time: one binary search per
-        // wave, a short forward scan per lane, four independent global loads in flight before the first is consumed
-        const int per_wave = (((N + SEL_T / 64 - 1) / (SEL_T / 64)) + 63) & ~63;
-        const int jbeg = min(N, wave * per_wave), jend = min(N, jbeg + per_wave);
-        int sg_w = 0;
-        {
-            int lo = 0, hi = nseg - 1;                          // smallest sg with s_pre[sg] > jbeg
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_pre[mid] > jbeg) hi = mid; else lo = mid + 1; }
-            sg_w = __builtin_amdgcn_readfirstlane(lo);
-        }
-        for (int j0 = jbeg; j0 < jend; j0 += 256) {
-            unsigned long long key[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int j = j0 + 64 * q + lane;
-                const bool valid = j < jend;
-                int sg = sg_w;
-                while (valid && s_pre[sg] <= j) ++sg;
-                if (q == 0) sg_w = __builtin_amdgcn_readfirstlane(sg);     // lane 0 of the first chunk: lower bound for what follows
-                const int off = j - (sg ? s_pre[sg - 1] : 0);
-                key[q] = valid ? sbase[(size_t)sg * seg_cap + off] : ~0ull;
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const bool keep = key[q] < kend;
-                const unsigned long long bal = __ballot(keep);
-                if (bal) {
-                    int base = 0;
-                    if (lane == 0) base = atomicAdd(&s_n, __popcll(bal));
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    const int pos = base + __popcll(bal & ((1ull << lane) - 1));
-                    if (keep && pos < cand_cap) cand[pos] = key[q];
-                }
-            }
-        }
-        __syncthreads();
-        C = min(s_n, cand_cap);
-        if (tid == 0) cand_count[b * OFK_CNT_STRIDE] = s_n;
-        if (s_n > cand_cap) {                                   // flat list overflow (uniform): the host reports OFK_E_CAPACITY
-            if (tid == 0) counts[b] = -1;
-            return;
-        }
-        __threadfence_block();
-        __syncthreads();
-    } else {
-        C = min(cand_count[b * OFK_CNT_STRIDE], cand_cap);
+    const int total_keys = cand_count[b * OFK_CNT_STRIDE];
+    if (total_keys > cand_cap) {                                // flat list overflow (uniform): the host reports OFK_E_CAPACITY
+        if (tid == 0) counts[b] = -1;
+        return;
     }
-    if (C == 0 || !(thr < __uint_as_float(mb))) return;         // nothing is strictly above the threshold
-
-    // keys handled per round: about twice the corners still wanted (sorting 4096 keys to accept 500 wasted 2/3 of the sort)
-    int tgt = 512;
-    while (tgt < 2 * max_corners && tgt < OFK_CHUNK) tgt <<= 1;
-    bool first_round = true;
-    while (a < kend) {
-        // ---- choose T in (a, kend] so that 1 <= #{a <= key < T} <= tgt (or detect that none is left)
-        unsigned long long curA = a, curB = kend, T = kend;
-        int taken = 0;
-        bool none_left = false;
-        bool have_cut = false;
-        if (hist && first_round) {
-            // the prep kernel's histogram starts at this round's lower bound: take as many leading bins as fit the budget
+    const int C = total_keys;
+    if (C <= 0 || !(thr < __uint_as_float(mb))) return;         // nothing is strictly above the threshold
+    const int tgt = sel_tgt(max_corners);
+    const int gw = (w + cs - 1) / cs, gh = (h + cs - 1) / cs;
+    const int nsel = min(cand_count[b * OFK_CNT_STRIDE + SEL_CNT_PICK], min(tgt, sel_stride));
+    const int Dbins = cand_count[b * OFK_CNT_STRIDE + SEL_CNT_BINS];
+    bool fast = Dbins > 0;                                      // k_select_pick made the first cut
+    bool grid_ready = false;
+    __syncthreads();
+    while (true) {
+        unsigned long long T = kend;
+        int n = 0;
+        if (fast) {
             const unsigned a_hi = ~mb, width = (unsigned)(kend >> 32) - a_hi;
             const int hshift = width <= SEL_HB ? 0 : 32 - __clz((int)(width - 1)) - 10;
-            unsigned incl = hist[(size_t)b * SEL_HB + tid];      // SEL_T == SEL_HB: one bin per thread
+            const unsigned long long cut = ((unsigned long long)a_hi + ((unsigned long long)Dbins << hshift)) << 32;
+            T = cut < kend ? cut : kend;
+            n = nsel;
+            const unsigned long long *src = sel_keys + (size_t)b * sel_stride;
+            for (int i = tid; i < n; i += SEL_T) s_key[i] = src[i];
+        } else {
+            if (!(a < kend)) break;
+            // ---- choose T in (a, kend] so that 1 <= #{a <= key < T} <= cap (or detect that none is left)
+            const int cap = tgtA / 2;                           // later rounds sort inside the index region: the grid and the accepted set live behind it
+            unsigned long long curA = a, curB = kend;
+            int taken = 0;
+            bool have_cut = false;
+            for (int level = 0; level < 9; ++level) {
+                const unsigned long long width = curB - curA;
+                const int shift = width <= SEL_NB ? 0 : 64 - __clzll((long long)(width - 1)) - 9;
+                const int nb = (int)((width - 1) >> shift) + 1;
+                for (int i = tid; i < SEL_NB; i += SEL_T) s_hist[i] = 0;
+                if (tid == 0) { s_D = 0; s_cum = 0; }
+                __syncthreads();
+                for (int i0 = tid; i0 < C; i0 += 4 * SEL_T) {
+                    unsigned long long key[4];
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const unsigned n_ = __shfl_up(incl, o); if (lane >= o) incl += n_; }
-            if (lane == 63) s_wsum[wave] = incl;
-            if (tid == 0) { s_D = 0; s_cum = 0; }
+                    for (int q = 0; q < 4; ++q) { const int i = i0 + q * SEL_T; key[q] = i < C ? cand[i] : ~0ull; }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (key[q] >= curA && key[q] < curB) atomicAdd(&s_hist[(unsigned)((key[q] - curA) >> shift)], 1u);
+                }
+                __syncthreads();
+                // inclusive prefix over the bins (SEL_NB / SEL_T per thread); D = #bins whose inclusive prefix fits the budget
+                constexpr int BPT = SEL_NB / SEL_T;
+                unsigned hv[BPT], loc = 0;
+#pragma unroll
+                for (int q = 0; q < BPT; ++q) { hv[q] = s_hist[BPT * tid + q]; loc += hv[q]; }
+                unsigned incl = loc;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const unsigned n_ = __shfl_up(incl, o); if (lane >= o) incl += n_; }
+                if (lane == 63) s_w[wave] = incl;
+                __syncthreads();
+                unsigned woff = 0, total = 0;
+#pragma unroll
+                for (int q = 0; q < NW; ++q) { const unsigned ws = s_w[q]; if (q < wave) woff += ws; total += ws; }
+                const int budget = cap - taken;
+                unsigned pre = woff + incl - loc;               // exclusive prefix of this thread's first bin
+                int fit = 0;
+#pragma unroll
+                for (int q = 0; q < BPT; ++q) { pre += hv[q]; fit += (int)pre <= budget; }
+                if (fit) atomicAdd(&s_D, fit);
+                __syncthreads();
+                const int D = min(s_D, nb);
+                // the thread that owns bin D - 1 knows the keys below the cut (prefixes are non-decreasing: the fitting bins are a leading run)
+                if (D > 0 && (D - 1) / BPT == tid) {
+                    unsigned p2 = woff + incl - loc;
+#pragma unroll
+                    for (int q = 0; q < BPT; ++q) { p2 += hv[q]; if (BPT * tid + q == D - 1) s_cum = (int)p2; }
+                }
+                __syncthreads();
+                taken += s_cum;
+                if (level == 0 && total == 0) break;            // no key left in [a, kend)
+                if (D >= nb) { T = curB; have_cut = true; break; }             // everything in [curA, curB) fits
+                const unsigned long long newA = curA + ((unsigned long long)D << shift);
+                if (taken >= cap / 4) { T = newA; have_cut = true; break; }
+                curA = newA;                                    // descend into the first bin that did not fit
+                const unsigned long long bin_end = newA + (1ull << shift);
+                if (bin_end < curB) curB = bin_end;
+                __syncthreads();                                // s_D / s_cum are reset at the top of the next level
+            }
+            if (!have_cut) break;                               // (nine levels of nine bits always reach single keys: a cut exists unless nothing is left)
+            // ---- gather keys in [a, T)
             __syncthreads();
-            unsigned woff = 0;
-            for (int q = 0; q < wave; ++q) woff += s_wsum[q];
-            incl += woff;
-            if ((int)incl <= tgt) atomicAdd(&s_D, 1);            // prefixes are non-decreasing: the fitting bins are a leading run
+            if (tid == 0) s_n = 0;
             __syncthreads();
-            const int D = s_D;
-            if (D > 0 && tid == D - 1) s_cum = (int)incl;
-            __syncthreads();
-            if (D > 0 && s_cum > 0) {
-                taken = s_cum;
-                const unsigned long long cut = ((unsigned long long)a_hi + ((unsigned long long)D << hshift)) << 32;
-                T = cut < kend ? cut : kend;
-                have_cut = true;
+            for (int i0 = tid; i0 < C; i0 += 4 * SEL_T) {
+                unsigned long long key[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const int i = i0 + q * SEL_T; key[q] = i < C ? cand[i] : ~0ull; }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (key[q] >= a && key[q] < T) { const int slot = atomicAdd(&s_n, 1); if (slot < cap) s_key[slot] = key[q]; }
             }
             __syncthreads();
+            n = min(s_n, cap);
         }
-        first_round = false;
-        for (int level = 0; level < 8 && !have_cut; ++level) {
-            const unsigned long long width = curB - curA;
-            const int shift = width <= SEL_BINS ? 0 : 64 - __clzll((long long)(width - 1)) - 11;
-            const int nb = (int)((width - 1) >> shift) + 1;
-            for (int i = tid; i < SEL_BINS; i += SEL_T) s_hist[i] = 0;
-            __syncthreads();
-            for (int i = tid; i < C; i += SEL_T) {
-                const unsigned long long key = cand[i];
-                if (key >= curA && key < curB) atomicAdd(&s_hist[(unsigned)((key - curA) >> shift)], 1u);
-            }
-            __syncthreads();
-            // inclusive prefix over the bins (2 bins per thread); D = #bins whose inclusive prefix fits the budget
-            const unsigned h0 = s_hist[2 * tid], h1 = s_hist[2 * tid + 1];
-            unsigned incl = h0 + h1;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const unsigned n_ = __shfl_up(incl, o); if (lane >= o) incl += n_; }
-            if (lane == 63) s_wsum[wave] = incl;
-            if (tid == 0) { s_D = 0; s_cum = 0; }
-            __syncthreads();
-            unsigned woff = 0, total = 0;
-            for (int q = 0; q < SEL_T / 64; ++q) { const unsigned ws = s_wsum[q]; if (q < wave) woff += ws; total += ws; }
-            const unsigned i1 = woff + incl, i0 = i1 - h1;      // inclusive prefixes of bins 2*tid and 2*tid+1
-            const int budget = tgt - taken;
-            const int fit = ((int)i0 <= budget) + ((int)i1 <= budget);
-            if (fit) atomicAdd(&s_D, fit);
-            __syncthreads();
-            const int D = min(s_D, nb);
-            if (D > 0 && (D - 1) / 2 == tid) s_cum = (int)(((D - 1) & 1) ? i1 : i0);
-            __syncthreads();
-            taken += s_cum;
-            if (level == 0 && total == 0) { none_left = true; break; }
-            if (D >= nb) { T = curB; break; }                  // everything in [curA, curB) fits
-            const unsigned long long newA = curA + ((unsigned long long)D << shift);
-            if (taken >= tgt / 4) { T = newA; break; }
-            curA = newA;                                        // descend into the first bin that did not fit
-            const unsigned long long bin_end = newA + (1ull << shift);
-            if (bin_end < curB) curB = bin_end;
-        }
-        if (none_left) break;
-        // ---- gather keys in [a, T)
-        __syncthreads();
-        if (tid == 0) s_n = 0;
-        __syncthreads();
-        // four independent loads in flight per thread (the loop is latency-bound: 45 trips over 46 k candidates at 1080p)
-        for (int i0 = tid; i0 < C; i0 += 4 * SEL_T) {
-            unsigned long long key[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { const int i = i0 + q * SEL_T; key[q] = i < C ? cand[i] : ~0ull; }
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (key[q] >= a && key[q] < T) { const int slot = atomicAdd(&s_n, 1); if (slot < OFK_CHUNK) s_key[slot] = key[q]; }
-        }
-        __syncthreads();
-        const int n = min(s_n, OFK_CHUNK);
+        fast = false;
         int npad = 64;
         while (npad < n) npad <<= 1;
         for (int i = n + tid; i < npad; i += SEL_T) s_key[i] = ~0ull;
         __syncthreads();
-        // ---- bitonic sort ascending
-        // (element i belongs to thread i % 1024, so for j < 64 both partners of a compare-exchange sit in the same wave:
-        //  those steps need no workgroup barrier — LDS executes a wave's accesses in order)
+        // ---- bitonic sort ascending.  Element i is handled by thread i % SEL_T: for j >= SEL_T both partners of a compare-exchange
+        // belong to the same thread, for j < 64 to the same wave (LDS executes a wave's accesses in order) — only the steps with
+        // 64 <= j < SEL_T exchange between waves and need the workgroup barrier, before and after.
         for (int kk = 2; kk <= npad; kk <<= 1)
             for (int j = kk >> 1; j > 0; j >>= 1) {
                 for (int i = tid; i < npad; i += SEL_T) {
@@ -1310,46 +1408,76 @@ __global__ __launch_bounds__(SEL_T) void k_select(unsigned long long *__restrict
                         if ((x0 > x1) == up) { s_key[i] = x1; s_key[p] = x0; }
                     }
                 }
-                if (j >= 64 || j == 1) __syncthreads();         // j == 1 ends a kk stage: the next stage starts with j = kk/2
+                const int nj = j > 1 ? (j >> 1) : kk;           // the step that follows (first step of the next stage: j = kk)
+                if ((j >= 64 && j < SEL_T) || (nj >= 64 && nj < SEL_T)) __syncthreads();
                 else __builtin_amdgcn_wave_barrier();
             }
+        __syncthreads();
+        // ---- sorted keys -> sorted pixel positions x | y << 16, in place (the key holds ~index: equal responses sort by DESCENDING
+        //      index); the two divisions per candidate happen here, once, spread over the whole workgroup
+        {
+            unsigned idxv[OFK_CHUNK / SEL_T];
+#pragma unroll
+            for (int q = 0; q < OFK_CHUNK / SEL_T; ++q) {
+                const int i = tid + q * SEL_T;
+                const unsigned idx = i < n ? ~(unsigned)(s_key[i] & 0xffffffffu) : 0u;
+                const unsigned y = idx / (unsigned)w;
+                idxv[q] = (idx - y * (unsigned)w) | (y << 16);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < OFK_CHUNK / SEL_T; ++q) { const int i = tid + q * SEL_T; if (i < n) s_idx[i] = idxv[q]; }
+        }
+        if (!grid_ready) {                                      // the first sort may have run over the grid's place
+            unsigned *g32 = reinterpret_cast<unsigned *>(sel_smem + 4 * (size_t)tgtA);
+            for (int i = tid; i < tgtA / 2; i += SEL_T) g32[i] = 0xffffffffu;
+            grid_ready = true;
+        }
+        __syncthreads();
         // ---- greedy over the sorted chunk, 64 candidates per round
         for (int base = 0; base < n; base += 64) {
             const int nacc = s_nacc;
             if (nacc >= max_corners) break;
             const int ci = base + lane;
             const bool live = ci < n;
-            const unsigned idx = live ? ~(unsigned)(s_key[ci] & 0xffffffffu) : 0u;     // the key holds ~index: equal responses sort by DESCENDING index
-            const int cx = (int)(idx % (unsigned)w), cy = (int)(idx / (unsigned)w);
-            // every wave tests the round's 64 candidates against its share of the accepted set (4 independent LDS reads
-            // in flight, no early exit) and builds 4 rows of the round's conflict matrix
-            bool rej = false;
+            const unsigned xy = live ? s_idx[ci] : 0u;
+            const int cx = (int)(xy & 0xffffu), cy = (int)(xy >> 16);
             if (use_dist) {
-                for (int j = wave * 4; j < nacc; j += 4 * (SEL_T / 64)) {
-                    const int a0 = s_acc_xy[j], a1 = s_acc_xy[min(j + 1, nacc - 1)], a2 = s_acc_xy[min(j + 2, nacc - 1)],
-                              a3 = s_acc_xy[min(j + 3, nacc - 1)];
-                    const int dx0 = cx - (a0 & 0xffff), dy0 = cy - (a0 >> 16), dx1 = cx - (a1 & 0xffff), dy1 = cy - (a1 >> 16);
-                    const int dx2 = cx - (a2 & 0xffff), dy2 = cy - (a2 >> 16), dx3 = cx - (a3 & 0xffff), dy3 = cy - (a3 >> 16);
-                    rej = rej || (float)(dx0 * dx0 + dy0 * dy0) < md2 || (float)(dx1 * dx1 + dy1 * dy1) < md2 ||
-                          (float)(dx2 * dx2 + dy2 * dy2) < md2 || (float)(dx3 * dx3 + dy3 * dy3) < md2;
-                }
+                // every wave builds its share of the round's 64 x 64 conflict matrix
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int j = __builtin_amdgcn_readfirstlane(wave) * 4 + q;   // candidate (lane) j of this round
+                for (int q = 0; q < 64 / NW; ++q) {
+                    const int j = __builtin_amdgcn_readfirstlane(wave) * (64 / NW) + q;   // candidate (lane) j of this round
                     const int jx = __builtin_amdgcn_readlane(cx, j), jy = __builtin_amdgcn_readlane(cy, j);
                     const int dx = cx - jx, dy = cy - jy;
                     const unsigned long long bj = __ballot((float)(dx * dx + dy * dy) < md2);
                     if (lane == 0) s_conf[j] = bj;
                 }
             }
-            const unsigned long long bal = __ballot(rej && live);
-            if (lane == 0) s_rej[wave] = bal;
             __syncthreads();
             if (wave == 0) {
-                unsigned long long r = 0;
+                // the accepted set through the grid: corners closer than minDistance sit in the 3 x 3 cells around the candidate's
+                const int gx = cx / cs, gy = cy / cs;
+                bool rej = false;
+                if (use_dist && live) {
+                    unsigned head[9];                           // the nine cell heads first (independent LDS reads), then the short chains
 #pragma unroll
-                for (int q = 0; q < SEL_T / 64; ++q) r |= s_rej[q];
-                const unsigned long long alive = __ballot(live) & ~r;   // survivors of the accepted-set test, best first
+                    for (int q = 0; q < 9; ++q) {
+                        const int yy = gy + q / 3 - 1, xx = gx + q % 3 - 1;
+                        const bool in = yy >= 0 && yy < gh && xx >= 0 && xx < gw;
+                        head[q] = in ? (unsigned)s_grid[in ? yy * gw + xx : 0] : 0xffffu;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) {
+                        unsigned j = head[q];
+                        while (j != 0xffffu) {
+                            const int aj = s_acc[j];
+                            const int dx = cx - (aj & 0xffff), dy = cy - (aj >> 16);
+                            rej = rej || (float)(dx * dx + dy * dy) < md2;
+                            j = s_next[j];
+                        }
+                    }
+                }
+                const unsigned long long alive = __ballot(live && !rej);   // survivors of the accepted-set test, best first
                 const unsigned long long myconf = use_dist ? s_conf[lane] : 0ull;   // lanes clashing with candidate `lane`
                 // Greedy acceptance in rank order, a few parallel sweeps instead of one scalar step per candidate: U = candidates not
                 // decided yet, with everything that clashes with an accepted one already removed.  A lane whose earlier clashing
@@ -1367,11 +1495,27 @@ __global__ __launch_bounds__(SEL_T) void k_select(unsigned long long *__restrict
                 }
                 const int room = max_corners - nacc;
                 const unsigned long long acc = __ballot(((A >> lane) & 1ull) && __popcll(A & lower) < room);
-                if ((acc >> lane) & 1ull) {                      // accepted candidates store in parallel, in rank order
-                    const int pos = nacc + __popcll(acc & ((1ull << lane) - 1));
-                    s_acc_xy[pos] = cx | (cy << 16);
+                const bool mine = (acc >> lane) & 1ull;
+                const int pos = nacc + __popcll(acc & lower);   // accepted candidates store in parallel, in rank order
+                if (mine) {
+                    s_acc[pos] = cx | (cy << 16);
                     pts[((size_t)b * pts_stride + pos) * 2] = (float)cx;
                     pts[((size_t)b * pts_stride + pos) * 2 + 1] = (float)cy;
+                }
+                if (use_dist) {
+                    // link the new corners into their cells: all lanes store their index as the cell's head, the lane that reads its
+                    // own index back won and chains to the old head; the others of that cell go again (order inside a cell is free)
+                    bool pend = mine;
+                    const int cell = gy * gw + gx;
+                    while (__ballot(pend)) {
+                        unsigned old = 0xffffu;
+                        if (pend) old = s_grid[cell];
+                        __builtin_amdgcn_wave_barrier();
+                        if (pend) s_grid[cell] = (unsigned short)pos;
+                        __builtin_amdgcn_wave_barrier();
+                        if (pend && s_grid[cell] == (unsigned short)pos) { s_next[pos] = (unsigned short)old; pend = false; }
+                        __builtin_amdgcn_wave_barrier();
+                    }
                 }
                 if (lane == 0) s_nacc = nacc + __popcll(acc);
             }
@@ -1402,17 +1546,21 @@ void ofk_launch_zero_detect_state(hipStream_t s, unsigned int *maxbits, int *can
 }
 
 void ofk_launch_select(hipStream_t s, unsigned long long *cand, int cand_cap, int *cand_count, const unsigned long long *seg,
-                       int seg_cap, const int *seg_count, int nseg, const unsigned int *maxbits, double quality, int w,
+                       int seg_cap, const int *seg_count, int nseg, const unsigned int *maxbits, double quality, int h, int w,
                        int max_corners, float min_distance, float *pts, int pts_stride, int *counts, const int *limit, int batch,
-                       unsigned *sel_hist, bool hist_is_zero)
+                       unsigned *sel_hist, unsigned long long *sel_keys, bool hist_is_zero)
 {
-    static_assert(SEL_T == SEL_HB, "k_select reads one histogram bin per thread");
-    const bool prep = nseg > 0 && sel_hist != nullptr;          // segments from the streaming response kernels: compact + histogram on SEL_G workgroups per image
-    if (prep) {
-        if (!hist_is_zero) hipMemsetAsync(sel_hist, 0, (size_t)batch * SEL_HB * sizeof(unsigned), s);
-        hipLaunchKernelGGL(k_select_prep, dim3(SEL_G, batch), dim3(256), 0, s, cand, cand_cap, cand_count, seg, seg_cap, seg_count, nseg, maxbits,
-                           quality, sel_hist, limit);
-    }
-    hipLaunchKernelGGL(k_select, dim3(batch), dim3(SEL_T), 0, s, cand, cand_cap, cand_count, seg, seg_cap, seg_count, nseg, maxbits,
-                       quality, w, max_corners, min_distance, pts, pts_stride, counts, limit, prep ? sel_hist : nullptr);
+    if (!hist_is_zero) (void)hipMemsetAsync(sel_hist, 0, (size_t)batch * SEL_HB * sizeof(unsigned), s);
+    hipLaunchKernelGGL(k_select_prep, dim3(SEL_G, batch), dim3(256), 0, s, cand, cand_cap, cand_count, seg, seg_cap, seg_count, nseg, maxbits,
+                       quality, sel_hist, limit);
+    hipLaunchKernelGGL(k_select_pick, dim3(SEL_G, batch), dim3(256), 0, s, cand, cand_cap, cand_count, maxbits, quality, sel_hist, limit,
+                       max_corners, sel_keys, OFK_CHUNK);
+    const int tgtA = sel_tgt(max_corners);
+    // grid of the accepted corners: cells at least minDistance wide, coarsened until the image has at most tgtA of them
+    const int cs0 = min_distance >= 1.f ? (int)ceilf(min_distance) : 1;
+    int cs = cs0;
+    while ((long long)((w + cs - 1) / cs) * ((h + cs - 1) / cs) > tgtA) cs += cs0;
+    const size_t lds = (size_t)8 * tgtA > (size_t)6 * tgtA + (size_t)6 * max_corners + 16 ? (size_t)8 * tgtA : (size_t)6 * tgtA + (size_t)6 * max_corners + 16;
+    hipLaunchKernelGGL(k_select_greedy, dim3(batch), dim3(SEL_T), lds, s, cand, cand_cap, cand_count, maxbits, quality, w, h, max_corners,
+                       min_distance, pts, pts_stride, counts, limit, sel_keys, OFK_CHUNK, tgtA, cs);
 }

@@ -241,71 +241,92 @@ __device__ __forceinline__ void rtilde_point(double x, double y, double ux, doub
 }
 
 // ------------------------------------------------------------------------------------------------ frame-pair solve
-// One block per pair: x = (next - c) * scaling, u = (next - prev) * scaling for tracked points (node:229-235),
+// One WAVE per pair: x = (next - c) * scaling, u = (next - prev) * scaling for tracked points (node:229-235),
 // optional r_tilde filter (node:238-245), solve (node:257), lever arm + rotation (node:258).
-__global__ __launch_bounds__(256) void k_pairs_solve(const float *__restrict__ prev_pts, const float *__restrict__ next_pts,
-                                                     const uint8_t *__restrict__ status, const int *__restrict__ counts,
-                                                     int pts_stride, const double *__restrict__ sensors, int variant,
-                                                     int use_feas, double feas_T, const int *__restrict__ cand_count,
-                                                     double *__restrict__ records)
+// A single wave moves in wherever one wave of the other slice's response kernel or LK retires; the 256-thread workgroup of rounds
+// 1-2 needed four wave slots with ~90 VGPRs each on one CU at the same moment and waited for them (13.6 us alone, 186 us mean /
+// 0.8 ms worst beside the response kernel, profiles/r02_kernel_stats_slices2.csv).  The sums are formed exactly as that workgroup
+// formed them - four "virtual waves" v = 0..3 take the points v*64 + lane + 256 k, each is reduced by the same shuffle butterfly,
+// and the four partial sums are added as (s0 + s1) + (s2 + s3) - so the records are the same bit for bit (fp64 addition is
+// not associative; k_stream_fuse and the stand-alone k_solve keep that order too).
+__device__ __forceinline__ bool pair_point(const float *pp, const float *np_, int i, double cx, double cy, double scaling, int use_feas,
+                                           double feas_T, const double *nrm, const double *vp, double d, double &x, double &y, double &ux,
+                                           double &uy)
 {
-    __shared__ double s_red[4];
-    __shared__ double s_v[8];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    x = ((double)np_[2 * i] - cx) * scaling; y = ((double)np_[2 * i + 1] - cy) * scaling;
+    ux = ((double)np_[2 * i] - (double)pp[2 * i]) * scaling; uy = ((double)np_[2 * i + 1] - (double)pp[2 * i + 1]) * scaling;
+    if (use_feas) {
+        double r, dd;
+        rtilde_point(x, y, ux, uy, nrm, vp, d, r, dd);
+        if (!(r <= feas_T)) return false;
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(64) void k_pairs_solve(const float *__restrict__ prev_pts, const float *__restrict__ next_pts,
+                                                    const uint8_t *__restrict__ status, const int *__restrict__ counts,
+                                                    int pts_stride, const double *__restrict__ sensors, int variant,
+                                                    int use_feas, double feas_T, const int *__restrict__ cand_count,
+                                                    double *__restrict__ records)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
     const double *sn = sensors + (size_t)b * OFK_SENSOR_DOUBLES;
     const double d = sn[0], nrm[3] = {sn[1], sn[2], sn[3]}, om[3] = {sn[4], sn[5], sn[6]};
     const double scaling = sn[19], cx = sn[20], cy = sn[21], vp[3] = {sn[22], sn[23], sn[24]};
     const int n = counts[b];
     const float *pp = prev_pts + (size_t)b * pts_stride * 2, *np_ = next_pts + (size_t)b * pts_stride * 2;
     const uint8_t *st = status + (size_t)b * pts_stride;
-    Acc a; acc_zero(a);
-    double tracked = 0.0;
-    for (int i = tid; i < n; i += 256) {
-        if (!st[i]) continue;
-        tracked += 1.0;
-        const double x = ((double)np_[2 * i] - cx) * scaling, y = ((double)np_[2 * i + 1] - cy) * scaling;
-        const double ux = ((double)np_[2 * i] - (double)pp[2 * i]) * scaling, uy = ((double)np_[2 * i + 1] - (double)pp[2 * i + 1]) * scaling;
-        if (use_feas) {
-            double r, dd;
-            rtilde_point(x, y, ux, uy, nrm, vp, d, r, dd);
-            if (!(r <= feas_T)) continue;
+    __shared__ double part[4][13];                               // wave-reduced sums of the four virtual waves (12: the residual)
+#pragma unroll 1
+    for (int vw = 0; vw < 4; ++vw) {
+        Acc a; acc_zero(a);
+        double tracked = 0.0;
+        for (int i = vw * 64 + lane; i < n; i += 256) {
+            if (!st[i]) continue;
+            tracked += 1.0;
+            double x, y, ux, uy;
+            if (!pair_point(pp, np_, i, cx, cy, scaling, use_feas, feas_T, nrm, vp, d, x, y, ux, uy)) continue;
+            double q0, q1, q2, sA, sB;
+            point_terms(variant, x, y, ux, uy, nrm, om, d, 1.0, q0, q1, q2, sA, sB);
+            acc_point(a, x, y, q0, q1, q2, sA, sB);
         }
-        double q0, q1, q2, sA, sB;
-        point_terms(variant, x, y, ux, uy, nrm, om, d, 1.0, q0, q1, q2, sA, sB);
-        acc_point(a, x, y, q0, q1, q2, sA, sB);
+        const double v[12] = {a.m00, a.m01, a.m02, a.m11, a.m12, a.m22, a.g0, a.g1, a.g2, a.bb, a.cnt, tracked};
+#pragma unroll
+        for (int k = 0; k < 12; ++k) { const double w_ = wave_sum(v[k]); if (lane == 0) part[vw][k] = w_; }
     }
-    acc_block_sum(a, s_red);
-    tracked = block_sum(tracked, s_red);
-    if (tid == 0) {
-        double v[3] = {0, 0, 0}, s3[3] = {0, 0, 0};
-        const int rank = a.cnt > 0.0 ? solve_from_acc(a, v, s3) : 0;
-        s_v[0] = v[0]; s_v[1] = v[1]; s_v[2] = v[2]; s_v[3] = (double)rank; s_v[4] = s3[0]; s_v[5] = s3[1]; s_v[6] = s3[2];
-    }
-    __syncthreads();
-    const double v[3] = {s_v[0], s_v[1], s_v[2]};
-    double r = 0.0;
-    for (int i = tid; i < n; i += 256) {
-        if (!st[i]) continue;
-        const double x = ((double)np_[2 * i] - cx) * scaling, y = ((double)np_[2 * i + 1] - cy) * scaling;
-        const double ux = ((double)np_[2 * i] - (double)pp[2 * i]) * scaling, uy = ((double)np_[2 * i + 1] - (double)pp[2 * i + 1]) * scaling;
-        if (use_feas) {
-            double rr, dd;
-            rtilde_point(x, y, ux, uy, nrm, vp, d, rr, dd);
-            if (!(rr <= feas_T)) continue;
+    __builtin_amdgcn_wave_barrier();                             // one wave: LDS executes its accesses in order
+    double t[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) t[k] = (part[0][k] + part[1][k]) + (part[2][k] + part[3][k]);
+    Acc a;
+    a.m00 = t[0]; a.m01 = t[1]; a.m02 = t[2]; a.m11 = t[3]; a.m12 = t[4]; a.m22 = t[5]; a.g0 = t[6]; a.g1 = t[7]; a.g2 = t[8]; a.bb = t[9]; a.cnt = t[10];
+    const double tracked = t[11];
+    double v[3] = {0, 0, 0}, s3[3] = {0, 0, 0};                  // every lane solves the same 3x3 system: no broadcast, no barrier
+    const int rank = a.cnt > 0.0 ? solve_from_acc(a, v, s3) : 0;
+#pragma unroll 1
+    for (int vw = 0; vw < 4; ++vw) {
+        double r = 0.0;
+        for (int i = vw * 64 + lane; i < n; i += 256) {
+            if (!st[i]) continue;
+            double x, y, ux, uy;
+            if (!pair_point(pp, np_, i, cx, cy, scaling, use_feas, feas_T, nrm, vp, d, x, y, ux, uy)) continue;
+            double q0, q1, q2, sA, sB;
+            point_terms(variant, x, y, ux, uy, nrm, om, d, 1.0, q0, q1, q2, sA, sB);
+            r += resid_point(x, y, q0, q1, q2, sA, sB, v);
         }
-        double q0, q1, q2, sA, sB;
-        point_terms(variant, x, y, ux, uy, nrm, om, d, 1.0, q0, q1, q2, sA, sB);
-        r += resid_point(x, y, q0, q1, q2, sA, sB, v);
+        r = wave_sum(r);
+        if (lane == 0) part[vw][12] = r;
     }
-    r = block_sum(r, s_red);
-    if (tid == 0) {
+    __builtin_amdgcn_wave_barrier();
+    const double r = (part[0][12] + part[1][12]) + (part[2][12] + part[3][12]);
+    if (lane == 0) {
         double *o = records + (size_t)b * OFK_RECORD_DOUBLES;
         const double *R = sn + 7, *off = sn + 16;
         // v_obs - [w]x offset, then rotate (node:258)
         const double e0 = v[0] - (om[1] * off[2] - om[2] * off[1]);
         const double e1 = v[1] - (om[2] * off[0] - om[0] * off[2]);
         const double e2 = v[2] - (om[0] * off[1] - om[1] * off[0]);
-        o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = r; o[4] = s_v[3]; o[5] = s_v[4]; o[6] = s_v[5]; o[7] = s_v[6];
+        o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = r; o[4] = (double)rank; o[5] = s3[0]; o[6] = s3[1]; o[7] = s3[2];
         o[8] = R[0] * e0 + R[1] * e1 + R[2] * e2; o[9] = R[3] * e0 + R[4] * e1 + R[5] * e2; o[10] = R[6] * e0 + R[7] * e1 + R[8] * e2;
         o[11] = a.cnt; o[12] = (double)n; o[13] = tracked; o[14] = cand_count ? (double)cand_count[b * OFK_CNT_STRIDE] : 0.0; o[15] = 0.0;
     }
@@ -315,7 +336,7 @@ void ofk_launch_pairs_solve(hipStream_t s, const float *prev_pts, const float *n
                             const int *counts, int pts_stride, const double *sensors, int variant, int use_feas,
                             double feas_T, const int *cand_count, double *records, int batch)
 {
-    hipLaunchKernelGGL(k_pairs_solve, dim3(batch), dim3(256), 0, s, prev_pts, next_pts, status, counts, pts_stride, sensors,
+    hipLaunchKernelGGL(k_pairs_solve, dim3(batch), dim3(64), 0, s, prev_pts, next_pts, status, counts, pts_stride, sensors,
                        variant, use_feas, feas_T, cand_count, records);
 }
 

@@ -168,6 +168,7 @@ extern "C" int ofk_create(int device, int max_w, int max_h, int max_batch, int m
     ALLOC(c->seg_count, B * OFK_SEG_MAX * 4);
     ALLOC(c->cand_count, B * OFK_CNT_STRIDE * 4); ALLOC(c->maxbits, B * OFK_MAX_STRIDE * 4);
     ALLOC(c->sel_hist, B * 1024 * 4);
+    ALLOC(c->sel_keys, B * OFK_CHUNK * 8);
     ALLOC(c->pts_prev, B * max_pts * 8); ALLOC(c->pts_next, B * max_pts * 8);
     ALLOC(c->status, B * max_pts); ALLOC(c->err, B * max_pts * 4); ALLOC(c->counts, B * 4);
     ALLOC(c->sensors, B * OFK_SENSOR_DOUBLES * 8); ALLOC(c->records, B * OFK_RECORD_DOUBLES * 8);
@@ -191,7 +192,7 @@ extern "C" int ofk_destroy(ofk_ctx *c)
     if (c->stream) hipDeviceSynchronize();
     ofk_comm_destroy(c);
     for (int k = 0; k < 2; ++k) { if (c->bgr[k]) hipFree(c->bgr[k]); if (c->pyr[k]) hipFree(c->pyr[k]); }
-    void *ptrs[] = {c->eig, c->mask, c->deriv, c->cand, c->cand_seg, c->seg_count, c->cand_count, c->sel_hist, c->maxbits, c->pts_prev, c->pts_next, c->status, c->err,
+    void *ptrs[] = {c->eig, c->mask, c->deriv, c->cand, c->cand_seg, c->seg_count, c->cand_count, c->sel_hist, c->sel_keys, c->maxbits, c->pts_prev, c->pts_next, c->status, c->err,
                     c->counts, c->sensors, c->records, c->dev_flags, c->scratch, c->pts_new, c->new_counts, c->limit,
                     c->imu_state, c->imu_dv, c->kf_mats, c->kf_x, c->kf_P, c->fused, c->imu_msgs, c->imu_counts};
     for (void *p : ptrs) if (p) hipFree(p);
@@ -410,8 +411,8 @@ static int run_select(ofk_ctx *c, bool have_max, const uint8_t *dmask, int batch
     OFK_HIP(c, hipMemsetAsync(c->cand_count, 0, (size_t)batch * OFK_CNT_STRIDE * 4, c->stream));
     ofk_launch_nms(c->stream, c->eig, c->img_stride, dmask, c->img_stride, h, w, c->maxbits, quality, c->cand, c->cand_cap,
                    c->cand_count, c->dev_flags, batch);
-    ofk_launch_select(c->stream, c->cand, c->cand_cap, c->cand_count, nullptr, 0, nullptr, 0, c->maxbits, quality, w, max_corners,
-                      (float)min_distance, c->pts_prev, c->max_pts, c->counts, nullptr, batch, nullptr);
+    ofk_launch_select(c->stream, c->cand, c->cand_cap, c->cand_count, nullptr, 0, nullptr, 0, c->maxbits, quality, h, w, max_corners,
+                      (float)min_distance, c->pts_prev, c->max_pts, c->counts, nullptr, batch, c->sel_hist, c->sel_keys);
     return check_launch(c, "corner selection");
 }
 
@@ -463,8 +464,8 @@ extern "C" int ofk_good_features(ofk_ctx *c, const uint8_t *gray, const uint8_t 
                                c->cand_cap, c->cand_count, c->cand_seg, c->seg_keys, c->seg_count, OFK_SEG_MAX, c->dev_flags, batch,
                                &nseg, &segcap))
         return ofk_fail(c, OFK_E_INVALID, "corner response: block_size %d does not fit (LDS tile / key segments)", block);
-    ofk_launch_select(c->stream, c->cand, c->cand_cap, c->cand_count, c->cand_seg, segcap, c->seg_count, nseg, c->maxbits, quality, w,
-                      max_corners, (float)min_distance, c->pts_prev, c->max_pts, c->counts, nullptr, batch, c->sel_hist);
+    ofk_launch_select(c->stream, c->cand, c->cand_cap, c->cand_count, c->cand_seg, segcap, c->seg_count, nseg, c->maxbits, quality, h, w,
+                      max_corners, (float)min_distance, c->pts_prev, c->max_pts, c->counts, nullptr, batch, c->sel_hist, c->sel_keys);
     TRY(check_launch(c, "corner detection"));
     return fetch_corners(c, batch, max_corners, pts, counts);
 }
@@ -955,8 +956,9 @@ extern "C" int ofk_pairs_run(ofk_ctx *c, const ofk_params *p)
         if (fork) OFK_HIP(c, hipEventRecord(c->ev_stagger[k], st));
         {
             StageTimer t(c, OFK_STAGE_SELECT, st);
-            ofk_launch_select(st, cand, c->cand_cap, cand_count, cand_seg, segcap, seg_count, nseg, maxbits, p->quality, w, p->max_corners,
-                              (float)p->min_distance, pts_prev, c->max_pts, counts, nullptr, nb, c->sel_hist + (size_t)b0 * 1024, true);
+            ofk_launch_select(st, cand, c->cand_cap, cand_count, cand_seg, segcap, seg_count, nseg, maxbits, p->quality, h, w, p->max_corners,
+                              (float)p->min_distance, pts_prev, c->max_pts, counts, nullptr, nb, c->sel_hist + (size_t)b0 * 1024,
+                              c->sel_keys + (size_t)b0 * OFK_CHUNK, true);
         }
         if (overlap) OFK_HIP(c, hipStreamWaitEvent(st, c->ev_aux[k], 0));    // LK needs both pyramids
         {
@@ -1059,8 +1061,8 @@ static int stream_detect(ofk_ctx *c, int k, const uint8_t *dmask, const int *lim
                                c->cand_cap, c->cand_count, c->cand_seg, c->seg_keys, c->seg_count, OFK_SEG_MAX, c->dev_flags, batch, &nseg,
                                &segcap))
         return ofk_fail(c, OFK_E_INVALID, "corner response: block_size %d does not fit (LDS tile / key segments)", p->block_size);
-    ofk_launch_select(c->stream, c->cand, c->cand_cap, c->cand_count, c->cand_seg, segcap, c->seg_count, nseg, c->maxbits, p->quality, w,
-                      p->max_corners, (float)p->min_distance, dst, c->max_pts, dst_counts, limit, batch, c->sel_hist);
+    ofk_launch_select(c->stream, c->cand, c->cand_cap, c->cand_count, c->cand_seg, segcap, c->seg_count, nseg, c->maxbits, p->quality, h, w,
+                      p->max_corners, (float)p->min_distance, dst, c->max_pts, dst_counts, limit, batch, c->sel_hist, c->sel_keys);
     return check_launch(c, "stream corner detection");
 }
 

@@ -56,6 +56,7 @@ struct ofk_ctx {
     size_t seg_keys;                // keys per image in cand_seg
     int *cand_count;                // [B][OFK_CNT_STRIDE]
     unsigned *sel_hist;             // [B][1024]                  key histogram of k_select_prep
+    unsigned long long *sel_keys;   // [B][OFK_CHUNK]             keys below the first cut, picked by k_select_pick for k_select_greedy
     unsigned int *maxbits;          // [B][OFK_MAX_STRIDE]                       bit pattern of max positive response
     float *pts_prev, *pts_next;     // [B][max_pts][2]
     uint8_t *status;                // [B][max_pts]
@@ -127,9 +128,9 @@ int  ofk_launch_mineig_cand(hipStream_t s, const uint8_t *gray, size_t gray_stri
                             int *segcap_out);
 void ofk_stream_geometry(int h, int w, int block, int batch, int *rows, int *nseg, int *seg_cap);
 void ofk_launch_select(hipStream_t s, unsigned long long *cand, int cand_cap, int *cand_count, const unsigned long long *seg,
-                       int seg_cap, const int *seg_count, int nseg, const unsigned int *maxbits, double quality, int w,
+                       int seg_cap, const int *seg_count, int nseg, const unsigned int *maxbits, double quality, int h, int w,
                        int max_corners, float min_distance, float *pts, int pts_stride, int *counts, const int *limit, int batch,
-                       unsigned *sel_hist, bool hist_is_zero = false);
+                       unsigned *sel_hist, unsigned long long *sel_keys, bool hist_is_zero = false);   // nseg == 0: the flat list holds the candidates already
 void ofk_launch_zero_detect_state(hipStream_t s, unsigned int *maxbits, int *cand_count, unsigned *sel_hist, int batch);                     // [batch][1024] scratch of the multi-workgroup prefilter (NULL: single-workgroup path)
 void ofk_launch_disc_mask(hipStream_t s, uint8_t *mask, size_t mask_stride, int h, int w, const float *pts, const int *counts,
                           int pts_stride, int radius, const int *limit, int batch);

@@ -240,6 +240,10 @@ static void weights(float a, float b, int iw[4])
     iw[3] = 16384 - iw[0] - iw[1] - iw[2];
 }
 
+/* Instrumentation (tools/experiments/probe_lk_divergence.py): when set, orc_lk_pyr stores the Newton steps point p spent on level l
+ * at orc_lk_iter_stats[p * 9 + l] (the device kernel runs four points per wave until the last one has converged). */
+int *orc_lk_iter_stats = 0;
+
 int orc_lk_pyr(const uint8_t *prev, const uint8_t *next, int h, int w, const float *prev_pts, int n, int win,
                int max_level, int max_count, double eps, double min_eig_thr, float *next_pts, uint8_t *status,
                float *err)
@@ -321,6 +325,7 @@ int orc_lk_pyr(const uint8_t *prev, const uint8_t *next, int h, int w, const flo
                     if (l == 0) status[p] = 0;
                     break;
                 }
+                if (orc_lk_iter_stats) orc_lk_iter_stats[p * 9 + l] = j + 1;
                 weights(qx - (float)iqx, qy - (float)iqy, iw);
                 int64_t sb1 = 0, sb2 = 0;
                 for (int y = 0; y < win; ++y)

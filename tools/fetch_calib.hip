@@ -44,11 +44,17 @@ __global__ __launch_bounds__(256) void c_dword4(const unsigned *__restrict__ p, 
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc ^= p[i];
     if (acc == 0x12345678u) out[0] = acc;
 }
-// images of H x W bytes, strips of 116 columns starting at 116 sx - 8 (clamped into the row), chunks of `rows` rows
-__global__ __launch_bounds__(64) void c_rows128(const uint8_t *__restrict__ p, int H, int W, int rows, unsigned *out)
+// images of H x W bytes, strips of 116 columns starting at 116 sx - 8 (clamped into the row), chunks of `rows` rows; the blocks of
+// an image go to ONE XCD (blocks n and n + 8 share an L2), as k_mineig_pair maps them: neighbouring strips share the 128-B lines
+// their 116-column pitch straddles, and only a common L2 fetches such a line once
+__global__ __launch_bounds__(64) void c_rows128(const uint8_t *__restrict__ p, int H, int W, int rows, int nimg, unsigned *out)
 {
-    const int lane = threadIdx.x, sx = blockIdx.x, chunk = blockIdx.y;
-    const uint8_t *img = p + (size_t)blockIdx.z * H * W;
+    const int lane = threadIdx.x;
+    const unsigned per = 17 * 4, n = blockIdx.x, k = n >> 3, rem = k % per;
+    const int b = 8 * (int)(k / per) + (int)(n & 7);
+    if (b >= nimg) return;
+    const int chunk = (int)(rem / 17), sx = (int)(rem % 17);
+    const uint8_t *img = p + (size_t)b * H * W;
     const int G0 = sx * 116 - 8;
     const int lrow = lane >> 5, lk = lane & 31;
     int off = G0 + 4 * lk; off = off < 0 ? 0 : off > W - 4 ? W - 4 : off;
@@ -121,8 +127,8 @@ int main()
     CK(hipDeviceSynchronize());
     printf("c_dword4 requested %zu unique64 %zu unique128 %zu\n", bytes, bytes, bytes);
     {
-        const int H = 1080, W = 1920, rows = 270, nimg = (int)(bytes / ((size_t)H * W));
-        hipLaunchKernelGGL(c_rows128, dim3(17, 4, nimg), dim3(64), 0, 0, buf, H, W, rows, out);
+        const int H = 1080, W = 1920, rows = 270, nimg = (int)(bytes / ((size_t)H * W)) & ~7;
+        hipLaunchKernelGGL(c_rows128, dim3(17 * 4 * nimg), dim3(64), 0, 0, buf, H, W, rows, nimg, out);
         CK(hipDeviceSynchronize());
         const size_t img_bytes = (size_t)nimg * H * W;                // every byte of every image is inside some strip: all lines, once
         printf("c_rows128 requested %zu unique64 %zu unique128 %zu\n", (size_t)nimg * 17 * 4 * (rows + 10) * 128, img_bytes, img_bytes);

@@ -15,7 +15,7 @@ build)
     src=$2; shift 2
     mkdir -p "$OUT"; rm -f "$OUT"/*.so
     make -s -C "$CS"
-    extra=""; [ "$src" = k_corners.hip ] && extra="-fno-slp-vectorize"
+    extra=""; [ "$src" = k_corners.hip ] && extra="-fno-slp-vectorize -mllvm -amdgpu-sched-strategy=max-ilp"    # the Makefile's flags for that file
     for spec in "$@"; do
         name=${spec%%:*}; defs=${spec#*:}
         /opt/rocm/bin/hipcc $FLAGS $extra $defs -c "$CS/$src" -o "$OUT/$name.o"
