@@ -124,6 +124,17 @@ def pmc_traffic(stage, pairs_per_launch):
         return None
 
 
+def checked_traffic(stage, pairs_per_launch, algorithmic_bytes_per_launch):
+    """pmc_traffic, refused (None + a note on stderr) when it lies below 0.8 x the kernel's algorithmic bytes: a cold kernel cannot
+    move less than it must, so such a number is a bookkeeping error (round 2's summary halved every stage)."""
+    t = pmc_traffic(stage, pairs_per_launch)
+    if t is not None and t < 0.8 * algorithmic_bytes_per_launch:
+        print(f"bench.py: PMC traffic of stage {stage} ({t} B per launch) is below 0.8 x its algorithmic bytes ({int(algorithmic_bytes_per_launch)} B): "
+              f"refused, reporting null (regenerate profiles/{PROFILE_TAG}_traffic_pmc.json with tools/profile_round.sh)", file=sys.stderr)
+        return None
+    return t
+
+
 def valu_roof(stage, pairs_per_launch, isolated_ms):
     """The stage's kernel against the VALU issue peak: wave-level instructions per launch (committed SQ_INSTS_VALU count, scaled
     to the pairs of one launch) / the kernel's duration alone on the chip.  Returns (achieved G/s, instructions per launch,
@@ -229,6 +240,10 @@ def main():
                     "trace then holds the timed schedule's launches only)")
     ap.add_argument("--cpu-sample", type=int, default=24, help="pairs timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-ingest", action="store_true", help="skip the ingest-inclusive legs (raw BGR upload / JPEG decode every step)")
+    ap.add_argument("--comms", type=int, default=0, help="RCCL communicators per rank under a launcher: 0 = one per slice (every slice gathers its "
+                    "own records on its own stream), 1 = a single communicator, one gather per step behind the last slice")
+    ap.add_argument("--watchdog", type=float, default=90.0, help="seconds the bootstrap + first gathered step may take under a launcher before "
+                    "the rank reports what it is waiting for and exits 3 (0 = off)")
     args = ap.parse_args()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # RCCL's device-memory IPC needs the dmabuf path on this pool
@@ -255,8 +270,29 @@ def main():
     # The exchange: RCCL through the library (no torch in the process).  Step k's records are exported and all-gathered on the
     # library's own stream right behind step k's solve (receive slot k % 2), so the host only queues work: step k+1 is
     # launched while step k's gather travels.  K steps issue K gathers inside the timed region.
+    # Watchdog for the first multi-rank step: a rank that waits longer than --watchdog seconds for the bootstrap or the first
+    # gathered step says which rank / communicator / slot it is waiting for and exits non-zero (no retry, no re-exec).
+    state = {"phase": "bootstrap (unique-id file + ncclCommInitRank)", "comm": None}
+    armed = None
+    if launched and args.watchdog > 0:
+        import threading
+        armed = threading.Event()
+
+        def bark():
+            if armed.wait(args.watchdog):
+                return
+            c = state["comm"]
+            pend = [c.pending(s) for s in (0, 1)] if c is not None else None
+            print(f"bench.py watchdog: rank {rank} of {world} (device {local}) has been in '{state['phase']}' for {args.watchdog:.0f} s; "
+                  f"communicators agreed: {c.n_comms if c is not None else 'none yet'}; gathers still travelling per slot (bit k = slice k): {pend}; "
+                  f"rendezvous file: {sharding.rendezvous_path(generation=0)}; try --comms 1", file=sys.stderr, flush=True)
+            os._exit(3)
+        threading.Thread(target=bark, daemon=True).start()
+    n_comms = max(1, args.streams) if args.comms <= 0 else max(1, min(args.comms, args.streams))
     with _stdout_to_stderr():                                    # librccl prints a version banner on stdout at communicator init
-        comm = sharding.Comm(pipe.ctx, rank, world, n_comms=max(1, args.streams)) if launched else None
+        comm = sharding.Comm(pipe.ctx, rank, world, n_comms=n_comms) if launched else None
+    state["comm"] = comm
+    state["phase"] = "warm-up: first steps + gathers + barrier"
 
     def sync_all():
         if comm is not None:
@@ -271,6 +307,8 @@ def main():
 
     run_steps(args.warmup, 0)
     sync_all()
+    if armed is not None:
+        armed.set()                                              # the first gathered steps and a barrier completed on every rank
     pipe.ctx.profile_read()
     pipe.ctx.profile_enable(0)                                   # the timed region runs without stage brackets (two event records per stage and slice)
     sync_all()
@@ -335,7 +373,7 @@ def main():
                           "stream, after the timed region); a kernel's time per step is <= ms_per_step by construction",
                 "hbm": {"achieved": round(hbm_ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_ach / HBM_PEAK_GBS, 4),
                         "algorithmic_bytes_per_launch": int(ab[dom] * iso_pairs)},
-                "traffic": pmc_traffic(dom, iso_pairs)}
+                "traffic": checked_traffic(dom, iso_pairs, ab[dom] * iso_pairs)}
         if vr is not None:
             roof.update({"bound": "valu", "achieved": round(vr[0], 1), "peak": VALU_PEAK_GINSTR, "unit": "G wave-instr/s",
                          "frac": round(vr[0] / VALU_PEAK_GINSTR, 4), "valu_instr_per_launch": vr[1],
@@ -359,14 +397,14 @@ def main():
             "data": "synthetic",
             "config": {"workload": "1920x1080 frame pairs, 500 Shi-Tomasi corners, 3-level LK pyramid (BASELINE configs[1])",
                        "pairs_per_gpu_per_step": B, "streams_per_gpu": args.streams, "corners_mean": round(n_pts, 1), "candidates_mean": round(n_cand, 1), "win": cfg.win, "max_level": cfg.max_level,
-                       "sharding": f"{world} x independent pair batches, RCCL all_gather of [B,8] f32 records on the library's stream" + ("" if launched else " (single process: nothing to exchange)")},
+                       "sharding": f"{world} x independent pair batches, RCCL all_gather of [B,8] f32 records on the library's stream" + (f", {comm.n_comms} communicator(s) per rank" if launched else " (single process: nothing to exchange)")},
             "roofline": roof,
             # "Pyramid+LK group (north-star kernel)" = G_pyr + G_lk (Scharr fused into LK), serial-pass durations
             "north_star_group": {"kernels": f"{KERNEL_OF['pyr']} + {KERNEL_OF['lk']}", "bound": "hbm",
                                  "achieved": round(grp_bytes / (t_grp * 1e-3) / 1e9, 1) if t_grp > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": round(grp_bytes / (t_grp * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if t_grp > 0 else None,
                                  "algorithmic_bytes_per_launch": int(grp_bytes), "avg_ms": {"pyr": round(iso_ms["pyr"], 4), "lk": round(iso_ms["lk"], 4)},
-                                 "traffic": (pmc_traffic("pyr", iso_pairs) or 0) + (pmc_traffic("lk", iso_pairs) or 0) or None,
+                                 "traffic": (checked_traffic("pyr", iso_pairs, ab["pyr"] * iso_pairs) or 0) + (checked_traffic("lk", iso_pairs, ab["lk"] * iso_pairs) or 0) or None,
                                  "note": "LK is bound by VALU issue, not HBM (stages_isolated.lk, roofline of stage lk in DESIGN.md §4)"},
             "pipeline_algorithmic_GBps": round(sum(ab.values()) * world * B * args.steps / dt / 1e9, 1),
             # event brackets of every stage from K more steps of the SAME schedule run right after the timed region (the timed steps
@@ -385,7 +423,7 @@ def main():
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(ab["pyr"] * B * args.steps / (iso["pyr"][0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if iso["pyr"][0] > 0 else None,
                                   "avg_ms": round(iso["pyr"][0] / max(1, iso["pyr"][1]), 4),
-                                  "traffic": pmc_traffic("pyr", B * args.steps / max(1, iso["pyr"][1]))},
+                                  "traffic": checked_traffic("pyr", B * args.steps / max(1, iso["pyr"][1]), ab["pyr"] * B * args.steps / max(1, iso["pyr"][1]))},
             "velocity_sample": [round(float(x), 6) for x in rec[0, :3]],
             "velocity_truth": list(truth["v"]),
         }

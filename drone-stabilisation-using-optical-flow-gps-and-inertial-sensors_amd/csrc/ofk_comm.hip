@@ -1,22 +1,33 @@
 // ofk_comm.hip — the one exchange step of the multi-GPU path: RCCL over xGMI, bound at run time (dlopen of librccl.so, so a
-// single-GPU user needs no RCCL) and driven from the library's own streams.  One process per GPU; ranks own independent frame
+// single-GPU user needs no RCCL, and the build needs no RCCL headers) and driven from the library's own streams.  One process per GPU; ranks own independent frame
 // pairs (no data-path collective); after every step the [B, 8] f32 velocity records of all ranks are all-gathered, stream-ordered
 // behind the step's solve on the last slice's stream — no host wait, no second HIP runtime in the process.
 #include "ofk_internal.h"
 #include <dlfcn.h>
-#include <rccl/rccl.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
+// The few RCCL declarations this file needs, stated here so that the build does not depend on the RCCL headers (the library is
+// bound with dlopen at run time; a single-GPU user needs neither).  Values and layouts are the stable NCCL 2 ABI that
+// rccl/rccl.h declares: ncclUniqueId = 128 opaque bytes passed BY VALUE to ncclCommInitRank, ncclSuccess = 0,
+// ncclFloat32 = 7, ncclFloat64 = 8, ncclSum / ncclMax / ncclMin = 0 / 2 / 3.
+#define NCCL_UNIQUE_ID_BYTES 128
+typedef struct { char internal[NCCL_UNIQUE_ID_BYTES]; } ncclUniqueId;
+typedef struct ncclComm *ncclComm_t;
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+typedef int ncclRedOp_t;
+enum { ncclSuccess = 0, ncclFloat32 = 7, ncclFloat64 = 8, ncclSum = 0, ncclMax = 2, ncclMin = 3 };
+
 struct ofk_comm {
     void *lib;
-    decltype(&ncclGetUniqueId) get_unique_id;
-    decltype(&ncclCommInitRank) comm_init_rank;
-    decltype(&ncclCommDestroy) comm_destroy;
-    decltype(&ncclAllGather) all_gather;
-    decltype(&ncclAllReduce) all_reduce;
-    decltype(&ncclGetErrorString) error_string;
+    ncclResult_t (*get_unique_id)(ncclUniqueId *);
+    ncclResult_t (*comm_init_rank)(ncclComm_t *, int, ncclUniqueId, int);
+    ncclResult_t (*comm_destroy)(ncclComm_t);
+    ncclResult_t (*all_gather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
+    ncclResult_t (*all_reduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+    const char *(*error_string)(ncclResult_t);
     ncclComm_t comm[OFK_MAX_STREAMS]; int ncomm;   // one communicator per free-running slice: a slice gathers its own records on its
                                                     // own stream, so the exchange never couples the slices (comm[0] also serves all-reduces)
     int rank, world;
@@ -81,9 +92,15 @@ extern "C" int ofk_comm_init(ofk_ctx *c, const uint8_t *ids, int n_ids, int rank
         memcpy(id.internal, ids + (size_t)k * NCCL_UNIQUE_ID_BYTES, NCCL_UNIQUE_ID_BYTES);
         ncclResult_t r = m->comm_init_rank(&m->comm[k], world, id, rank);
         if (r != ncclSuccess) {
-            ofk_fail(c, OFK_E_HIP, "ncclCommInitRank(communicator %d, rank %d of %d): %s", k, rank, world, m->error_string(r));
-            ofk_comm_destroy(c);
-            return OFK_E_HIP;
+            if (k == 0) {
+                ofk_fail(c, OFK_E_HIP, "ncclCommInitRank(communicator 0, rank %d of %d): %s", rank, world, m->error_string(r));
+                ofk_comm_destroy(c);
+                return OFK_E_HIP;
+            }
+            // a per-slice communicator is an optimisation: without it the step's records travel in ONE gather behind the last slice
+            fprintf(stderr, "libofk: rank %d: ncclCommInitRank of communicator %d failed (%s); gathering on %d communicator(s)\n", rank, k, m->error_string(r), k);
+            m->comm[k] = nullptr;
+            break;
         }
         m->ncomm = k + 1;
     }
@@ -98,6 +115,15 @@ extern "C" int ofk_comm_init(ofk_ctx *c, const uint8_t *ids, int n_ids, int rank
     ok = ok && hipMalloc((void **)&m->red, 64 * sizeof(double)) == hipSuccess && hipHostMalloc(&m->hred, 64 * sizeof(double)) == hipSuccess &&
          hipHostMalloc((void **)&m->hrecv, m->hrecv_bytes) == hipSuccess;
     if (!ok) { ofk_comm_destroy(c); return ofk_fail(c, OFK_E_HIP, "ofk_comm_init: device buffers"); }
+    // every rank must cut its gathers the same way: agree on the smallest communicator count any rank ended up with
+    if (n_ids > 1) {
+        double have = (double)m->ncomm;
+        rc = ofk_comm_allreduce_f64(c, &have, 1, 2);
+        if (rc != OFK_OK) { ofk_comm_destroy(c); return rc; }
+        const int agreed = (int)have < 1 ? 1 : (int)have;
+        for (int k = agreed; k < m->ncomm; ++k) { m->comm_destroy(m->comm[k]); m->comm[k] = nullptr; }
+        if (agreed < m->ncomm) m->ncomm = agreed;
+    }
     return OFK_OK;
 }
 
@@ -177,13 +203,40 @@ extern "C" int ofk_comm_fetch_records(ofk_ctx *c, int slot, int batch, float *ho
     const size_t bytes = (size_t)m->world * batch * 8 * sizeof(float);
     if (S == 1) { OFK_HIP(c, hipMemcpy(host_out, m->recv[slot], bytes, hipMemcpyDeviceToHost)); return OFK_OK; }
     OFK_HIP(c, hipMemcpy(m->hrecv, m->recv[slot], bytes, hipMemcpyDeviceToHost));
-    for (int k = 0; k < S; ++k) {
-        const int b0 = (int)((long long)batch * k / S), nb = (int)((long long)batch * (k + 1) / S) - b0;
-        for (int r = 0; r < m->world; ++r)
-            memcpy(host_out + ((size_t)r * batch + b0) * 8, m->hrecv + ((size_t)m->world * b0 + (size_t)r * nb) * 8, (size_t)nb * 8 * sizeof(float));
+    return ofk_comm_reorder_records(m->hrecv, m->world, batch, S, host_out);
+}
+
+// Host-only (no device, no communicator): the receive buffer of a step gathered per slice holds, slice after slice,
+// [world][pairs of the slice][8] f32 - slice k owns the pairs [batch k / S, batch (k+1) / S) of every rank; this restores the
+// rank-major [world][batch][8] order ofk_comm_fetch_records returns.  Exported so that the indexing can be checked for any
+// world / slice count / uneven cut on a machine without GPUs (tests/test_dist_gloo.py).
+extern "C" int ofk_comm_reorder_records(const float *recv, int world, int batch, int slices, float *out)
+{
+    if (!recv || !out || world < 1 || batch < 1 || slices < 1 || slices > OFK_MAX_STREAMS) return ofk_fail(nullptr, OFK_E_INVALID, "ofk_comm_reorder_records: bad argument");
+    for (int k = 0; k < slices; ++k) {
+        const int b0 = (int)((long long)batch * k / slices), nb = (int)((long long)batch * (k + 1) / slices) - b0;
+        for (int r = 0; r < world; ++r)
+            memcpy(out + ((size_t)r * batch + b0) * 8, recv + ((size_t)world * b0 + (size_t)r * nb) * 8, (size_t)nb * 8 * sizeof(float));
     }
     return OFK_OK;
 }
+
+// Non-blocking: bit k set = the gather of slice k (bit 0: the single gather) of `slot` has not completed yet; 0 = all done or
+// nothing queued; < 0 = error.  For watchdogs: names the communicator a hung step is waiting for.
+extern "C" int ofk_comm_pending(ofk_ctx *c, int slot)
+{
+    if (!c || !c->comm || slot < 0 || slot > 1) return OFK_E_INVALID;
+    ofk_comm *m = c->comm;
+    int mask = 0;
+    for (int k = 0; k < m->slot_slices[slot]; ++k) {
+        const hipError_t e = hipEventQuery(m->done[slot][k]);
+        if (e == hipErrorNotReady) mask |= 1 << k;
+        else if (e != hipSuccess) { (void)hipGetLastError(); return OFK_E_HIP; }
+    }
+    return mask;
+}
+
+extern "C" int ofk_comm_count(const ofk_ctx *c) { return c && c->comm ? c->comm->ncomm : 0; }
 
 // In-place all-reduce of n <= 64 doubles over the ranks (op 0 = sum, 1 = max, 2 = min) on the context's stream, synchronous: the
 // benchmark's barrier / max-over-ranks and the Monte-Carlo sweep's (sum v, sum v^2, count) reduction.

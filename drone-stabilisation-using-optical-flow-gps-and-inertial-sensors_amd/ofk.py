@@ -33,7 +33,7 @@ SYMBOLS = (
     "ofk_imu_reset", "ofk_imu_push", "ofk_imu_state", "ofk_filter_configure", "ofk_filter_state", "ofk_stream_step_fused",
     "ofk_stream_step_fused_jpeg", "ofk_stream_last_points", "ofk_pairs_filter_step",
     "ofk_comm_unique_id", "ofk_comm_init", "ofk_comm_destroy", "ofk_comm_rank", "ofk_comm_world", "ofk_comm_gather_records",
-    "ofk_comm_fetch_records", "ofk_comm_allreduce_f64",
+    "ofk_comm_fetch_records", "ofk_comm_allreduce_f64", "ofk_comm_count", "ofk_comm_pending", "ofk_comm_reorder_records",
 )
 
 
@@ -145,6 +145,7 @@ def load_library():
         L.ofk_comm_rank.argtypes = [vp]; L.ofk_comm_world.argtypes = [vp]
         L.ofk_comm_gather_records.argtypes = [vp, i, i]; L.ofk_comm_fetch_records.argtypes = [vp, i, i, vp]
         L.ofk_comm_allreduce_f64.argtypes = [vp, vp, i, i]
+        L.ofk_comm_count.argtypes = [vp]; L.ofk_comm_pending.argtypes = [vp, i]; L.ofk_comm_reorder_records.argtypes = [vp, i, i, i, vp]
         for s in SYMBOLS:
             if s != "ofk_last_error":
                 getattr(L, s).restype = i
@@ -734,6 +735,14 @@ class Context:
             self._ck(self._L.ofk_comm_fetch_records(self._h, int(slot), int(batch), _p(out)))
         return out
 
+    def comm_count(self):
+        """Communicators the ranks agreed on (1 = one gather per step behind the last slice)."""
+        return int(self._L.ofk_comm_count(self._h))
+
+    def comm_pending(self, slot=0):
+        """Non-blocking: bitmask of the slices whose gather of `slot` has not completed (watchdogs)."""
+        return int(self._L.ofk_comm_pending(self._h, int(slot)))
+
     def comm_allreduce(self, values, op="sum"):
         v = np.ascontiguousarray(np.atleast_1d(values), np.float64).copy()
         with self._lock:
@@ -784,6 +793,17 @@ def comm_unique_id(n_ids=1):
     if rc != OK:
         raise OfkError(rc, load_library().ofk_last_error(None).decode())
     return uid.tobytes()
+
+
+def comm_reorder_records(recv, world, batch, slices):
+    """Host-only: the per-slice receive order of ofk_comm_gather_records -> rank-major [world, batch, 8] (ofk_comm_fetch_records'
+    reassembly, callable without a GPU)."""
+    recv = np.ascontiguousarray(recv, np.float32)
+    out = np.empty((int(world), int(batch), 8), np.float32)
+    L = load_library()
+    if recv.size != out.size or L.ofk_comm_reorder_records(_p(recv), int(world), int(batch), int(slices), _p(out)) != OK:
+        raise OfkError(E_INVALID, "comm_reorder_records: bad argument")
+    return out
 
 
 def set_tuning(knob, value):

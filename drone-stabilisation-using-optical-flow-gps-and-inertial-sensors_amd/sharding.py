@@ -10,9 +10,9 @@ process (BASELINE.json north_star): the collectives are queued on
 stream-ordered behind the step that produced its records and nothing waits on the host.  One process per GPU, launched by any
 launcher that exports RANK / WORLD_SIZE / LOCAL_RANK (torch.distributed.run does; it is only the process launcher here).
 
-Bootstrap: rank 0 draws the 128-byte RCCL unique id and publishes it through a file the launcher's ranks share (all ranks of a
-run sit on one node: the bench contract); the file name carries the launcher's pid and MASTER_PORT so concurrent runs do not
-meet.  `exchange_unique_id` is transport-agnostic (it moves 128 bytes) and is tested on the CPU with two processes.
+Bootstrap: rank 0 draws the 128-byte RCCL unique ids and publishes them through a file the launcher's ranks share (all ranks of a
+run sit on one node: the bench contract); the file name carries MASTER_ADDR, MASTER_PORT, the elastic run id and the number of the
+exchange inside the launch, so concurrent runs and consecutive exchanges do not meet, and readers ignore files older than the launch.  `exchange_unique_id` is transport-agnostic (it moves 128 bytes) and is tested on the CPU with two processes.
 """
 import os
 import tempfile
@@ -36,22 +36,65 @@ def env_ranks(environ=None):
     return int(e["RANK"]), int(e["WORLD_SIZE"]), int(e.get("LOCAL_RANK", e["RANK"]))
 
 
-def rendezvous_path(environ=None, directory=None):
-    """File through which rank 0 hands the unique id to the other ranks of THIS launch: keyed by the launcher (parent) pid, the
-    rendezvous port and the elastic run id, under /dev/shm when present (memory-backed, node-local)."""
+_exchange_generation = 0          # exchanges this process has taken part in: every rank of a launch makes them in the same order
+
+
+def _proc_start_time(pid):
+    """Start time of process `pid` in seconds since the epoch (Linux /proc), None if it cannot be read."""
+    try:
+        with open(f"/proc/{pid}/stat") as f:
+            ticks = int(f.read().rsplit(")", 1)[1].split()[19])            # field 22: starttime in clock ticks since boot
+        with open("/proc/stat") as f:
+            btime = next(int(line.split()[1]) for line in f if line.startswith("btime"))
+        return btime + ticks / os.sysconf("SC_CLK_TCK")
+    except Exception:
+        return None
+
+
+def launch_epoch():
+    """A time no file of THIS launch can be older than: the start of the launcher (the ranks' common parent under
+    torch.distributed.run / mpirun) when it can be read, else of this process.  A unique-id file left behind by a crashed earlier
+    run whose MASTER_PORT recurs is older than that and is ignored by the readers."""
+    t_self = _proc_start_time(os.getpid())
+    t_parent = _proc_start_time(os.getppid()) if os.getppid() > 1 else None
+    ts = [t for t in (t_self, t_parent) if t is not None]
+    return (min(ts) - 1.0) if ts else 0.0
+
+
+def rendezvous_path(environ=None, directory=None, generation=None):
+    """File through which rank 0 hands the unique ids to the other ranks of THIS launch, under /dev/shm when present
+    (memory-backed, node-local).  Keyed by what the launcher gives every rank alike — MASTER_ADDR : MASTER_PORT and the elastic
+    run id — so the ranks need not share a parent process; the launcher's pid is only the last resort when no rendezvous address
+    is exported.  `generation` numbers the exchanges of a launch (a process that builds a second Comm must not meet the first
+    one's file)."""
     e = os.environ if environ is None else environ
     d = directory or ("/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir())
-    key = f"{e.get('MASTER_PORT', '0')}_{e.get('TORCHELASTIC_RUN_ID', 'none')}_{os.getppid()}"
-    return os.path.join(d, f"ofk_rccl_uid_{key}")
+    if "MASTER_PORT" in e:
+        addr = "".join(ch if ch.isalnum() else "-" for ch in e.get("MASTER_ADDR", "local"))
+        key = f"{addr}_{e['MASTER_PORT']}_{e.get('TORCHELASTIC_RUN_ID', 'none')}"
+    else:
+        key = f"ppid{os.getppid()}"
+    g = _exchange_generation if generation is None else generation
+    return os.path.join(d, f"ofk_rccl_uid_{key}_g{g}")
 
 
-def exchange_unique_id(make_id, rank, world, path=None, timeout=120.0, nbytes=128):
-    """Rank 0 calls make_id() -> bytes and publishes them (write + atomic rename); the other ranks poll the file.  Returns the
-    id on every rank.  Rank 0 removes the file once every rank has acknowledged (one small file per rank)."""
-    path = path or rendezvous_path()
+def exchange_unique_id(make_id, rank, world, path=None, timeout=120.0, nbytes=128, not_before=None):
+    """Rank 0 calls make_id() -> bytes and publishes them (stale file removed, write, atomic rename); the other ranks poll the
+    file and ignore one that is older than the launch (`not_before`, default launch_epoch()).  Returns the id on every rank.
+    Rank 0 removes the file once every rank has acknowledged (one small file per rank).  Every call of a process uses the next
+    generation's file name unless `path` is given."""
+    global _exchange_generation
+    if path is None:
+        path = rendezvous_path()
+        _exchange_generation += 1
     if world == 1:
         return bytes(make_id())
     if rank == 0:
+        for stale in [path] + [f"{path}.ack{r}" for r in range(1, world)]:        # leftovers of a crashed run with the same key
+            try:
+                os.remove(stale)
+            except OSError:
+                pass
         uid = bytes(make_id())
         if len(uid) != nbytes:
             raise ValueError(f"unique id has {len(uid)} bytes, expected {nbytes}")
@@ -75,21 +118,30 @@ def exchange_unique_id(make_id, rank, world, path=None, timeout=120.0, nbytes=12
         except OSError:
             pass
         if pending:
-            raise TimeoutError(f"ranks {sorted(pending)} never picked up the unique id at {path}")
+            raise TimeoutError(f"rank 0: ranks {sorted(pending)} of {world} never picked up the unique id at {path} within {timeout} s "
+                               f"(do all ranks see MASTER_ADDR/MASTER_PORT = {os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')} and this directory?)")
         return uid
+    if not_before is None:
+        not_before = launch_epoch()
     deadline = time.monotonic() + timeout
+    stale_seen = False
     while time.monotonic() < deadline:
         try:
-            with open(path, "rb") as f:
-                uid = f.read()
-            if len(uid) == nbytes:
-                with open(f"{path}.ack{rank}", "wb") as f:
-                    f.write(b"1")
-                return uid
+            if os.stat(path).st_mtime < not_before:
+                stale_seen = True                               # a crashed earlier run's file: rank 0 of this launch replaces it
+            else:
+                with open(path, "rb") as f:
+                    uid = f.read()
+                if len(uid) == nbytes:
+                    with open(f"{path}.ack{rank}", "wb") as f:
+                        f.write(b"1")
+                    return uid
         except OSError:
             pass
         time.sleep(0.005)
-    raise TimeoutError(f"rank {rank}: no unique id at {path} after {timeout} s")
+    raise TimeoutError(f"rank {rank} of {world}: no unique id at {path} after {timeout} s" +
+                       (" (only a stale file from before this launch was there)" if stale_seen else "") +
+                       f"; rank 0 publishes it there - MASTER_ADDR/MASTER_PORT here: {os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}")
 
 
 class Comm:
@@ -102,15 +154,21 @@ class Comm:
         comm.barrier(); t = comm.max(seconds)
     """
 
-    def __init__(self, ctx, rank, world, path=None, n_comms=1):
+    def __init__(self, ctx, rank, world, path=None, n_comms=1, make_id=None):
         try:
             from . import ofk
         except ImportError:
             import ofk
         self.ctx, self.rank, self.world = ctx, int(rank), int(world)
         # one communicator per free-running slice (ofk_set_streams): each slice then gathers its own records on its own stream
-        uid = exchange_unique_id(lambda: ofk.comm_unique_id(n_comms), self.rank, self.world, path=path, nbytes=128 * int(n_comms))
+        # (make_id: a stand-in for ncclGetUniqueId where no RCCL exists - the CPU tests drive this class against a fake context)
+        uid = exchange_unique_id(make_id or (lambda: ofk.comm_unique_id(n_comms)), self.rank, self.world, path=path, nbytes=128 * int(n_comms))
         ctx.comm_init(uid, self.rank, self.world)
+        self.n_comms = ctx.comm_count()                          # what the ranks agreed on (a failed per-slice communicator is dropped everywhere)
+
+    def pending(self, slot=0):
+        """Bitmask of the slices whose gather of `slot` is still travelling (non-blocking; for watchdogs)."""
+        return self.ctx.comm_pending(slot)
 
     def gather_async(self, batch, slot=0):
         self.ctx.comm_gather_records(batch, slot)

@@ -357,6 +357,14 @@ int ofk_comm_world(const ofk_ctx *ctx);
 int ofk_comm_gather_records(ofk_ctx *ctx, int batch, int slot);
 int ofk_comm_fetch_records(ofk_ctx *ctx, int slot, int batch, float *host_out);
 int ofk_comm_allreduce_f64(ofk_ctx *ctx, double *inout, int n, int op);
+/* Communicators the ranks agreed on at ofk_comm_init (a per-slice communicator whose ncclCommInitRank fails on any rank is
+ * dropped everywhere, down to one: the step's records then travel in one gather behind the last slice). */
+int ofk_comm_count(const ofk_ctx *ctx);
+/* Non-blocking watchdog query: bit k set = the gather of slice k of `slot` has not completed (0 = done / nothing queued). */
+int ofk_comm_pending(ofk_ctx *ctx, int slot);
+/* Host-only helper (needs neither a device nor a communicator): receive-buffer order of a step gathered per slice
+ * ([slice][world][pairs of the slice][8] f32) -> rank-major [world][batch][8]; what ofk_comm_fetch_records applies. */
+int ofk_comm_reorder_records(const float *recv, int world, int batch, int slices, float *out);
 
 /* Number of concurrent slices ofk_pairs_run cuts the batch into (1..8, default 1): each slice runs the whole stage chain on
  * its own HIP stream so that latency-bound stages overlap with streaming ones; results do not depend on it.  With more than

@@ -6,7 +6,13 @@ checked here instead:
     rank-major all-gather layout of the [B, 8] records and MAX-over-ranks timing, i.e. the semantics ofk_comm_gather_records /
     ofk_comm_allreduce_f64 implement on the GPUs;
   * test_world2_bootstrap_with_fake_collective — sharding.exchange_unique_id + env_ranks + combine_moments with two plain
-    processes and a file-based fake all-reduce: the torch-free bootstrap path bench.py and simulation.sweep_flow_errors take.
+    processes and a file-based fake all-reduce: the torch-free bootstrap path bench.py and simulation.sweep_flow_errors take;
+    a stale unique-id file from "a crashed earlier run" lies at the rendezvous path and must be ignored; two more exchanges of
+    the same processes on the default path must not meet each other's files (generation counter).
+  * test_world2_comm_sequence_with_fake_context — sharding.Comm's full call sequence (two communicators, two slots, gather per
+    slice, fetch) against a fake context whose "all-gather" goes through files and whose reassembly is libofk.so's own host
+    function ofk_comm_reorder_records: the [world][B][8] rank-major result for world = 2, S = 2, uneven slices.
+  * test_reorder_records_matches_numpy_for_uneven_cuts — that host function against numpy for worlds of 1..8, 1..4 slices.
 """
 import os
 import socket
@@ -62,6 +68,13 @@ BOOT = textwrap.dedent("""
         return bytes((7 * i + 3) %% 256 for i in range(128))
     uid = sharding.exchange_unique_id(make_id, rank, world, path=path, timeout=60)
     assert uid == bytes((7 * i + 3) %% 256 for i in range(128)) and len(made) == (1 if rank == 0 else 0)
+    # two more exchanges on the default path (MASTER_ADDR / MASTER_PORT key): consecutive generations, distinct files, distinct ids
+    g0 = sharding.rendezvous_path()
+    u1 = sharding.exchange_unique_id(lambda: bytes([1]) * 128, rank, world, timeout=60)
+    g1 = sharding.rendezvous_path()
+    u2 = sharding.exchange_unique_id(lambda: bytes([2]) * 128, rank, world, timeout=60)
+    assert g0 != g1 and g0.endswith("_g0") and g1.endswith("_g1") and os.environ["MASTER_PORT"] in g0
+    assert u1 == bytes([1]) * 128 and u2 == bytes([2]) * 128
 
     # a fake all-reduce(sum) over files: each rank publishes its vector, waits for the others', adds them up in rank order
     def allreduce(v, tag=[0]):
@@ -109,16 +122,49 @@ def test_world2_gloo_gather_and_shard(tmp_path):
 
 
 def test_world2_bootstrap_with_fake_collective(tmp_path):
-    _run_world(BOOT, tmp_path, {"OFK_TEST_RDV": str(tmp_path / "rdv")})
-    assert not (tmp_path / "rdv").exists()                      # rank 0 cleaned the rendezvous file up
+    import time
+    stale = tmp_path / "rdv"
+    stale.write_bytes(bytes(128))                               # a crashed earlier run left a well-formed id behind ...
+    old = time.time() - 3600
+    os.utime(stale, (old, old))                                 # ... an hour ago
+    (tmp_path / "rdv.ack1").write_bytes(b"1")
+    _run_world(BOOT, tmp_path, {"OFK_TEST_RDV": str(stale)})
+    assert not stale.exists() and not (tmp_path / "rdv.ack1").exists()      # rank 0 cleaned the rendezvous files up
+
+
+COMM = open(os.path.join(ROOT, "tests", "comm_sequence_worker.py")).read()
+
+
+def test_world2_comm_sequence_with_fake_context(tmp_path):
+    _run_world(COMM, tmp_path, {"OFK_TEST_RDV": str(tmp_path / "rdv"), "OFK_TEST_ROOT": ROOT})
+
+
+def test_reorder_records_matches_numpy_for_uneven_cuts():
+    import numpy as np
+    from __graft_entry__ import load_package
+    load_package()
+    from of_amd import ofk
+    rng = np.random.default_rng(3)
+    for world, batch, slices in ((3, 7, 2), (3, 10, 3), (2, 256, 2), (8, 5, 4), (1, 9, 2), (4, 6, 1)):
+        per_rank = rng.standard_normal((world, batch, 8)).astype(np.float32)
+        recv = []
+        for s in range(slices):
+            b0, b1 = batch * s // slices, batch * (s + 1) // slices
+            for r in range(world):
+                recv.append(per_rank[r, b0:b1].ravel())
+        out = ofk.comm_reorder_records(np.concatenate(recv), world, batch, slices)
+        assert np.array_equal(out, per_rank), (world, batch, slices)
 
 
 def test_rendezvous_path_is_per_launch():
     from __graft_entry__ import load_package
     load_package()
     from of_amd.sharding import rendezvous_path, env_ranks
-    a = rendezvous_path({"MASTER_PORT": "29500"}, "/tmp"); b = rendezvous_path({"MASTER_PORT": "29501"}, "/tmp")
-    assert a != b and str(os.getppid()) in a
+    a = rendezvous_path({"MASTER_PORT": "29500", "MASTER_ADDR": "127.0.0.1"}, "/tmp"); b = rendezvous_path({"MASTER_PORT": "29501"}, "/tmp")
+    assert a != b and "127-0-0-1_29500" in a and str(os.getppid()) not in os.path.basename(a)      # ranks need not share a parent
+    assert f"ppid{os.getppid()}" in rendezvous_path({}, "/tmp")                                       # last resort: no rendezvous address exported
+    assert rendezvous_path({"MASTER_PORT": "1"}, "/tmp", generation=0) != rendezvous_path({"MASTER_PORT": "1"}, "/tmp", generation=1)
+    assert rendezvous_path({"MASTER_PORT": "1", "TORCHELASTIC_RUN_ID": "a"}, "/tmp") != rendezvous_path({"MASTER_PORT": "1", "TORCHELASTIC_RUN_ID": "b"}, "/tmp")
     assert env_ranks({}) == (0, 1, 0) and env_ranks({"RANK": "3", "WORLD_SIZE": "8", "LOCAL_RANK": "3"}) == (3, 8, 3)
 
 

@@ -1,0 +1,52 @@
+"""CPU-only: the committed measurement summaries are self-consistent (profiles/r02_traffic_pmc.json was half the
+truth for every stage because a substring match doubled its step count, and bench.py passed it on).
+
+  * the calibrated case: k_gray_bgr8's counter bytes == 2 * 4 * P * batch within 1 %;
+  * no stage moves less than 0.8 x its algorithmic bytes (a cold kernel cannot);
+  * the FETCH_SIZE factor in use is the calibrated one (tools/fetch_calib.hip: 2.0 for every access pattern of the pipeline);
+  * bench.py refuses a traffic number that violates the second rule."""
+import json
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TAG = "r03"
+
+
+def load(name):
+    p = os.path.join(ROOT, "profiles", f"{TAG}_{name}.json")
+    if not os.path.exists(p):
+        pytest.skip(f"{p} not committed yet")
+    return json.load(open(p))
+
+
+def test_traffic_summary_is_self_consistent():
+    t = load("traffic_pmc")
+    B, P = t["batch"], 1920 * 1080
+    gray = t["stages"]["gray"]["hbm_bytes_per_step"]
+    assert abs(gray / (2 * 4 * P * B) - 1) < 0.01
+    assert t["kernels"]["k_gray_bgr8"]["launches_per_step"] == 2 and t["kernels"]["k_mineig_pair"]["launches_per_step"] == 1
+    # compulsory bytes per stage and pair (SURVEY.md §8(d) with the fused kernels' real inputs/outputs)
+    floor = {"gray": 2 * 4 * P, "pyr": 2 * (P + P // 4 + P // 16 + P // 64), "eig": P, "lk": 500 * 4 * (17 * 17 + 22 * 22) // 2}
+    for s, per_pair in floor.items():
+        assert t["stages"][s]["hbm_bytes_per_step"] >= 0.8 * per_pair * B, s
+
+
+def test_fetch_factor_is_calibrated():
+    c = load("fetch_calibration")
+    for k, p in c["patterns"].items():
+        assert abs(p["factor128"] - 2.0) < 0.1, (k, p["factor128"])          # the L2 asks for whole 128-B lines, tallied at 64 B
+    t = load("traffic_pmc")
+    for k, v in t["kernels"].items():
+        assert v["fetch_factor"] == c["fetch_factor_of_kernel"].get(k, 2.0)
+
+
+def test_bench_refuses_impossible_traffic(monkeypatch, capsys):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.setattr(bench, "pmc_traffic", lambda stage, pairs: 300)
+    assert bench.checked_traffic("eig", 256, 625) is None and "refused" in capsys.readouterr().err
+    assert bench.checked_traffic("eig", 256, 300) == 300
