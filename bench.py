@@ -240,8 +240,9 @@ def main():
                     "trace then holds the timed schedule's launches only)")
     ap.add_argument("--cpu-sample", type=int, default=24, help="pairs timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-ingest", action="store_true", help="skip the ingest-inclusive legs (raw BGR upload / JPEG decode every step)")
-    ap.add_argument("--comms", type=int, default=0, help="RCCL communicators per rank under a launcher: 0 = one per slice (every slice gathers its "
-                    "own records on its own stream), 1 = a single communicator, one gather per step behind the last slice")
+    ap.add_argument("--comms", type=int, default=1, help="RCCL communicators per rank under a launcher: 1 (default) = one gather per step behind the "
+                    "last slice - the plain usage every RCCL build supports; S = --streams: one communicator per slice, every slice gathers its own "
+                    "records on its own stream (+0.8 %% at N = 1; two collectives of one rank then run concurrently)")
     ap.add_argument("--watchdog", type=float, default=90.0, help="seconds the bootstrap + first gathered step may take under a launcher before "
                     "the rank reports what it is waiting for and exits 3 (0 = off)")
     args = ap.parse_args()
@@ -288,7 +289,7 @@ def main():
                   f"rendezvous file: {sharding.rendezvous_path(generation=0)}; try --comms 1", file=sys.stderr, flush=True)
             os._exit(3)
         threading.Thread(target=bark, daemon=True).start()
-    n_comms = max(1, args.streams) if args.comms <= 0 else max(1, min(args.comms, args.streams))
+    n_comms = max(1, min(args.comms, args.streams))
     with _stdout_to_stderr():                                    # librccl prints a version banner on stdout at communicator init
         comm = sharding.Comm(pipe.ctx, rank, world, n_comms=n_comms) if launched else None
     state["comm"] = comm

@@ -1247,6 +1247,7 @@ static int stream_step_impl(ofk_ctx *c, const uint8_t *next_bgr, const double *s
         if (fu->filter && c->kf_ns < 1) return ofk_fail(c, OFK_E_INVALID, "ofk_stream_step_fused: filter requested but ofk_filter_configure was not called");
         if (fu->flow < 0 || fu->flow > 1 || fu->keep < 0 || fu->keep > 1 || fu->control < 0 || fu->control > 1 || fu->min_solve < 0)
             return ofk_fail(c, OFK_E_INVALID, "ofk_stream_step_fused: bad ofk_fusion field");
+        if (fu->hold_on_skip && B != 1) return ofk_fail(c, OFK_E_INVALID, "ofk_fusion.hold_on_skip needs a context with one stream (%d here): a batch shares one frame swap", B);
         TRY(filters_alloc(c));
     } else if (p->solve_variant != OFK_SOLVE_NODE && p->solve_variant != OFK_SOLVE_SIM) return ofk_fail(c, OFK_E_INVALID, "solve_variant must be NODE or SIM");
     const ofk_levels lv = ofk_make_levels(h, w, p->win, p->max_level);
@@ -1272,7 +1273,16 @@ static int stream_step_impl(ofk_ctx *c, const uint8_t *next_bgr, const double *s
                                p->use_feasibility, p->feas_T, nullptr, c->records, B);
     // re-detection for the streams that had few features (node:157-166): mask = discs around the OLD positions, image = OLD frame.
     // The host knows the track counts from the previous call, so the whole branch is skipped when no stream needs it.
-    const bool any = few && !(fu && fu->redetect_replace);
+    // of_module.py:138 `continue`: a step of the ONE stream that did not solve leaves old_gray / old_pos as they were.  The host has to
+    // know before it queues the track update, hence one wait (hold_on_skip is opt-in).
+    bool hold = false;
+    if (fu && fu->hold_on_skip) {
+        double solved = 1.0;
+        OFK_HIP(c, hipMemcpyAsync(&solved, c->records + 15, 8, hipMemcpyDeviceToHost, c->stream));
+        OFK_HIP(c, hipStreamSynchronize(c->stream));
+        hold = solved == 0.0;
+    }
+    const bool any = few && !(fu && fu->redetect_replace) && !hold;
     if (any) {
         ofk_launch_redetect_limits(c->stream, c->counts, min_features, p->max_corners, c->limit, B);
         OFK_HIP(c, hipMemsetAsync(c->mask, 1, (size_t)B * c->img_stride, c->stream));
@@ -1280,14 +1290,16 @@ static int stream_step_impl(ofk_ctx *c, const uint8_t *next_bgr, const double *s
         TRY(stream_detect(c, 0, c->mask, c->limit, B, h, w, p, c->pts_new, c->new_counts));
     }
     // tracks := new[status == 1] ++ re-detected (node:134,166); the new frame becomes the previous one (node:175)
-    ofk_launch_update_tracks(c->stream, c->pts_next, c->status, c->counts, c->max_pts, any ? c->pts_new : nullptr, any ? c->new_counts : nullptr,
-                             c->pts_prev, c->counts, p->max_corners, B);
+    if (!hold)
+        ofk_launch_update_tracks(c->stream, c->pts_next, c->status, c->counts, c->max_pts, any ? c->pts_new : nullptr, any ? c->new_counts : nullptr,
+                                 c->pts_prev, c->counts, p->max_corners, B);
     TRY(check_launch(c, "ofk_stream_step"));
     if (records) OFK_HIP(c, hipMemcpyAsync(records, c->records, (size_t)B * OFK_RECORD_DOUBLES * 8, hipMemcpyDeviceToHost, c->stream));
     if (fu && fused) OFK_HIP(c, hipMemcpyAsync(fused, c->fused, (size_t)B * 64, hipMemcpyDeviceToHost, c->stream));
     // The tracks on the device already belong to the new frame (k_update_tracks), so the frame swap happens whatever the fetch
     // reports (OFK_E_CAPACITY from a re-detection, a failed copy): the next step must track against THIS frame's pyramid.
     const int rc = stream_fetch_tracks(c, B, p->max_corners, tracks, counts);
+    if (hold) return rc;                                         // old frame and old tracks stay; the next frame overwrites slot 1
     uint8_t *t = c->pyr[0]; c->pyr[0] = c->pyr[1]; c->pyr[1] = t;
     t = c->bgr[0]; c->bgr[0] = c->bgr[1]; c->bgr[1] = t;
     return rc;

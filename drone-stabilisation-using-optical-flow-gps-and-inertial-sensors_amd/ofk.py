@@ -58,7 +58,7 @@ class Fusion(C.Structure):
     """ofk_fusion (include/ofk.h): what ofk_stream_step_fused does between LK and the next frame."""
     _fields_ = [("use_imu", C.c_int), ("flow", C.c_int), ("keep", C.c_int), ("filter", C.c_int), ("control", C.c_int),
                 ("z_sign", C.c_double), ("z_source", C.c_int), ("vel_overwrite", C.c_int), ("redetect_replace", C.c_int),
-                ("min_solve", C.c_int)]
+                ("min_solve", C.c_int), ("hold_on_skip", C.c_int)]
 
 
 _lib = None

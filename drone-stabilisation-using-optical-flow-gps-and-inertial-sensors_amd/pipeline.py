@@ -120,18 +120,21 @@ class FusionConfig:
     vel_overwrite: bool = False
     redetect_replace: bool = False
     min_solve: int = 2
+    hold_on_skip: bool = False
     model: "FilterModel" = None
 
     @classmethod
-    def of_module(cls, synthetic_flow=True):
+    def of_module(cls, synthetic_flow=True, hold_on_skip=False):
         """The loop of optical_flow_experiments/of_module.py:78-167: kalman.predict(control) -> legacy r_tilde with the predicted
         velocity, keep r - (status - 1) >= T with cv2's uint8 status (a lost point's status-1 wraps to 255: dropped) -> A_i = [p]x / dist_i system -> kalman.correct(-v_obs); tracks := kept points;
         <= 10 tracks: replace by fresh corners.  synthetic_flow reproduces :113-114 (the measured flow overwritten by the
         rotational field of a random omega); False keeps the LK flow the script's TODO asks for.
         Use with PipelineConfig.of_module() (feas_T = 0.9, solve_variant = OFMODULE) and sensors cx, cy = of.pix_trans((480, 640)),
-        scaling = 1 (the script works in pixels, :96-102)."""
+        scaling = 1 (the script works in pixels, :96-102).  hold_on_skip=True (a FlowStream of ONE stream, which is what the script is)
+        also reproduces its `continue` at :138: a frame with <= 3 feasible points leaves old_gray and old_pos untouched, so the next
+        frame is tracked from the old one; in a batch of streams the frame always advances (one frame swap for all)."""
         return cls(flow=ofk.FLOW_ROTATIONAL if synthetic_flow else ofk.FLOW_LK, keep=ofk.KEEP_LEGACY, filter=True, control=ofk.CONTROL_SENSORS,
-                   z_sign=-1.0, z_source=0, redetect_replace=True, min_solve=3, model=FilterModel.kf3())
+                   z_sign=-1.0, z_source=0, redetect_replace=True, min_solve=3, hold_on_skip=bool(hold_on_skip), model=FilterModel.kf3())
 
     @classmethod
     def node(cls):
@@ -148,7 +151,7 @@ class FusionConfig:
 
     def to_struct(self):
         return ofk.Fusion(1 if self.use_imu else 0, int(self.flow), int(self.keep), 1 if self.filter else 0, int(self.control), float(self.z_sign),
-                          int(self.z_source), 1 if self.vel_overwrite else 0, 1 if self.redetect_replace else 0, int(self.min_solve))
+                          int(self.z_source), 1 if self.vel_overwrite else 0, 1 if self.redetect_replace else 0, int(self.min_solve), 1 if self.hold_on_skip else 0)
 
 
 class FlowStream:

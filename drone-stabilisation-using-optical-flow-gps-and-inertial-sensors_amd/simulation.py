@@ -104,15 +104,98 @@ def overlap(data1, data2):
     return ofk.default_context().hist_overlap(data1, data2, 100)
 
 
-def sweep_flow_errors(data, linear_velocity, angular_velocity, height_above_gr, normal_vector, translation, sigmas,
-                      k=100, trials=100, generator=None, comm=None):
-    """The "Effect of flow errors" driver (simulation.py:183-202): k sigma-steps, flow_sig = 0.001 i,
-    position_sig = sqrt(2)/1000 i; returns np.append(v_mean, v_std) laid out like the saved .npy files.
+# The eight Monte-Carlo sweeps of simulation.py:183-461 (each a '''-quoted block the author enabled one at a time; the saved
+# effect_*.npy files are their outputs).  axis -> (file the reference saved, reference's `iterations`, what step i of k changes)
+SWEEP_AXES = {
+    "flow_errors":       ("effect_of_flow_errors", 100),        # :183-202  flow_sig = 0.001 i, position_sig = sqrt(2)/1000 i
+    "distance_error":    ("effect_of_distance_error", 100),     # :216-235  height_sig = 0.001 i
+    "ang_vel_error":     ("effect_o_ang_vel_error", 100),       # :249-271  ang_vel_sig = 0.001 i
+    "normal_error":      ("effect_of_normal_error", 10),        # :285-304  normal_sig = 0.001 i (of_simulation discards the normal draw, :45-46)
+    "translation_error": ("effect_of_translation_error", 100),  # :319-338  translation_sig = 0.001 i
+    "orientation":       ("effect_of_orientation", 10),         # :355-377  normal = (sin(pi i/k), 0, cos(pi i/k)), true_flow regenerated
+    "height":            ("effect_of_height", 100),             # :398-423  height = 0.2 + linspace(0.2, 7.65, k)[i], true_flow regenerated
+    "point_position":    ("effect_of_point_position", 100),     # :441-461  points shifted by i/100 in x and y
+}
+SIGMA_ORDER = ("ang_vel_sig", "translation_sig", "height_sig", "flow_sig", "position_sig", "normal_sig")
+DEFAULT_SIGMAS = dict(ang_vel_sig=0.00071, translation_sig=0.005, height_sig=0.01, flow_sig=0.056 * np.sqrt(2) * 1.23,
+                      position_sig=0.056 * 1.23, normal_sig=0.00065)      # simulation.py:166-171
+
+
+def sweep_step(axis, i, k, data, height_above_gr, normal_vector, sigmas):
+    """What step i of `k` of the reference's sweep `axis` runs of_simulation with: (points, height, normal, six sigmas).
+    `data` are the raw points (points.txt); every block first centres and stretches them in place (:188-189 ...), the
+    point-position block with its own operator precedence (:443-444: x - mean(x) * 1.27)."""
+    if axis not in SWEEP_AXES:
+        raise ValueError(f"unknown sweep axis {axis!r}: one of {sorted(SWEEP_AXES)}")
+    d = np.array(data, np.float64)[:, :2].copy()
+    if axis == "point_position":
+        d[:, 0] = d[:, 0] - np.mean(d[:, 0]) * 1.27; d[:, 1] = d[:, 1] - np.mean(d[:, 1]) * 0.93
+        d = d + np.ones_like(d) * i / 100
+    else:
+        d[:, 0] = (d[:, 0] - np.mean(d[:, 0])) * 1.27; d[:, 1] = (d[:, 1] - np.mean(d[:, 1])) * 0.93
+    sg = dict(DEFAULT_SIGMAS); sg.update(sigmas or {})
+    h = float(height_above_gr); n = np.asarray(normal_vector, np.float64)
+    if axis == "flow_errors":
+        sg["flow_sig"] = 0.001 * i; sg["position_sig"] = np.sqrt(2) / 1000 * i
+    elif axis == "distance_error":
+        sg["height_sig"] = 0.001 * i
+    elif axis == "ang_vel_error":
+        sg["ang_vel_sig"] = 0.001 * i
+    elif axis == "normal_error":
+        sg["normal_sig"] = 0.001 * i
+    elif axis == "translation_error":
+        sg["translation_sig"] = 0.001 * i
+    elif axis == "orientation":
+        n = np.array([np.sin(np.pi * i / k), 0.0, np.cos(np.pi * i / k)])
+    elif axis == "height":
+        h = 0.2 + np.linspace(0.2, 7.65, k)[i]
+    return d, h, n, [sg[name] for name in SIGMA_ORDER]
+
+
+def sweep(axis, data, linear_velocity, angular_velocity, height_above_gr, normal_vector, translation, sigmas=None, k=100, trials=None,
+          steps=None, generator=None, comm=None):
+    """One of the reference's eight Monte-Carlo sweeps (SWEEP_AXES; simulation.py:183-461): k steps, `trials` of_simulation
+    iterations per step (default: the block's own `iterations`), all trials of a step in ONE launch of k_of_simulation.  Returns
+    np.append(v_mean, v_std) laid out like the saved effect_*.npy files ([k,3] means then [k,3] standard deviations); with
+    `steps` (a list of step indices) only those rows are computed and returned ([len(steps),3] + [len(steps),3]).
 
     With `comm` (sharding.Comm) the trials of every step are sharded over the ranks: rank r solves the contiguous slice
     shard_range(trials, r, world) of the step's trials on its own GPU and the per-step statistics come from one all-reduce of
     (sum v, sum v^2, count) = 7 doubles - trials never travel.  Every rank draws the step's full noise
     tensor from the same generator and keeps its slice, so the result does not depend on the number of ranks."""
+    global true_flow, iterations
+    try:
+        from . import sharding
+    except ImportError:
+        import sharding
+    trials = int(trials or SWEEP_AXES[axis][1])
+    rank, world = (comm.rank, comm.world) if comm is not None else (0, 1)
+    lo, hi = sharding.shard_range(trials, rank, world)
+    idx = list(range(k)) if steps is None else [int(i) for i in steps]
+    v_mean = np.zeros((len(idx), 3)); v_std = np.zeros((len(idx), 3))
+    saved_iterations = iterations
+    for row, i in enumerate(idx):
+        d, h, n, sig = sweep_step(axis, i, k, data, height_above_gr, normal_vector, sigmas)
+        true_flow = generate_test_data(d, linear_velocity, angular_velocity, h, n, translation)
+        z = draw_noise(len(d), trials, generator)[lo:hi]
+        if hi > lo:
+            iterations = hi - lo
+            v_obs, _, _ = of_simulation(linear_velocity, angular_velocity, h, n, translation, d, *sig, z=z)
+        else:
+            v_obs = np.zeros((0, 3))
+        if comm is None:
+            v_mean[row] = v_obs.mean(axis=0); v_std[row] = v_obs.std(axis=0)
+        else:
+            v_mean[row], v_std[row], _ = sharding.combine_moments(v_obs.sum(0), (v_obs * v_obs).sum(0), len(v_obs), comm.allreduce)
+    iterations = saved_iterations
+    return np.append(v_mean, v_std)
+
+
+def sweep_flow_errors(data, linear_velocity, angular_velocity, height_above_gr, normal_vector, translation, sigmas,
+                      k=100, trials=100, generator=None, comm=None):
+    """The "Effect of flow errors" driver (simulation.py:183-202) on points that are ALREADY centred / scaled (kept from round 2 for
+    its callers; sweep("flow_errors", raw_points, ...) applies the block's own centring): k sigma-steps, flow_sig = 0.001 i,
+    position_sig = sqrt(2)/1000 i; returns np.append(v_mean, v_std) laid out like the saved .npy files.  Sharding as in sweep()."""
     global true_flow, iterations
     try:
         from . import sharding

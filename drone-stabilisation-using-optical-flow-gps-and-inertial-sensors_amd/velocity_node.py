@@ -84,6 +84,58 @@ class optical_fusion:
     scaling = 0.01
     T = 0.0
 
+
+    # ---- the attributes call_imu owns (node:61-89).  Plain host values while the node runs as shipped; with the restored pipeline
+    #      their truth lives on the device between frames and the host copy is refreshed only when somebody reads one
+    #      (ofk_imu_state), or pushed down when somebody assigns one.
+    def _imu_refresh(self):
+        if self._imu_stale and self._stream is not None:
+            self._imu_flush()
+            st, _ = self._stream.ctx.imu_state(1)
+            s0 = st[0]
+            d = self._imu
+            d["vel"] = s0[0:3].copy(); d["old_time"] = float(s0[3]); d["time_zero"] = int(s0[4]); d["first_imu_"] = bool(s0[5] != 0.0)
+            d["rotation"] = s0[6:15].reshape(3, 3).copy(); d["normal"] = s0[15:18].copy(); d["ang"] = s0[18:21].copy(); d["ang_err"] = s0[21:24].copy()
+            self._imu_stale = False
+
+    def _imu_flush(self):
+        """Host -> device: a state somebody assigned on the host first, then the messages received since the last frame."""
+        fs = self._stream
+        if fs is None:
+            return
+        if self._imu_host_dirty:
+            d = self._imu
+            s0 = np.zeros(ofk.IMU_STATE)
+            s0[0:3] = d["vel"]; s0[3] = d["old_time"]; s0[4] = d["time_zero"]; s0[5] = 1.0 if d["first_imu_"] else 0.0
+            s0[6:15] = np.asarray(d["rotation"], np.float64).ravel(); s0[15:18] = d["normal"]; s0[18:21] = d["ang"]
+            s0[21:24] = np.asarray(d["ang_err"], np.float64).ravel()[:3] if np.size(d["ang_err"]) >= 3 else 0.0
+            fs.ctx.imu_reset(1, s0)
+            self._imu_host_dirty = False
+        if self._imu_pending:
+            fs.push_imu(np.stack(self._imu_pending)[None])
+            self._imu_pending = []
+
+    def _imu_get(self, name):
+        with self._lock:
+            self._imu_refresh()
+            return self._imu[name]
+
+    def _imu_set(self, name, value):
+        with self._lock:
+            self._imu_refresh()                                  # messages queued before the assignment are applied before it
+            self._imu[name] = value
+            if self._stream is not None:
+                self._imu_host_dirty = True
+
+    vel = property(lambda self: self._imu_get("vel"), lambda self, v: self._imu_set("vel", v))
+    old_time = property(lambda self: self._imu_get("old_time"), lambda self, v: self._imu_set("old_time", v))
+    time_zero = property(lambda self: self._imu_get("time_zero"), lambda self, v: self._imu_set("time_zero", v))
+    first_imu_ = property(lambda self: self._imu_get("first_imu_"), lambda self, v: self._imu_set("first_imu_", v))
+    rotation = property(lambda self: self._imu_get("rotation"), lambda self, v: self._imu_set("rotation", v))
+    normal = property(lambda self: self._imu_get("normal"), lambda self, v: self._imu_set("normal", v))
+    ang = property(lambda self: self._imu_get("ang"), lambda self, v: self._imu_set("ang", v))
+    ang_err = property(lambda self: self._imu_get("ang_err"), lambda self, v: self._imu_set("ang_err", v))
+
     def call_dist(self, data):
         """node:55-58 — reads the range and discards it (self.d stays 0.75)."""
         distance = data.range  # noqa: F841
@@ -94,6 +146,14 @@ class optical_fusion:
         cov = data.angular_velocity_covariance
         msg = np.array([st.secs, st.nsecs, q.x, q.y, q.z, q.w, w.x, w.y, w.z, cov[0], cov[4], cov[8], a.x, a.y, a.z], np.float64)
         with self._lock:
+            if self._stream is not None and not self.synthetic_test:
+                # The restored pipeline keeps node:61-89's state on the device (FlowStream, FusionConfig.node(): k_imu_seq applies the
+                # messages, k_stream_fuse reads normal / omega / R / velocity from there and writes self.vel = v_uav back).  A message
+                # costs a list append here; the whole batch since the last frame goes up with that frame (or when an attribute is read).
+                self._imu_pending.append(msg)
+                self._imu_stale = True
+                self.got_ang_vel_ = True
+                return
             state = np.zeros(ofk.IMU_STATE)
             state[0:3] = self.vel; state[3] = self.old_time; state[4] = self.time_zero; state[5] = 1.0 if self.first_imu_ else 0.0
             state = self._ctx().imu_propagate(state, msg)
@@ -174,9 +234,10 @@ class optical_fusion:
                                  win=int(self.lk_params["winSize"][0]), max_level=int(self.lk_params["maxLevel"]), max_count=cnt, eps=eps,
                                  use_feasibility=True, feas_T=float(self.T))
             self._stream = FlowStream(w, h, batch=1, cfg=cfg, device=int(os.environ.get("OFK_DEVICE", "0")), min_features=int(self.min_feat),
-                                      mask_radius=30, fusion=FusionConfig(keep=ofk.KEEP_STATUS, min_solve=2))
+                                      mask_radius=30, fusion=FusionConfig.node())
             self._stream_dim = (h, w)
             self.first = True
+            self._imu_host_dirty = True                          # the dead-reckoning state so far moves to the device with the first step
         fs = self._stream
         if self.first:
             tracks, counts = fs.begin_jpeg([frame]) if is_jpeg else fs.begin(frame[None])
@@ -188,9 +249,12 @@ class optical_fusion:
         old = np.asarray(self.feat, np.float32).reshape(-1, 2)
         translation = of.pix_trans((320, 240))                   # node:229 (the node centres with (160, 120) whatever the frame size)
         fs._params.feas_T = float(self.T)
-        sensors = ofk.make_sensors(1, d=self.d, normal=self.normal, omega=self.ang, rotation=np.asarray(self.rotation, np.float64), offset=self.offset,
-                                   scaling=self.scaling, cx=translation[0], cy=translation[1], v_prior=self.vel)
+        self._imu_flush()                                        # host-side assignments, then the IMU messages since the last frame: one upload
+        # normal / omega / R / prior velocity come from the resident IMU state (FusionConfig.node(): use_imu); the record only
+        # carries what call_imu does not own
+        sensors = ofk.make_sensors(1, d=self.d, offset=self.offset, scaling=self.scaling, cx=translation[0], cy=translation[1])
         rec, fused, tracks, counts = fs.step_fused([frame] if is_jpeg else frame[None], sensors)
+        self._imu_stale = True                                   # the step wrote self.vel = v_uav on the device (node:261)
         nxt, keep = fs.ctx.stream_last_points(max(1, len(old)))
         k = keep[0, :len(old)] != 0
         n = int(counts[0])
@@ -218,7 +282,8 @@ class optical_fusion:
                     return None
                 v_obs, v_uav, R, rank, sv = res
                 print('    '.join(map(str, v_obs)))                                                          # node:259
-                self.vel = v_uav                                                                             # node:261
+                # node:261 self.vel = v_uav happened on the device behind the solve (vel_overwrite); reading self.vel fetches it
+                self.last_v_uav = v_uav
                 self.last_residual, self.last_rank, self.last_s = R, rank, sv
                 return v_obs
             # ---- the node as shipped: 4 test features, flow from generate_test_data, feasibility forced to -1
@@ -244,9 +309,11 @@ class optical_fusion:
 
     def __init__(self, spin=True, synthetic_test=True):
         self._lock = threading.RLock()
+        self._imu = {}                                           # host copy of the attributes call_imu owns (see the properties above)
+        self._imu_pending, self._imu_stale, self._imu_host_dirty = [], False, False
+        self._stream = None
         self.synthetic_test = synthetic_test
-        self._stream = None                                      # pipeline.FlowStream of the restored pipeline (created with the first frame)
-        self._stream_dim = None
+        self._stream_dim = None                                  # (self._stream: pipeline.FlowStream of the restored pipeline, created with the first frame)
         self._resident_result = None
         self.vel = np.array([0.1, 0.1, 0.1])
         self.vel_err = np.array([0.1, 0.1, 0.1])

@@ -307,14 +307,17 @@ typedef struct ofk_fusion {
     int    redetect_replace; /* 1: streams with <= min_features tracks REPLACE them by maxCorners - count fresh corners of the previous
                                 frame, no mask, before tracking (of_module.py:83-86); 0: append with a disc mask after tracking (node:157-166) */
     int    min_solve;        /* solve only with MORE than this many kept points (of_module.py:138: 3; node:256: 2) */
+    int    hold_on_skip;     /* 1 (one stream per context only): a step that does not solve leaves the previous frame and the tracks as they
+                                were, like the `continue` of of_module.py:138 - the next frame is tracked from the OLD one; the filter keeps
+                                its prediction.  Costs one host wait per step.  0: the frame always advances (a batch shares one frame swap) */
 } ofk_fusion;
 /* ofk_stream_step with the filters in the loop: (redetect_replace) -> gray + pyramid of the new frames -> LK -> k_stream_fuse
  * (centre/scale, flow, filter predict, feasibility, solve with p->solve_variant incl. OFK_SOLVE_OFMODULE, lever arm + rotation,
  * filter correct, velocity overwrite) -> tracks := kept points -> (masked re-detection) -> frame swap.  records as in
  * ofk_stream_step (slot 15: 1 if the system was solved); fused [batch][8] = filter state x[0..5] (zero padded), trace(P), solved —
- * without a filter: v_uav (or the dead-reckoned velocity when nothing was solved).  Deviation from of_module.py:138, which
- * `continue`s on <= 3 feasible points WITHOUT advancing the frame: a batch of streams shares one frame swap, so the frame always
- * advances; the filter then keeps its prediction and the record reports rank 0. */
+ * without a filter: v_uav (or the dead-reckoned velocity when nothing was solved).  of_module.py:138 `continue`s on <= 3 feasible points
+ * WITHOUT advancing the frame: f->hold_on_skip = 1 reproduces that for a context with ONE stream (what the script is); a batch of
+ * streams shares one frame swap, so there the frame always advances, the filter keeps its prediction and the record reports rank 0. */
 int ofk_stream_step_fused(ofk_ctx *ctx, const uint8_t *next_bgr, const double *sensors, const ofk_params *p, const ofk_fusion *f,
                           int min_features, int mask_radius, double *records, double *fused, float *tracks, int *counts);
 /* Next positions [batch][stride][2] and keep flags [batch][stride] of the latest step (valid until the next one): with the tracks

@@ -46,14 +46,15 @@ def oracle_stream(frames, cfg, sensors, min_feat, radius):
     return first, steps
 
 
-def oracle_of_module(frames, cfg, normal, controls, omegas, min_feat, cx, cy, model, synthetic_flow=True):
+def oracle_of_module(frames, cfg, normal, controls, omegas, min_feat, cx, cy, model, synthetic_flow=True, hold=False):
     """optical_flow_experiments/of_module.py:78-167 written with the oracle's functions, one stream:
     re-detect (replace) when <= min_feat tracks (:83-86) -> LK (:88) -> x = [new - pix_trans, 1] in pixels (:96-102) -> u = LK flow or
     the synthetic rotational field of omega on the un-centred positions (:107-114) -> kalman.predict(control) (:122) -> legacy
     r_tilde with the predicted velocity (:125) -> keep r - (status - 1) >= T with uint8 status, i.e. tracked and r >= T (:129-131) -> A_i = [p]x / dist_i system, lstsq
     (:136-146) -> kalman.correct(-v_obs) (:152) -> old_pos = new_pos[keep] (:166).
-    One deviation, shared with the device (include/ofk.h, ofk_stream_step_fused): on <= 3 feasible points the script `continue`s
-    without advancing the frame; here the frame advances and the filter keeps its prediction.
+    On <= 3 feasible points the script `continue`s without advancing the frame (:138): hold=True does the same (the device's
+    ofk_fusion.hold_on_skip, one stream per context); hold=False advances the frame and lets the filter keep its prediction, which
+    is what a batch of streams sharing one frame swap does (include/ofk.h, ofk_stream_step_fused).
     Returns per step (v_obs or None, filter state x, P, tracks after the step, n_old, n_kept)."""
     n = np.asarray(normal, np.float64)
     g_prev = io.gray_bgr8(frames[0])
@@ -87,13 +88,16 @@ def oracle_of_module(frames, cfg, normal, controls, omegas, min_feat, cx, cy, mo
         if keep.sum() > 3:
             v = eo.solve_of_module(x3[keep], u3[keep], dist[keep], n)[0]
             xk, P = eo.kf_correct(xk, P, model.H, model.R, -v)
+        elif hold:                                               # of_module.py:138 `continue`: old_gray and old_pos stay as they are
+            steps.append((None, xk.copy(), P.copy(), old.copy(), n_old, int(keep.sum())))
+            continue
         old = new[keep]
         steps.append((v, xk.copy(), P.copy(), old.copy(), n_old, int(keep.sum())))
         g_prev = g
     return first, steps
 
 
-def oracle_node_fused(frames, cfg, statics, imu_msgs, min_feat, radius, model=None):
+def oracle_node_fused(frames, cfg, statics, imu_msgs, min_feat, radius, model=None, gps=None):
     """velocity_measurment_node with its commented-out blocks restored AND its IMU callback in the loop, one stream:
     call_imu for every message since the last frame (node:61-89: quaternion -> R, normal, dead-reckoned velocity) -> LK (:133) ->
     centre + scale (:229-235) -> solve_lgs on the tracked points with the IMU's normal / omega (:257) -> lever arm + rotation (:258)
@@ -132,8 +136,8 @@ def oracle_node_fused(frames, cfg, statics, imu_msgs, min_feat, radius, model=No
         if len(x) > 2:
             v = eo.solve_lgs_node(x, u, statics["d"], nrm, om)[0]
             vu = eo.post_solve(v, R, om, np.asarray(statics["offset"], np.float64))
-            if model is not None:
-                xk, P = eo.kf_correct(xk, P, model.H, model.R, vu)
+            if model is not None:                              # FilterModel.ekf6(gps=True): the second velocity measurement stacked under the optical fix
+                xk, P = eo.kf_correct(xk, P, model.H, model.R, vu if gps is None else np.concatenate([vu, np.asarray(gps[t - 1], np.float64)]))
             else:
                 state["vel"] = vu.copy()
         tracked = new[ok]

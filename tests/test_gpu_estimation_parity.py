@@ -149,6 +149,68 @@ def test_of_simulation_statistics_vs_saved_sweep(gpu_ctx, golden):
     assert np.all(np.abs(v.std(0) / std_s[i] - 1) < 0.35)
 
 
+# ---- the eight saved Monte-Carlo sweeps (simulation.py:183-461): every effect_*.npy the reference holds is a statistical pin
+SWEEP_RULES = {
+    # axis: (sigma overrides, n_ref = the block's `iterations`, std band (None: not compared), steps whose std is compared,
+    #        extra tolerance on the means, components compared)
+    # --- curves the script AS COMMITTED reproduces: mean within 4 sigma / sqrt(n) of both samples, std within the band
+    "flow_errors":       ({}, 100, (0.65, 1.35), (10, 50, 90), 0.0, (0, 1, 2)),
+    "point_position":    ({}, 100, (0.65, 1.35), (10, 50, 90), 0.0, (0, 1, 2)),
+    "orientation":       ({}, 10, (0.4, 2.5), (10, 50, 90), 0.0, (0, 1, 2)),       # 10 trials per step in the reference: its std estimate scatters by 24 %
+    # --- effect_of_distance_error.npy predates the "* 1.23" the author later put on flow_sig / position_sig (:169-170): with the
+    #     constants without it the curve is reproduced as tightly as the three above (v_z bias 0.971 instead of 0.956)
+    "distance_error":    ({"flow_sig": 0.056 * np.sqrt(2), "position_sig": 0.056}, 100, (0.65, 1.35), (10, 50, 90), 0.0, (0, 1, 2)),
+    # --- curves saved under base constants the script no longer holds (v_z bias 0.98-0.99 instead of 0.956: smaller position noise at
+    #     the time): the swept sigma dominates the spread from the middle of the sweep on, which is what is compared; means get
+    #     the bias difference as tolerance
+    "ang_vel_error":     ({}, 100, (0.65, 1.35), (50, 90), 0.045, (0, 1)),
+    "translation_error": ({}, 100, (0.65, 1.35), (50, 90), 0.045, (0, 1, 2)),
+    "normal_error":      ({}, 10, (0.3, 3.0), (10, 50, 90), 0.045, (0, 1, 2)),       # the normal draw is discarded (:45-46): a flat curve, 10 trials per step
+    # --- effect_of_height.npy: x / y spread 3-5 x what the committed constants give (the block carries commented-out alternative
+    #     velocities, :408-409): only the means are comparable
+    "height":            ({}, 100, None, (), 0.06, (0, 1, 2)),
+}
+
+
+@pytest.fixture(scope="module")
+def sweeps_golden():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_sweeps.npz"))
+
+
+@pytest.mark.parametrize("axis", sorted(SWEEP_RULES))
+def test_saved_sweep_is_reproduced(pkg, gpu_ctx, sweeps_golden, axis):
+    """simulation.sweep(axis) - one launch of k_of_simulation per step, 2000 trials - against the curve the reference saved for
+    that block, at steps 10, 50 and 90 of 100 (unseeded RNG in the reference: a statistical comparison)."""
+    import of_amd.simulation as sim
+    override, n_ref, band, std_steps, mean_tol, comps = SWEEP_RULES[axis]
+    saved = sweeps_golden[sim.SWEEP_AXES[axis][0]]
+    mean_s, std_s = saved[:300].reshape(100, 3), saved[300:].reshape(100, 3)
+    steps, trials = (10, 50, 90), 2000
+    out = sim.sweep(axis, sweeps_golden["points_raw"], [1.0, 1, 1], [1.0, 1, 1], 1.0, [0.0, 0, 1], [0.02, 0, 0.205], sigmas=override,
+                    k=100, trials=trials, steps=steps, generator=np.random.default_rng(11))
+    mean_o, std_o = out[:9].reshape(3, 3), out[9:].reshape(3, 3)
+    assert np.all(np.isfinite(out))
+    for row, i in enumerate(steps):
+        for c in comps:
+            tol = 4 * std_s[i, c] / np.sqrt(n_ref) + 4 * std_o[row, c] / np.sqrt(trials) + mean_tol
+            assert abs(mean_o[row, c] - mean_s[i, c]) < tol, (axis, i, c, mean_o[row], mean_s[i], tol)
+            if band is not None and i in std_steps:
+                assert band[0] < std_o[row, c] / std_s[i, c] < band[1], (axis, i, c, std_o[row], std_s[i])
+
+
+def test_sweep_layout_and_default_trials(pkg, gpu_ctx, sweeps_golden):
+    """Full-length call: np.append(v_mean, v_std) of k x 3 + k x 3 values like the saved files; `trials` defaults to the block's own
+    `iterations`; the module's `iterations` global is left as it was."""
+    import of_amd.simulation as sim
+    before = sim.iterations
+    out = sim.sweep("orientation", sweeps_golden["points_raw"], [1.0, 1, 1], [1.0, 1, 1], 1.0, [0.0, 0, 1], [0.02, 0, 0.205], k=12,
+                    generator=np.random.default_rng(2))
+    assert out.shape == (72,) and np.all(np.isfinite(out)) and sim.iterations == before
+    with pytest.raises(ValueError):
+        sim.sweep_step("no_such_axis", 0, 100, sweeps_golden["points_raw"], 1.0, [0, 0, 1], None)
+
+
 # ---- feas_simulation + overlap (simulation.py:70-104, 124-136; the live experiment :753-774), golden from the reference's functions
 @pytest.fixture(scope="module")
 def feas_golden():

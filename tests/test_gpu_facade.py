@@ -171,3 +171,60 @@ def test_simulation_module(mods, golden):
     sim.rng = np.random.default_rng(1); sim.iterations = 200
     v_obs, feas, Rb = sim.of_simulation(g["g1_v"], g["g1_omega"], 1, g["g1_n"], g["g1_t"], g["g1_points"], sg[0], sg[1], sg[2], 0.01, 0.01, sg[5])
     assert v_obs.shape == (200, 3) and np.all(np.abs(v_obs.mean(0) - 1) < 0.02)
+
+
+def test_node_keeps_its_imu_state_on_the_device(mods, pkg):
+    """velocity_measurment_node with its pipeline restored AND its IMU callback in the loop (node:61-89 + :229-261): once the
+    stream exists, call_imu only queues the message; the batch since the last frame goes up with that frame, k_imu_seq applies it,
+    k_stream_fuse takes normal / omega / R / the dead-reckoned velocity from the resident state and writes self.vel = v_uav back.
+    The node's attributes read the device state lazily.  Against the oracle composition of the reference's steps
+    (tests/stream_oracle.py::oracle_node_fused)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from stream_oracle import oracle_node_fused
+    from of_amd import synth
+    from of_amd.pipeline import PipelineConfig
+    node = mods.node
+    h, w, nf = 480, 640, 6
+    frames, info = synth.render_sequence(h, w, 61, nf, v=(0.01, -0.008, 0.004), omega=(0.002, 0.001, -0.003), d=0.75, scaling=0.01)
+    rng = np.random.default_rng(8)
+
+    def msgs_at(t0, n):
+        out = np.zeros((n, 15))
+        for k in range(n):
+            t = t0 + 0.02 * (k + 1)
+            ax = rng.normal(0, 0.02, 3)
+            q = np.array([ax[0] / 2, ax[1] / 2, ax[2] / 2, 1.0]); q /= np.linalg.norm(q)
+            out[k] = [int(t), int((t - int(t)) * 1e9), *q, *rng.normal(0, 0.002, 3), 1e-4, 2e-4, 3e-4, *(rng.normal(0, 0.05, 3) + [0, 0, 9.81])]
+        return out
+    msgs = np.stack([msgs_at(200.0 + 0.1 * t, 3) for t in range(nf - 1)])
+    n = node.optical_fusion(spin=False, synthetic_test=False)
+    n.feature_params = dict(qualityLevel=0.05, minDistance=10, blockSize=12)
+    n.T = 2.0                                                    # keep every tracked point (r_tilde <= 1 always): the oracle loop has no r_tilde filter
+    cfg = PipelineConfig(max_corners=100, quality=0.05, min_distance=10, block_size=12, win=15, max_level=3, max_count=20, eps=0.03)
+    statics = dict(d=0.75, offset=(0.0, 0.0, 0.1), scaling=0.01, cx=160.0, cy=120.0)      # node:229 centres with pix_trans((320, 240))
+    ref = oracle_node_fused(frames, cfg, statics, msgs, 20, 30, None)
+    n.call_optical(frames[0])
+    assert len(n.feat) == len(ref[0]) and n._stream is not None
+    for t in range(1, nf):
+        for m in msgs[t - 1]:
+            n.call_imu(fake_imu(np.concatenate([m[:9], m[12:15]]), m[9:12]))
+        assert len(n._imu_pending) == 3                          # queued on the host, nothing went to the device yet
+        n.call_optical(frames[t])
+        assert n._imu_pending == []
+        v_obs = n.step()
+        v, vu, vel, tr, n_old, n_tr = ref[1][t - 1]
+        np.testing.assert_allclose(v_obs, v, rtol=1e-8, atol=1e-12)
+        np.testing.assert_allclose(n.vel, vel, rtol=1e-8, atol=1e-12)          # self.vel = v_uav (node:261), read back from the device
+        np.testing.assert_allclose(n.last_v_uav, vu, rtol=1e-8, atol=1e-12)
+        assert len(n.feat) == len(tr)
+    # attributes are the device state; an assignment on the host goes down with the next use
+    assert n.got_ang_vel_ and not n.first_imu_ and n.rotation.shape == (3, 3) and abs(np.linalg.det(n.rotation) - 1) < 1e-9
+    n.vel = np.array([0.5, 0.25, -0.125])
+    m = msgs_at(300.0, 1)[0]
+    n.call_imu(fake_imu(np.concatenate([m[:9], m[12:15]]), m[9:12]))
+    state = dict(vel=np.array([0.5, 0.25, -0.125]), old_time=n._imu["old_time"], time_zero=n._imu["time_zero"], first=False,
+                 rotation=np.eye(3), normal=np.array([0.0, 0, 1]), ang=np.zeros(3))
+    want = eo.imu_step(state, m[0], m[1], m[2:6], m[6:9], m[9:12], m[12:15])
+    np.testing.assert_allclose(n.vel, want["vel"], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(n.normal, want["normal"], rtol=1e-12, atol=1e-14)

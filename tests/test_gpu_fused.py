@@ -173,3 +173,100 @@ def test_of_module_keep_rule_drops_lost_points(pkg, ofk):
         lost_total += int(rec[0, 12] - rec[0, 13])
     assert lost_total > 0, "the clip must lose points for this test to mean anything"
     fs.close()
+
+
+def test_ekf6_with_gps_measurement_block(pkg, ofk, gpu_ctx):
+    """FilterModel.ekf6(gps=True): H = [[I 0], [I 0]], R = diag(r I, r_gps I) (nm = 6; DESIGN.md §2a - the reference has no GPS
+    data, so this row is build-defined and needs its own known-answer tests):
+      1. stand-alone kernel (ofk_kf_predict_update, nm = 6) == the numpy restatement;
+      2. information-fusion identity: two independent measurements z1 (variance r) and z2 (variance r_gps) of the same state are
+         one measurement (z1 / r + z2 / r_gps) / (1 / r + 1 / r_gps) with variance 1 / (1 / r + 1 / r_gps) - the 6-row update must
+         land on the 3-row update with those, to rounding;
+      3. through the resident stream loop (k_stream_fuse reads the second block from sensor slots 22-24) == the oracle
+         composition of the node loop with the stacked measurement, and == the stand-alone kernel fed the same numbers."""
+    from of_amd import synth
+    from of_amd.pipeline import FlowStream, PipelineConfig, FusionConfig, FilterModel
+    from oracle import estimation_oracle as eo
+    m6 = FilterModel.ekf6(dt=0.1, r=4.0, gps=True, r_gps=0.5)
+    m3 = FilterModel.ekf6(dt=0.1, r=1.0 / (1.0 / 4.0 + 1.0 / 0.5), gps=False)
+    assert m6.nm == 6 and m6.H.shape == (6, 6) and m6.R.shape == (6, 6)
+    rng = np.random.default_rng(21)
+    x6, P6 = m6.x0.copy(), m6.P0.copy(); x3, P3 = m3.x0.copy(), m3.P0.copy(); xn, Pn = m6.x0.copy(), m6.P0.copy()
+    for t in range(6):
+        u = rng.normal(0, 0.05, 3); z1 = rng.normal(0.3, 0.2, 3); z2 = z1 + rng.normal(0, 0.05, 3)
+        x6, P6 = gpu_ctx.kf_predict_update(m6.F, m6.H, m6.Q, m6.R, x6, P6, B=m6.B, u=u, z=np.concatenate([z1, z2]))
+        xn, Pn = eo.kf_predict(xn, Pn, m6.F, m6.Q, m6.B, u); xn, Pn = eo.kf_correct(xn, Pn, m6.H, m6.R, np.concatenate([z1, z2]))
+        zeff = (z1 / 4.0 + z2 / 0.5) / (1.0 / 4.0 + 1.0 / 0.5)
+        x3, P3 = gpu_ctx.kf_predict_update(m3.F, m3.H, m3.Q, m3.R, x3, P3, B=m3.B, u=u, z=zeff)
+        np.testing.assert_allclose(x6, xn, rtol=1e-11, atol=1e-14); np.testing.assert_allclose(P6, Pn, rtol=1e-10, atol=1e-14)
+        np.testing.assert_allclose(x6, x3, rtol=1e-10, atol=1e-13); np.testing.assert_allclose(P6, P3, rtol=1e-9, atol=1e-13)
+    # 3. the resident loop
+    h, w, nf = 240, 320, 6
+    cfg = PipelineConfig(max_corners=80, quality=0.02, min_distance=8, block_size=7, max_level=2)
+    frames, info = synth.render_sequence(h, w, 951, nf, v=(0.004, -0.003, 0.002), omega=(0.002, 0.001, -0.003), d=1.0)
+    statics = dict(d=1.0, offset=(0.0, 0.0, 0.1), scaling=info["scaling"], cx=info["cx"], cy=info["cy"])
+    msgs = np.stack([make_imu_msgs(rng, 50.0 + 0.1 * t, 3) for t in range(nf - 1)])          # [nf-1, 3, 15]
+    gps = rng.normal(0.0, 0.01, (nf - 1, 3)) + [0.004, -0.003, 0.002]
+    fusion = FusionConfig.ekf6(dt=0.1, gps=True, r=4.0, r_gps=0.5)
+    fs = FlowStream(w, h, batch=1, cfg=cfg, min_features=70, mask_radius=12, fusion=fusion)
+    fs.begin(frames[0][None])
+    ref = oracle_node_fused(frames, cfg, statics, msgs, 70, 12, fusion.model, gps=gps)
+    xs, Ps = fusion.model.x0.copy(), fusion.model.P0.copy()
+    for t in range(1, nf):
+        fs.push_imu(msgs[t - 1][None])
+        _, dv = fs.ctx.imu_state(1)                              # the increments the step will consume as the filter's control
+        sensors = ofk.make_sensors(1, d=statics["d"], offset=statics["offset"], scaling=statics["scaling"], cx=statics["cx"], cy=statics["cy"],
+                                   v_prior=gps[t - 1])           # slots 22-24: the second measurement block
+        rec, fused, tracks, counts = fs.step_fused(frames[t][None], sensors)
+        v, vu, xk, tr, n_old, n_tr = ref[1][t - 1]
+        assert rec[0, 15] == 1 and counts[0] == len(tr)
+        np.testing.assert_allclose(rec[0, 8:11], vu, rtol=1e-8, atol=1e-12)
+        np.testing.assert_allclose(fused[0, :6], xk, rtol=1e-8, atol=1e-12)
+        xs, Ps = gpu_ctx.kf_predict_update(fusion.model.F, fusion.model.H, fusion.model.Q, fusion.model.R, xs, Ps, B=fusion.model.B, u=dv[0],
+                                           z=np.concatenate([rec[0, 8:11], gps[t - 1]]))
+        gx, gP = fs.ctx.filter_state(1)
+        assert np.array_equal(gx[0].view(np.uint64), xs.view(np.uint64)) and np.array_equal(gP[0].view(np.uint64), Ps.view(np.uint64)), t
+    fs.close()
+
+
+@pytest.mark.parametrize("T", [0.2, 0.8])
+def test_of_module_continue_keeps_the_old_frame(pkg, ofk, T):
+    """of_module.py:138: with <= 3 feasible points the script `continue`s - old_gray and old_pos stay, the next frame is tracked from
+    the OLD one, the filter keeps its prediction.  FusionConfig.of_module(hold_on_skip=True) on a FlowStream of one stream against
+    the oracle loop with the same rule; both thresholds give clips with held AND solved steps.  A batch of streams refuses the flag."""
+    from of_amd import synth
+    from of_amd.of_library import pix_trans
+    from of_amd.pipeline import FlowStream, PipelineConfig, FusionConfig
+    h, w, nf = 240, 320, 9
+    frames, info = synth.render_sequence(h, w, 41, nf, v=(0.006, -0.004, 0.002), omega=(0.001, -0.002, 0.003), d=1.0)
+    rng = np.random.default_rng(13)
+    controls = rng.normal(0, 0.01, (nf - 1, 3)); omegas = rng.normal(0, 0.01, (nf - 1, 3))
+    cx, cy = pix_trans((240, 320))
+    normal = np.array([0.0, 0.0, 1.0])
+    cfg = PipelineConfig.of_module(); cfg.max_corners = 60; cfg.quality = 0.05; cfg.block_size = 7; cfg.min_distance = 8; cfg.max_level = 2; cfg.feas_T = T
+    fusion = FusionConfig.of_module(synthetic_flow=False, hold_on_skip=True)
+    ref = oracle_of_module(frames, cfg, normal, controls, omegas, 10, cx, cy, fusion.model, False, hold=True)
+    fs = FlowStream(w, h, batch=1, cfg=cfg, min_features=10, mask_radius=10, fusion=fusion)
+    tracks, counts = fs.begin(frames[0][None])
+    held = solved = 0
+    for t in range(1, nf):
+        sensors = ofk.make_sensors(1, d=1.0, normal=normal, omega=omegas[t - 1], scaling=1.0, cx=cx, cy=cy)
+        sensors[:, 25:28] = controls[t - 1]
+        rec, fused, tracks, counts = fs.step_fused(frames[t][None], sensors)
+        v, xk, P, tr, n_old, n_keep = ref[1][t - 1]
+        assert rec[0, 12] == n_old and rec[0, 11] == n_keep and counts[0] == len(tr), (t, rec[0, 11:14], n_old, n_keep, len(tr))
+        assert np.array_equal(tracks[0, :counts[0]].view(np.uint32), tr.astype(np.float32).view(np.uint32)), t
+        np.testing.assert_allclose(fused[0, :3], xk, rtol=1e-8, atol=1e-12)
+        if v is None:
+            held += 1
+            assert rec[0, 15] == 0
+        else:
+            solved += 1
+            np.testing.assert_allclose(rec[0, :3], v, rtol=1e-7, atol=1e-12)
+    assert held >= 1 and solved >= 2
+    fs.close()
+    fs2 = FlowStream(w, h, batch=2, cfg=cfg, min_features=10, mask_radius=10, fusion=fusion)
+    fs2.begin(np.stack([frames[0], frames[0]]))
+    with pytest.raises(ofk.OfkError):
+        fs2.step_fused(np.stack([frames[1], frames[1]]), ofk.make_sensors(2, scaling=1.0, cx=cx, cy=cy))
+    fs2.close()

@@ -157,3 +157,35 @@ def test_overlap_oracle_matches_reference(feas_golden):
     g = feas_golden
     assert eo.overlap(g["ov_d1"], g["ov_d2"]) == int(g["ov_12"]) and eo.overlap(g["ov_d3"], g["ov_d3"]) == int(g["ov_33"]) == 40
     assert eo.overlap(g["ov_d1"], g["ov_d3"]) == int(g["ov_13"])
+
+
+def test_sweep_steps_follow_the_reference_blocks(pkg):
+    """simulation.sweep_step restates what step i of each of the eight sweep blocks (simulation.py:183-461) feeds of_simulation;
+    and the oracle's of_simulation on those inputs lands on the curve the reference saved (CPU, two axes, 150 trials)."""
+    import os
+    import of_amd.simulation as sim
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_sweeps.npz"))
+    raw = g["points_raw"]
+    d, h, n, sig = sim.sweep_step("flow_errors", 40, 100, raw, 1.0, [0, 0, 1], None)
+    np.testing.assert_allclose(d[:, 0], (raw[:, 0] - raw[:, 0].mean()) * 1.27); np.testing.assert_allclose(d[:, 1], (raw[:, 1] - raw[:, 1].mean()) * 0.93)
+    assert sig[3] == 0.04 and abs(sig[4] - np.sqrt(2) * 0.04) < 1e-15 and sig[0] == 0.00071 and h == 1.0
+    d, h, n, sig = sim.sweep_step("point_position", 30, 100, raw, 1.0, [0, 0, 1], None)
+    np.testing.assert_allclose(d[:, 0], raw[:, 0] - raw[:, 0].mean() * 1.27 + 0.3)       # the block's own precedence (:443) and shift (:451)
+    d, h, n, sig = sim.sweep_step("height", 99, 100, raw, 1.0, [0, 0, 1], None)
+    assert abs(h - 7.85) < 1e-12
+    d, h, n, sig = sim.sweep_step("orientation", 50, 100, raw, 1.0, [0, 0, 1], None)
+    np.testing.assert_allclose(n, [1.0, 0.0, 0.0], atol=1e-15)
+    for axis, i in (("distance_error", 60), ("translation_error", 60), ("ang_vel_error", 60), ("normal_error", 60)):
+        sig = sim.sweep_step(axis, i, 100, raw, 1.0, [0, 0, 1], None)[3]
+        assert sig[{"distance_error": 2, "translation_error": 1, "ang_vel_error": 0, "normal_error": 5}[axis]] == 0.06
+    rng = np.random.default_rng(4)
+    v, om, t = np.array([1.0, 1, 1]), np.array([1.0, 1, 1]), np.array([0.02, 0, 0.205])
+    for axis, i in (("flow_errors", 70), ("point_position", 50)):
+        saved = g[sim.SWEEP_AXES[axis][0]]
+        mean_s, std_s = saved[:300].reshape(100, 3)[i], saved[300:].reshape(100, 3)[i]
+        d, h, n, sig = sim.sweep_step(axis, i, 100, raw, 1.0, [0, 0, 1], None)
+        tf = eo.generate_test_data(d, v, om, h, n, t)
+        T = 150
+        vo, _, _ = eo.of_simulation(v, om, h, n, t, d, tf, sig, rng.standard_normal((T, 10 + 4 * len(d))), T)
+        assert np.all(np.abs(vo.mean(0) - mean_s) < 4 * std_s / 10 + 4 * vo.std(0) / np.sqrt(T)), (axis, vo.mean(0), mean_s)
+        assert np.all(np.abs(vo.std(0) / std_s - 1) < 0.4), (axis, vo.std(0), std_s)
