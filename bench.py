@@ -196,6 +196,17 @@ def ingest_inclusive(pipe, prev, nxt, sensors, B, reps=2):
         out["jpeg_decode_on_device"] = {"value": round(B * reps / dt, 1), "unit": "frame-pairs/s",
                                         "bytes_per_pair": int(np.mean([len(a) + len(b) for a, b in zip(jp, jn)])),
                                         "streams": f"{D} distinct 1080p 4:2:0 quality-80 frames per side, repeated"}
+        # the same with the ingest double-buffered (FlowPipeline.run_jpeg_batches): a helper thread parses, stages and uploads batch
+        # k + 1 while the GPU decodes batch k and runs its pairs
+        nb = 10                                                  # enough batches for the steady state (the first one stages unhidden)
+        pipe.run_jpeg_batches([(jp, jn)], sensors); pipe.sync()
+        t0 = time.perf_counter()
+        pipe.run_jpeg_batches([(jp, jn)] * nb, sensors)
+        pipe.sync()
+        dt = time.perf_counter() - t0
+        out["jpeg_double_buffered"] = {"value": round(B * nb / dt, 1), "unit": "frame-pairs/s", "batches": nb,
+                                       "how": "ofk_jpeg_stage of batch k+1 on a helper thread (host parse, pinned staging, H2D on the copy stream) "
+                                              "while ofk_pairs_upload_staged decodes batch k; both frames of a pair in one decoder batch"}
     except Exception as e:
         out["jpeg_decode_on_device"] = {"error": str(e)[:200]}
     return out

@@ -506,13 +506,14 @@ __device__ inline void jchroma8(const uint8_t *__restrict__ pl, int pitch, int c
 }
 
 // eight pixels per thread: 8 bytes of luma in, 24 bytes of BGR out as dwords (bytes when the row pitch is not a dword multiple)
-__global__ __launch_bounds__(256) void k_jpeg_color(jpeg_geom g, const uint8_t *__restrict__ planes, uint8_t *__restrict__ bgr, size_t bgr_stride)
+__global__ __launch_bounds__(256) void k_jpeg_color(jpeg_geom g, const uint8_t *__restrict__ planes, uint8_t *__restrict__ bgr, uint8_t *__restrict__ bgr2, int split,
+                                                    size_t bgr_stride)
 {
     const int b = blockIdx.z;
     const int x0 = (blockIdx.x * 64 + threadIdx.x) * 8, y = blockIdx.y * 4 + threadIdx.y;
     if (x0 >= g.w || y >= g.h) return;
     const uint8_t *pl = planes + (size_t)b * g.plane_stride;
-    uint8_t *o = bgr + (size_t)b * bgr_stride + ((size_t)y * g.w + x0) * 3;
+    uint8_t *o = (b < split ? bgr + (size_t)b * bgr_stride : bgr2 + (size_t)(b - split) * bgr_stride) + ((size_t)y * g.w + x0) * 3;   // pairs: previous frames | next frames
     const uint2 y8 = *(const uint2 *)(pl + g.plane_off[0] + (size_t)y * g.pw[0] + x0);              // pw is a multiple of 8
     uint8_t px[24];
     if (g.ncomp == 1) {
@@ -691,13 +692,80 @@ extern "C" int ofk_jpeg_info(const uint8_t *jpeg, size_t nbytes, int *h, int *w,
 }
 
 static size_t jup(size_t v, size_t a) { return (v + a - 1) / a * a; }
+#define TRY_J(expr) do { int rc_ = (expr); if (rc_ != OFK_OK) return rc_; } while (0)
 
-// Decodes `batch` streams of one geometry into dst (device, [batch][dst_stride] BGR8), or, with dst == NULL, into the context's
-// scratch (*out / *out_stride tell where).  Synchronous on the context's stream.
-int ofk_jpeg_decode_device(ofk_ctx *c, const uint8_t *const *jpeg, const size_t *nbytes, int batch, uint8_t *dst, size_t dst_stride,
-                           size_t dst_capacity_px, int *h_out, int *w_out, uint8_t **out, size_t *out_stride)
+// ---- two-phase ingest.  Phase 1 (jstage_fill, host + copy engine): marker parse, tables and entropy segments into a pinned
+// staging slot, one asynchronous H2D copy on the context's copy stream.  Phase 2 (jdecode_staged, device): the decoder passes on
+// the context's stream, behind the copy.  Two slots: a caller thread stages batch k + 1 (ofk_jpeg_stage) while the main thread is
+// inside the decode of batch k (ofk_pairs_upload_staged) - host parse, staging copy and PCIe transfer then hide behind the GPU's work.
+struct jstage {
+    void *host; size_t host_bytes;          // pinned
+    void *dev; size_t dev_bytes;            // device copy of the slot
+    size_t stage_bytes, tab_bytes;
+    jpeg_geom g;
+    int batch, nch_max, valid;
+    hipEvent_t copied;                      // H2D of this slot complete
+};
+struct jstages {
+    jstage slot[2]; hipStream_t copy;
+    int *hmap, *hmap_dev; size_t hmap_ints;   // host memory the device writes its convergence flags / end-of-stream records into (pinned,
+                                              // mapped): the host reads them after a stream wait, no copy engine in the round trip - a D2H
+                                              // copy queues behind the other slot's 200 MB H2D transfer and stalls the decoder for its length
+};
+
+__global__ void k_jpeg_ints_to_host(const int *__restrict__ src, int *__restrict__ dst, int n)
 {
-    if (!jpeg || !nbytes || batch < 1) return ofk_fail(c, OFK_E_INVALID, "ofk_jpeg: bad argument");
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+static int jhmap(ofk_ctx *c, jstages *js, size_t ints)
+{
+    if (js->hmap_ints >= ints) return OFK_OK;
+    if (js->hmap) { hipHostFree(js->hmap); js->hmap = nullptr; js->hmap_ints = 0; }
+    ints = (ints + 4095) / 4096 * 4096;
+    OFK_HIP(c, hipHostMalloc((void **)&js->hmap, ints * 4, hipHostMallocMapped));
+    OFK_HIP(c, hipHostGetDevicePointer((void **)&js->hmap_dev, js->hmap, 0));
+    js->hmap_ints = ints;
+    return OFK_OK;
+}
+
+static jstages *jstages_of(ofk_ctx *c)
+{
+    if (!c->jstage) {
+        jstages *js = (jstages *)calloc(1, sizeof(jstages));
+        if (!js) return nullptr;
+        if (hipStreamCreateWithFlags(&js->copy, hipStreamNonBlocking) != hipSuccess) { free(js); return nullptr; }
+        for (int k = 0; k < 2; ++k)
+            if (hipEventCreateWithFlags(&js->slot[k].copied, hipEventDisableTiming) != hipSuccess) { free(js); return nullptr; }
+        c->jstage = js;
+    }
+    return (jstages *)c->jstage;
+}
+
+void ofk_jpeg_release(ofk_ctx *c)
+{
+    jstages *js = (jstages *)c->jstage;
+    if (!js) return;
+    for (int k = 0; k < 2; ++k) {
+        if (js->slot[k].host) hipHostFree(js->slot[k].host);
+        if (js->slot[k].dev) hipFree(js->slot[k].dev);
+        if (js->slot[k].copied) hipEventDestroy(js->slot[k].copied);
+    }
+    if (js->copy) hipStreamDestroy(js->copy);
+    if (js->hmap) hipHostFree(js->hmap);
+    free(js);
+    c->jstage = nullptr;
+}
+
+// Phase 1.  Touches only the slot, the copy stream and the host: safe to call from a second thread while the context's owner is
+// inside a decode of the OTHER slot.
+static int jstage_fill(ofk_ctx *c, int slot, const uint8_t *const *jpeg, const size_t *nbytes, int batch)
+{
+    if (!jpeg || !nbytes || batch < 1 || slot < 0 || slot > 1) return ofk_fail(c, OFK_E_INVALID, "ofk_jpeg: bad argument");
+    jstages *js = jstages_of(c);
+    if (!js) return ofk_fail(c, OFK_E_HIP, "ofk_jpeg: staging set-up failed");
+    jstage &J = js->slot[slot];
+    J.valid = 0;
     jhost *jh = (jhost *)malloc(sizeof(jhost) * (size_t)batch);
     if (!jh) return ofk_fail(c, OFK_E_INVALID, "ofk_jpeg: out of host memory");
     size_t ent_total = 0;
@@ -720,17 +788,22 @@ int ofk_jpeg_decode_device(ofk_ctx *c, const uint8_t *const *jpeg, const size_t 
         const int nch = (int)((jh[b].ent_len + JB0) / (size_t)g.jch) + 1;
         if (nch > nch_max) nch_max = nch;
     }
-    if (dst && (size_t)g.w * g.h > dst_capacity_px) { const int rc = ofk_fail(c, OFK_E_INVALID, "ofk_jpeg: %dx%d frames exceed the destination", g.w, g.h); free(jh); return rc; }
     // pinned staging: tables + entropy segments, one H2D copy
     const size_t tab_bytes = jup(sizeof(jpeg_tab) * (size_t)batch, 256);
     const size_t stage = tab_bytes + ent_total;
-    if (c->hstage_bytes < stage) {
-        if (c->hstage) { hipHostFree(c->hstage); c->hstage = nullptr; c->hstage_bytes = 0; }
-        if (hipHostMalloc(&c->hstage, jup(stage, 1 << 20), hipHostMallocDefault) != hipSuccess) { free(jh); return ofk_fail(c, OFK_E_HIP, "ofk_jpeg: pinned staging allocation failed"); }
-        c->hstage_bytes = jup(stage, 1 << 20);
+    if (J.copied) (void)hipEventSynchronize(J.copied);           // the slot's previous transfer has left the pinned buffer
+    if (J.host_bytes < stage) {
+        if (J.host) { hipHostFree(J.host); J.host = nullptr; J.host_bytes = 0; }
+        if (hipHostMalloc(&J.host, jup(stage, 1 << 20), hipHostMallocDefault) != hipSuccess) { free(jh); return ofk_fail(c, OFK_E_HIP, "ofk_jpeg: pinned staging allocation failed"); }
+        J.host_bytes = jup(stage, 1 << 20);
     }
-    jpeg_tab *ht = (jpeg_tab *)c->hstage;
-    uint8_t *hent = (uint8_t *)c->hstage + tab_bytes;
+    if (J.dev_bytes < stage) {
+        if (J.dev) { hipFree(J.dev); J.dev = nullptr; J.dev_bytes = 0; }
+        if (hipMalloc(&J.dev, jup(stage, 1 << 20)) != hipSuccess) { free(jh); return ofk_fail(c, OFK_E_HIP, "ofk_jpeg: device staging allocation failed"); }
+        J.dev_bytes = jup(stage, 1 << 20);
+    }
+    jpeg_tab *ht = (jpeg_tab *)J.host;
+    uint8_t *hent = (uint8_t *)J.host + tab_bytes;
     // tables and entropy segments into the staging buffer: a plain copy of ~0.4 MB per 1080p frame, spread over a few host threads
     // (one thread moves ~10 GB/s, which would make this copy the slowest stage of the ingest)
     size_t *eoff = (size_t *)malloc(sizeof(size_t) * (size_t)batch);
@@ -765,11 +838,29 @@ int ofk_jpeg_decode_device(ofk_ctx *c, const uint8_t *const *jpeg, const size_t 
     }
     free(eoff);
     free(jh);
+    OFK_HIP(c, hipMemcpyAsync(J.dev, J.host, stage, hipMemcpyHostToDevice, js->copy));
+    OFK_HIP(c, hipEventRecord(J.copied, js->copy));
+    J.stage_bytes = stage; J.tab_bytes = tab_bytes; J.g = g; J.batch = batch; J.nch_max = nch_max; J.valid = 1;
+    return OFK_OK;
+}
+
+// Phase 2: the staged streams [0, split) go to dst ([.][dst_stride] BGR8), the streams [split, batch) to dst2 (split >= batch: all
+// to dst); with dst == NULL into the context's scratch (*out / *out_stride tell where).  Synchronous on the context's stream.
+static int jdecode_staged(ofk_ctx *c, int slot, uint8_t *dst, uint8_t *dst2, int split, size_t dst_stride, size_t dst_capacity_px,
+                          int *h_out, int *w_out, uint8_t **out, size_t *out_stride)
+{
+    jstages *js = (jstages *)c->jstage;
+    if (!js || slot < 0 || slot > 1 || !js->slot[slot].valid) return ofk_fail(c, OFK_E_INVALID, "ofk_jpeg: slot %d holds no staged streams (ofk_jpeg_stage)", slot);
+    jstage &J = js->slot[slot];
+    J.valid = 0;                                                 // a slot is decoded once
+    const jpeg_geom g = J.g;
+    const int batch = J.batch, nch_max = J.nch_max;
+    if (dst && (size_t)g.w * g.h > dst_capacity_px) return ofk_fail(c, OFK_E_INVALID, "ofk_jpeg: %dx%d frames exceed the destination", g.w, g.h);
     // device scratch
     const size_t B = (size_t)batch;
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += jup(bytes, 256); return o; };
-    const size_t o_stage = take(stage), o_state = take(B * nch_max * 8), o_used = take(B * nch_max * 8), o_count = take(B * nch_max * 4),
+    const size_t o_state = take(B * nch_max * 8), o_used = take(B * nch_max * 8), o_count = take(B * nch_max * 4),
                  o_base = take(B * (nch_max + 1) * 4), o_flags = take(JMAX_ITERS * 4 + B * 8), o_coef = take(B * g.nblk * 130),
                  o_planes = take(B * g.plane_stride);
     const size_t own_stride = jup((size_t)g.w * g.h * 3, 256);
@@ -777,34 +868,37 @@ int ofk_jpeg_decode_device(ofk_ctx *c, const uint8_t *const *jpeg, const size_t 
     const int rc = ofk_need_scratch(c, off);
     if (rc != OFK_OK) return rc;
     char *S = (char *)c->scratch;
-    if (!dst) { dst = (uint8_t *)(S + o_out); dst_stride = own_stride; }
+    if (!dst) { dst = (uint8_t *)(S + o_out); dst_stride = own_stride; dst2 = nullptr; split = batch; }
+    if (!dst2 || split >= batch) { dst2 = dst; split = batch; }
     if (out) *out = dst;
     if (out_stride) *out_stride = dst_stride;
-    const jpeg_tab *dt = (const jpeg_tab *)(S + o_stage);
-    const uint8_t *dent = (const uint8_t *)(S + o_stage + tab_bytes);
+    const jpeg_tab *dt = (const jpeg_tab *)J.dev;
+    const uint8_t *dent = (const uint8_t *)J.dev + J.tab_bytes;
     unsigned long long *state = (unsigned long long *)(S + o_state), *used = (unsigned long long *)(S + o_used);
     int *count = (int *)(S + o_count), *base = (int *)(S + o_base), *flags = (int *)(S + o_flags), *endinfo = flags + JMAX_ITERS;
     int16_t *coef = (int16_t *)(S + o_coef), *dcarr = coef + B * g.nblk * 64;     // coefficient blocks, then the dense DC array
     uint8_t *planes = (uint8_t *)(S + o_planes);
     hipStream_t st = c->stream;
-    OFK_HIP(c, hipMemcpyAsync(S + o_stage, c->hstage, stage, hipMemcpyHostToDevice, st));
     OFK_HIP(c, hipMemsetAsync(flags, 0, JMAX_ITERS * 4 + B * 8, st));
     OFK_HIP(c, hipMemsetAsync(coef, 0, B * g.nblk * 130, st));
+    OFK_HIP(c, hipStreamWaitEvent(st, J.copied, 0));             // tables and entropy data are on the device from here on
     const dim3 dgrid((nch_max + JTPB - 1) / JTPB, batch);
-    int hflags[JMAX_ITERS];
+    TRY_J(jhmap(c, js, JMAX_ITERS + 2 * B));
+    volatile int *hflags = js->hmap;
     int iter = 0;
     hipLaunchKernelGGL(k_jpeg_sync, dgrid, dim3(JTPB), 0, st, dt, dent, g, nch_max, state, used, count, iter, flags);
     bool converged = nch_max == 1;
     while (!converged) {
         const int first = iter + 1;
-        const int burst = iter == 0 ? 3 : 4;                      // two iterations settle most chunks, later ones the stragglers; an iteration
-                                                                  // past the fixed point costs ~10 us (its workgroups leave at once), a host round trip more
+        // Two iterations settle most chunks, the stragglers take five to eleven (1080p, quality 80); an iteration past the fixed
+        // point costs ~10 us (its workgroups leave at once), a host round trip far more: seven iterations go out before the first look.
+        const int burst = iter == 0 ? 7 : 4;
         for (int k = 0; k < burst; ++k) {
             ++iter;
             if (iter >= JMAX_ITERS) OFK_HIP(c, hipMemsetAsync(flags + JMAX_ITERS - 1, 0, 4, st));
             hipLaunchKernelGGL(k_jpeg_sync, dgrid, dim3(JTPB), 0, st, dt, dent, g, nch_max, state, used, count, iter, flags);
         }
-        OFK_HIP(c, hipMemcpyAsync(hflags, flags, sizeof hflags, hipMemcpyDeviceToHost, st));
+        hipLaunchKernelGGL(k_jpeg_ints_to_host, dim3(1), dim3(64), 0, st, flags, js->hmap_dev, JMAX_ITERS);
         OFK_HIP(c, hipStreamSynchronize(st));
         for (int k = first; k <= iter; ++k)
             if (!hflags[k < JMAX_ITERS ? k : JMAX_ITERS - 1]) converged = true;
@@ -814,17 +908,38 @@ int ofk_jpeg_decode_device(ofk_ctx *c, const uint8_t *const *jpeg, const size_t 
     hipLaunchKernelGGL(k_jpeg_write, dgrid, dim3(JTPB), 0, st, dt, dent, g, nch_max, state, base, coef, dcarr, endinfo);
     hipLaunchKernelGGL(k_jpeg_dc, dim3(batch, g.ncomp), dim3(1024), 0, st, dt, g, dcarr);
     hipLaunchKernelGGL(k_jpeg_idct, dim3((g.nblk + 31) / 32, batch), dim3(256), 0, st, dt, g, coef, dcarr, planes);
-    hipLaunchKernelGGL(k_jpeg_color, dim3((g.w + 511) / 512, (g.h + 3) / 4, batch), dim3(64, 4), 0, st, g, planes, dst, dst_stride);
-    int *hend = (int *)malloc(B * 8);
-    if (!hend) return ofk_fail(c, OFK_E_INVALID, "ofk_jpeg: out of host memory");
-    hipError_t e = hipMemcpyAsync(hend, endinfo, B * 8, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    hipLaunchKernelGGL(k_jpeg_color, dim3((g.w + 511) / 512, (g.h + 3) / 4, batch), dim3(64, 4), 0, st, g, planes, dst, dst2, split, dst_stride);
+    hipLaunchKernelGGL(k_jpeg_ints_to_host, dim3(4), dim3(256), 0, st, endinfo, js->hmap_dev + JMAX_ITERS, 2 * batch);
+    hipError_t e = hipStreamSynchronize(st);
     if (e == hipSuccess) e = hipGetLastError();
-    if (e != hipSuccess) { free(hend); return ofk_fail(c, OFK_E_HIP, "ofk_jpeg: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) return ofk_fail(c, OFK_E_HIP, "ofk_jpeg: %s", hipGetErrorString(e));
+    const volatile int *hend = js->hmap + JMAX_ITERS;
     for (int b = 0; b < batch; ++b)
-        if (!hend[2 * b + 1]) { free(hend); return ofk_fail(c, OFK_E_INVALID, "ofk_jpeg: stream %d: entropy data ends before the last block (truncated or corrupt)", b); }
-    free(hend);
+        if (!hend[2 * b + 1]) return ofk_fail(c, OFK_E_INVALID, "ofk_jpeg: stream %d: entropy data ends before the last block (truncated or corrupt)", b);
     if (h_out) *h_out = g.h;
     if (w_out) *w_out = g.w;
     return OFK_OK;
+}
+
+// Decodes `batch` streams of one geometry into dst (device, [batch][dst_stride] BGR8), or, with dst == NULL, into the context's
+// scratch (*out / *out_stride tell where).  Synchronous on the context's stream.  (Both phases, staging slot 0.)
+int ofk_jpeg_decode_device(ofk_ctx *c, const uint8_t *const *jpeg, const size_t *nbytes, int batch, uint8_t *dst, size_t dst_stride,
+                           size_t dst_capacity_px, int *h_out, int *w_out, uint8_t **out, size_t *out_stride)
+{
+    int rc = jstage_fill(c, 0, jpeg, nbytes, batch);
+    if (rc != OFK_OK) return rc;
+    return jdecode_staged(c, 0, dst, nullptr, batch, dst_stride, dst_capacity_px, h_out, w_out, out, out_stride);
+}
+
+int ofk_jpeg_stage_streams(ofk_ctx *c, int slot, const uint8_t *const *jpeg, const size_t *nbytes, int count) { return jstage_fill(c, slot, jpeg, nbytes, count); }
+
+int ofk_jpeg_decode_staged_pairs(ofk_ctx *c, int slot, uint8_t *dst_prev, uint8_t *dst_next, size_t dst_stride, size_t dst_capacity_px, int *batch_out,
+                                 int *h_out, int *w_out)
+{
+    jstages *js = (jstages *)c->jstage;
+    if (!js || slot < 0 || slot > 1 || !js->slot[slot].valid) return ofk_fail(c, OFK_E_INVALID, "ofk_pairs_upload_staged: slot %d holds no staged streams (ofk_jpeg_stage)", slot);
+    const int count = js->slot[slot].batch;
+    if (count & 1) return ofk_fail(c, OFK_E_INVALID, "ofk_pairs_upload_staged: %d staged streams are not pairs (previous frames first, then the next frames)", count);
+    if (batch_out) *batch_out = count / 2;
+    return jdecode_staged(c, slot, dst_prev, dst_next, count / 2, dst_stride, dst_capacity_px, h_out, w_out, nullptr, nullptr);
 }

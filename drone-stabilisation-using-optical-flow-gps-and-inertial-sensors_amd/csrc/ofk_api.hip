@@ -197,6 +197,7 @@ extern "C" int ofk_destroy(ofk_ctx *c)
                     c->imu_state, c->imu_dv, c->kf_mats, c->kf_x, c->kf_P, c->fused, c->imu_msgs, c->imu_counts};
     for (void *p : ptrs) if (p) hipFree(p);
     if (c->hstage) hipHostFree(c->hstage);
+    ofk_jpeg_release(c);
     if (c->ev) { for (int i = 0; i < c->ev_cap; ++i) if (c->ev[i]) hipEventDestroy(c->ev[i]); free(c->ev); }
     free(c->ev_stage);
     free(c->h_counts);
@@ -819,15 +820,38 @@ extern "C" int ofk_pairs_upload_jpeg(ofk_ctx *c, const uint8_t *const *prev_jpeg
                                      const size_t *next_bytes, int batch)
 {
     if (!c) return OFK_E_INVALID;
-    if (hipSetDevice(c->device) != hipSuccess) return ofk_fail(c, OFK_E_HIP, "hipSetDevice failed");
+    if (!prev_jpeg || !prev_bytes || !next_jpeg || !next_bytes) return ofk_fail(c, OFK_E_INVALID, "ofk_pairs_upload_jpeg: NULL argument");
     if (batch < 1 || batch > c->max_batch) return ofk_fail(c, OFK_E_INVALID, "ofk_pairs_upload_jpeg: batch %d exceeds the context (%d)", batch, c->max_batch);
+    // both frames of every pair in ONE decoder batch (previous frames first): half the launches and host round trips of two batches
+    const uint8_t **all = (const uint8_t **)malloc(sizeof(void *) * 2 * (size_t)batch);
+    size_t *len = (size_t *)malloc(sizeof(size_t) * 2 * (size_t)batch);
+    if (!all || !len) { free(all); free(len); return ofk_fail(c, OFK_E_INVALID, "out of host memory"); }
+    for (int b = 0; b < batch; ++b) { all[b] = prev_jpeg[b]; len[b] = prev_bytes[b]; all[batch + b] = next_jpeg[b]; len[batch + b] = next_bytes[b]; }
+    int rc = ofk_jpeg_stage(c, 0, all, len, 2 * batch);
+    free(all); free(len);
+    if (rc != OFK_OK) return rc;
+    return ofk_pairs_upload_staged(c, 0);
+}
+
+// Phase 1 of the compressed ingest, callable from a second thread while the context's owner decodes the other slot (include/ofk.h).
+extern "C" int ofk_jpeg_stage(ofk_ctx *c, int slot, const uint8_t *const *jpeg, const size_t *nbytes, int count)
+{
+    if (!c) return OFK_E_INVALID;
+    if (hipSetDevice(c->device) != hipSuccess) return ofk_fail(c, OFK_E_HIP, "hipSetDevice failed");
+    return ofk_jpeg_stage_streams(c, slot, jpeg, nbytes, count);
+}
+
+// Phase 2: the 2 B streams staged in `slot` (B previous frames, then B next frames) decoded into the resident frame-pair buffers.
+extern "C" int ofk_pairs_upload_staged(ofk_ctx *c, int slot)
+{
+    if (!c) return OFK_E_INVALID;
+    if (hipSetDevice(c->device) != hipSuccess) return ofk_fail(c, OFK_E_HIP, "hipSetDevice failed");
     TRY(join_slices(c));
-    int h0 = 0, w0 = 0, h1 = 0, w1 = 0;
+    int h = 0, w = 0, batch = 0;
     c->cur_batch = 0;
-    TRY(ofk_jpeg_decode_device(c, prev_jpeg, prev_bytes, batch, c->bgr[0], c->bgr_stride, c->P, &h0, &w0, nullptr, nullptr));
-    TRY(ofk_jpeg_decode_device(c, next_jpeg, next_bytes, batch, c->bgr[1], c->bgr_stride, c->P, &h1, &w1, nullptr, nullptr));
-    if (h0 != h1 || w0 != w1) return ofk_fail(c, OFK_E_INVALID, "ofk_pairs_upload_jpeg: previous frames are %dx%d, next frames %dx%d", w0, h0, w1, h1);
-    c->cur_batch = batch; c->cur_h = h0; c->cur_w = w0;
+    TRY(ofk_jpeg_decode_staged_pairs(c, slot, c->bgr[0], c->bgr[1], c->bgr_stride, c->P, &batch, &h, &w));
+    if (batch > c->max_batch) return ofk_fail(c, OFK_E_INVALID, "ofk_pairs_upload_staged: %d pairs exceed the context (%d)", batch, c->max_batch);
+    c->cur_batch = batch; c->cur_h = h; c->cur_w = w;
     return OFK_OK;
 }
 

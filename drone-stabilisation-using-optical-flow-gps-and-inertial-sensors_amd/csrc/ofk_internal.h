@@ -71,6 +71,7 @@ struct ofk_ctx {
     int *dev_flags;                 // [4]                        device-side error flags (bit 0: candidate overflow)
     void *scratch; size_t scratch_bytes;          // device scratch for the estimation entry points
     void *hstage; size_t hstage_bytes;            // pinned host staging
+    void *jstage;                                 // JPEG staging slots + copy stream (k_jpeg.hip), NULL until the first compressed frame
 
     // per-stream filters resident on the device (ofk_imu_*, ofk_filter_*, ofk_stream_step_fused); lazily allocated
     double *imu_state, *imu_dv;     // [B][OFK_IMU_STATE], [B][3]
@@ -101,6 +102,10 @@ int ofk_join_slices(ofk_ctx *ctx);
 int ofk_prepare_streams(ofk_ctx *ctx);                                 // create the slice / auxiliary streams of the current schedule
 int ofk_export_records_stream(ofk_ctx *c, float *device_dst, int batch, hipStream_t *stream_out);   // k_records_f32 on the stream that ends the step
                                    // before touching the context's stream / shared buffers
+void ofk_jpeg_release(ofk_ctx *c);
+int ofk_jpeg_stage_streams(ofk_ctx *c, int slot, const uint8_t *const *jpeg, const size_t *nbytes, int count);
+int ofk_jpeg_decode_staged_pairs(ofk_ctx *c, int slot, uint8_t *dst_prev, uint8_t *dst_next, size_t dst_stride, size_t dst_capacity_px, int *batch_out,
+                                 int *h_out, int *w_out);
 int ofk_jpeg_decode_device(ofk_ctx *c, const uint8_t *const *jpeg, const size_t *nbytes, int batch, uint8_t *dst, size_t dst_stride,
                            size_t dst_capacity_px, int *h_out, int *w_out, uint8_t **out, size_t *out_stride);   // k_jpeg.hip
 

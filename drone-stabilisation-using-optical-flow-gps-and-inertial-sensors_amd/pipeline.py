@@ -222,6 +222,33 @@ class FlowPipeline:
         self.ctx.pairs_upload_jpeg(prev_streams, next_streams)
         self.ctx.pairs_set_sensors(sensors)
 
+    def run_jpeg_batches(self, batches, sensors, on_step=None):
+        """The pipeline over an iterable of (prev_streams, next_streams) batches with the ingest double-buffered: a helper thread
+        parses, stages and uploads batch k + 1 (ofk_jpeg_stage, slot (k + 1) & 1) while this thread decodes batch k on the device
+        (ofk_pairs_upload_staged) and queues its ofk_pairs_run.  `sensors`: one [B, 28] array for all batches or a callable
+        k -> array.  on_step(k) is called after step k was queued (e.g. to pick up step k - 1's records).  Returns the number of steps;
+        the last one is still running (call sync() / run-download)."""
+        from concurrent.futures import ThreadPoolExecutor
+        it = iter(batches)
+        first = next(it, None)
+        if first is None:
+            return 0
+        n = 0
+        with ThreadPoolExecutor(1) as ex:
+            fut = ex.submit(self.ctx.jpeg_stage, 0, list(first[0]) + list(first[1]))
+            while fut is not None:
+                staged = fut.result()
+                nxt = next(it, None)
+                fut = ex.submit(self.ctx.jpeg_stage, (n + 1) & 1, list(nxt[0]) + list(nxt[1])) if nxt is not None else None
+                self.ctx.pairs_upload_staged(n & 1, staged)
+                if callable(sensors) or n == 0:
+                    self.ctx.pairs_set_sensors(sensors(n) if callable(sensors) else sensors)
+                self.run_async()
+                if on_step is not None:
+                    on_step(n)
+                n += 1
+        return n
+
     def run_async(self):
         self.ctx.pairs_run(self._params)
 

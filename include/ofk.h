@@ -229,6 +229,19 @@ int ofk_pairs_upload(ofk_ctx *ctx, const uint8_t *prev_bgr, const uint8_t *next_
  * into the resident buffers; pixels identical to libjpeg's default decompressor (see ofk_jpeg_decode_bgr8). */
 int ofk_pairs_upload_jpeg(ofk_ctx *ctx, const uint8_t *const *prev_jpeg, const size_t *prev_bytes, const uint8_t *const *next_jpeg,
                           const size_t *next_bytes, int batch);
+/* The same in two phases, so that a camera loop can hide the host's share of the ingest (marker parse, staging copy, PCIe) behind
+ * the GPU's work on the batch before:
+ *   ofk_jpeg_stage(ctx, slot, jpeg, nbytes, count)   host + copy engine: parses `count` streams, packs tables and entropy segments
+ *       into pinned staging slot 0 or 1 and queues ONE asynchronous H2D copy on the context's copy stream; returns when the host
+ *       part is done.  It touches nothing but its slot, so it may run on a SECOND THREAD while the context's owner is inside any
+ *       other entry point - as long as that is not the decode of the same slot.
+ *   ofk_pairs_upload_staged(ctx, slot)               device: decodes the 2 B streams staged in `slot` - the B previous frames
+ *       first, then the B next frames - into the resident frame-pair buffers (what ofk_pairs_upload_jpeg does after staging
+ *       slot 0 itself).  A slot is decoded once.
+ * Loop: stage(0, batch 0); for k: { stage(k+1 & 1, batch k+1) on the helper thread; upload_staged(k & 1); ofk_pairs_run; }.
+ * pipeline.FlowPipeline.run_jpeg_batches does exactly that; bench.py reports its rate as ingest_inclusive.jpeg_double_buffered. */
+int ofk_jpeg_stage(ofk_ctx *ctx, int slot, const uint8_t *const *jpeg, const size_t *nbytes, int count);
+int ofk_pairs_upload_staged(ofk_ctx *ctx, int slot);
 int ofk_pairs_set_sensors(ofk_ctx *ctx, const double *sensors, int batch);
 /* Runs gray -> pyramids -> corners -> LK -> centre/scale -> (feasibility) -> solve -> post-solve for every resident
  * pair.  Asynchronous on the context's stream; call ofk_sync / ofk_pairs_download to wait. */

@@ -149,3 +149,39 @@ def test_pairs_upload_jpeg_feeds_the_pipeline(pkg, ofk):
         assert np.array_equal(out[k], ref[k]), k
     assert int(out["counts"].min()) > 20
     pipe.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("streams_per_gpu", [1, 2])
+def test_double_buffered_ingest_matches_the_one_shot_path(pkg, ofk, streams_per_gpu):
+    """FlowPipeline.run_jpeg_batches (a helper thread stages batch k + 1 - marker parse, pinned staging, asynchronous H2D on the copy
+    stream - while the main thread decodes batch k and queues its pairs run) returns, batch for batch, what upload_jpeg + run return;
+    four batches through the two staging slots, the last one smaller than the others, with one and two free-running slices."""
+    from of_amd import synth
+    from of_amd.pipeline import FlowPipeline, PipelineConfig
+    h, w = 480, 640
+    sizes = [3, 3, 3, 2]
+    pairs = [[synth.render_pair(h, w, 60 + 10 * k + b) for b in range(n)] for k, n in enumerate(sizes)]
+    batches = [([_encode(p["prev"], 88, 2) for p in ps], [_encode(p["next"], 88, 2) for p in ps]) for ps in pairs]
+    p0 = pairs[0][0]
+    cfg = PipelineConfig(max_corners=120, quality=0.03, min_distance=7)
+    pipe = FlowPipeline(w, h, 3, cfg, streams=streams_per_gpu)
+    sens = lambda k: ofk.make_sensors(sizes[k], scaling=p0["scaling"], cx=p0["cx"], cy=p0["cy"], omega=(0.001 * k, 0, 0))
+    want = []
+    for k, (sp, sn) in enumerate(batches):
+        pipe.upload_jpeg(sp, sn, sens(k))
+        want.append(pipe.run())
+    got = []
+    n = pipe.run_jpeg_batches(batches, sens, on_step=lambda k: got.append(pipe.ctx.pairs_download()))
+    assert n == 4 and len(got) == 4
+    for k in range(4):
+        for key in ("counts", "prev_pts", "next_pts", "status", "records"):
+            assert np.array_equal(got[k][key], want[k][key]), (k, key)
+        assert got[k]["records"].shape[0] == sizes[k] and int(got[k]["counts"].min()) > 20
+    # a slot is decoded once; staging an odd number of streams is not a batch of pairs
+    with pytest.raises(ofk.OfkError):
+        pipe.ctx.pairs_upload_staged(0, (6, h, w))
+    st = pipe.ctx.jpeg_stage(1, batches[0][0])
+    with pytest.raises(ofk.OfkError):
+        pipe.ctx.pairs_upload_staged(1, st)
+    pipe.close()
