@@ -1125,7 +1125,7 @@ __global__ __launch_bounds__(256) void k_select_prep(unsigned long long *__restr
     unsigned long long *cand = cand_all + (size_t)b * cand_cap;
     if (nseg > 0) {
         const unsigned long long *sbase = seg + (size_t)b * nseg * seg_cap;
-        for (int sg = g; sg < nseg; sg += SEL_G) {
+        for (int sg = g; sg < nseg; sg += (int)gridDim.x) {
             const int n = min(seg_count[(size_t)b * nseg + sg], seg_cap);
             const unsigned long long *sp = sbase + (size_t)sg * seg_cap;
             for (int i0 = 0; i0 < n; i0 += 1024) {                   // uniform trip count per wave: ballots below need every lane
@@ -1157,7 +1157,7 @@ __global__ __launch_bounds__(256) void k_select_prep(unsigned long long *__restr
     } else {
         // the flat list exists already (k_nms, or the LDS-tile response kernel with its running threshold): histogram only
         const int C = min(cand_count[b * OFK_CNT_STRIDE], cand_cap);
-        for (int i0 = g * 1024; i0 < C; i0 += SEL_G * 1024) {
+        for (int i0 = g * 1024; i0 < C; i0 += (int)gridDim.x * 1024) {
             unsigned long long key[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) { const int i = i0 + 256 * q + tid; key[q] = i < C ? cand[i] : ~0ull; }
@@ -1274,7 +1274,7 @@ __global__ __launch_bounds__(SEL_T) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     volatile unsigned short *s_grid = reinterpret_cast<volatile unsigned short *>(sel_smem + 4 * (size_t)tgtA);
     int *s_acc = reinterpret_cast<int *>(sel_smem + 6 * (size_t)tgtA);
     volatile unsigned short *s_next = reinterpret_cast<volatile unsigned short *>(sel_smem + 6 * (size_t)tgtA + 4 * (size_t)max_corners_all);
-    __shared__ unsigned long long s_conf[64];                   // conflict matrix of the current greedy round
+    __shared__ unsigned long long s_conf[128];                  // conflict matrices of the current and the next greedy round
     __shared__ unsigned s_w[NW];
     __shared__ int s_n, s_nacc, s_D, s_cum;
 
@@ -1434,29 +1434,39 @@ __global__ __launch_bounds__(SEL_T) __attribute__((amdgpu_waves_per_eu(8, 8))) v
             grid_ready = true;
         }
         __syncthreads();
-        // ---- greedy over the sorted chunk, 64 candidates per round
-        for (int base = 0; base < n; base += 64) {
+        // ---- greedy over the sorted chunk, 64 candidates per round, software-pipelined over the waves: while wave 0 resolves round r
+        //      (accepted-set test through the grid, acceptance sweeps, stores), the other waves build the 64 x 64 conflict matrix of
+        //      round r + 1 into the other half of s_conf - one workgroup barrier per round, the matrix off wave 0's path
+        auto conflict_rows = [&](int base_, unsigned long long *conf) {
+            // rows of the matrix of the round starting at base_, shared by the waves 1 .. NW-1 (all of it by wave 0 when alone)
+            const int ci_ = base_ + lane;
+            const unsigned xy_ = ci_ < n ? s_idx[ci_] : 0u;
+            const int x_ = (int)(xy_ & 0xffffu), y_ = (int)(xy_ >> 16);
+            const int w0 = NW > 1 ? wave - 1 : 0, nw = NW > 1 ? NW - 1 : 1;
+            for (int j = __builtin_amdgcn_readfirstlane(w0); j < 64; j += nw) {
+                const int jx = __builtin_amdgcn_readlane(x_, j), jy = __builtin_amdgcn_readlane(y_, j);
+                const int dx = x_ - jx, dy = y_ - jy;
+                const unsigned long long bj = __ballot((float)(dx * dx + dy * dy) < md2);
+                if (lane == 0) conf[j] = bj;
+            }
+        };
+        if (use_dist && n > 0 && (NW == 1 || wave > 0)) conflict_rows(0, s_conf);
+        __syncthreads();
+        const float inv_cs = 1.f / (float)cs;                   // floor((c + 0.5) / cs) exactly: |error| <= 2.4e-7 * 16384 / cs < 0.5 / cs
+        int round = 0;
+        for (int base = 0; base < n; base += 64, ++round) {
             const int nacc = s_nacc;
             if (nacc >= max_corners) break;
-            const int ci = base + lane;
-            const bool live = ci < n;
-            const unsigned xy = live ? s_idx[ci] : 0u;
-            const int cx = (int)(xy & 0xffffu), cy = (int)(xy >> 16);
-            if (use_dist) {
-                // every wave builds its share of the round's 64 x 64 conflict matrix
-#pragma unroll
-                for (int q = 0; q < 64 / NW; ++q) {
-                    const int j = __builtin_amdgcn_readfirstlane(wave) * (64 / NW) + q;   // candidate (lane) j of this round
-                    const int jx = __builtin_amdgcn_readlane(cx, j), jy = __builtin_amdgcn_readlane(cy, j);
-                    const int dx = cx - jx, dy = cy - jy;
-                    const unsigned long long bj = __ballot((float)(dx * dx + dy * dy) < md2);
-                    if (lane == 0) s_conf[j] = bj;
-                }
+            if (wave > 0 || NW == 1) {
+                if (use_dist && base + 64 < n) conflict_rows(base + 64, s_conf + 64 * ((round + 1) & 1));
             }
-            __syncthreads();
             if (wave == 0) {
+                const int ci = base + lane;
+                const bool live = ci < n;
+                const unsigned xy = live ? s_idx[ci] : 0u;
+                const int cx = (int)(xy & 0xffffu), cy = (int)(xy >> 16);
                 // the accepted set through the grid: corners closer than minDistance sit in the 3 x 3 cells around the candidate's
-                const int gx = cx / cs, gy = cy / cs;
+                const int gx = (int)(((float)cx + 0.5f) * inv_cs), gy = (int)(((float)cy + 0.5f) * inv_cs);
                 bool rej = false;
                 if (use_dist && live) {
                     unsigned head[9];                           // the nine cell heads first (independent LDS reads), then the short chains
@@ -1478,7 +1488,7 @@ __global__ __launch_bounds__(SEL_T) __attribute__((amdgpu_waves_per_eu(8, 8))) v
                     }
                 }
                 const unsigned long long alive = __ballot(live && !rej);   // survivors of the accepted-set test, best first
-                const unsigned long long myconf = use_dist ? s_conf[lane] : 0ull;   // lanes clashing with candidate `lane`
+                const unsigned long long myconf = use_dist ? s_conf[64 * (round & 1) + lane] : 0ull;   // lanes clashing with candidate `lane`
                 // Greedy acceptance in rank order, a few parallel sweeps instead of one scalar step per candidate: U = candidates not
                 // decided yet, with everything that clashes with an accepted one already removed.  A lane whose earlier clashing
                 // lanes are all decided is accepted in this sweep (the lowest undecided lane always is); the accepted lanes and
@@ -1551,6 +1561,8 @@ void ofk_launch_select(hipStream_t s, unsigned long long *cand, int cand_cap, in
                        unsigned *sel_hist, unsigned long long *sel_keys, bool hist_is_zero)
 {
     if (!hist_is_zero) (void)hipMemsetAsync(sel_hist, 0, (size_t)batch * SEL_HB * sizeof(unsigned), s);
+    // (SEL_G = 16 workgroups per image walk ~4 segments each; one segment per workgroup - 64 per image - was measured: 44 -> 67 us, the
+    //  histogram flush of four times as many workgroups costs more than the shorter chains save)
     hipLaunchKernelGGL(k_select_prep, dim3(SEL_G, batch), dim3(256), 0, s, cand, cand_cap, cand_count, seg, seg_cap, seg_count, nseg, maxbits,
                        quality, sel_hist, limit);
     hipLaunchKernelGGL(k_select_pick, dim3(SEL_G, batch), dim3(256), 0, s, cand, cand_cap, cand_count, maxbits, quality, sel_hist, limit,
