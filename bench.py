@@ -18,8 +18,12 @@ node-local file, of_amd/sharding.py), hipDeviceSynchronize through the library s
 The gather of step k is queued on the library's own stream right behind step k's solve (stream-ordered, no host wait), so
 step k+1 is launched while it travels; K steps issue K gathers inside the timed region.
 
-Schedule (default): the batch runs as two free-running slices (--streams 2): each slice has its own stage chain
-and auxiliary stream, the slices are offset by one response kernel and are not joined between steps.
+Schedule (default): one stage chain (response -> selection -> LK -> solve) on the context's stream, the HBM-bound gray
+conversions and pyramids of the NEXT step on an auxiliary stream beside it, B = 512 pairs per step.  Round 3
+measured this against the two free-running slices of rounds 1-2 (--streams 2 --batch 256): since the selection and the solve run
+in wave-sized workgroups that fit beside the response kernel, one slice with the larger batch is 3-6 % faster (126.5 k against
+119.5-122 k pairs/s on the same box, profiles/r03_batch_streams_sweep.txt) and needs neither a second communicator nor more
+hardware queues.
 
 The JSON line also carries
   roofline     : the dominant kernel = the longest stage of the step's critical chain (response -> select -> LK -> solve).
@@ -244,8 +248,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="frame pairs per GPU per step")
-    ap.add_argument("--streams", type=int, default=2, help="free-running slices of the batch (HIP streams) per GPU")
+    ap.add_argument("--batch", type=int, default=512, help="frame pairs per GPU per step (512 resident 1080p pairs = 14 GB of the 288 GB)")
+    ap.add_argument("--streams", type=int, default=1, help="free-running slices of the batch (HIP streams) per GPU")
     ap.add_argument("--no-overlap", action="store_true", help="run every stage of a step serially on one stream")
     ap.add_argument("--no-isolated", action="store_true", help="skip the serial pass behind the timed region (profiling: the kernel "
                     "trace then holds the timed schedule's launches only)")

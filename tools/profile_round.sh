@@ -5,9 +5,9 @@
 #      -> gpurun_out/<tag>_traffic_pmc.json (tools/make_traffic_json.py); bench.py reads profiles/<tag>_traffic_pmc.json for roofline.traffic
 #   2. SQ counters (SQ_INSTS_VALU ...) of every kernel, two runs  -> gpurun_out/<tag>_valu_pmc.json (tools/make_valu_json.py)
 #   3. rocprofv3 --kernel-trace --stats of the default bench command and of --no-overlap --streams 1 (every kernel alone on the chip)
-#      -> gpurun_out/<tag>_kernel_stats_{slices2,serial}.csv
+#      -> gpurun_out/<tag>_kernel_stats_{overlap,serial}.csv
 #   4. the plain bench line -> gpurun_out/<tag>_bench.json
-TAG=${1:-r03}; BATCH=${2:-256}
+TAG=${1:-r03}; BATCH=${2:-512}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 mkdir -p $O
@@ -35,6 +35,6 @@ rocprofv3 --kernel-trace --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_
 (cd $R && python3 tools/make_valu_json.py gpurun_out/${TAG}_valu_pmc.json $BATCH > gpurun_out/valu_$TAG.log 2>&1) || { tail -5 $O/valu_$TAG.log; exit 1; }
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_overlap -o p -- python3 $R/bench.py --batch $BATCH --steps 10 --warmup 2 $QUIET --no-isolated > $O/prof_${TAG}_overlap.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_serial -o p -- python3 $R/bench.py --batch $BATCH --steps 10 --warmup 2 $QUIET --no-overlap --streams 1 > $O/prof_${TAG}_serial.log 2>&1 || exit 1
-cp $(find $O/prof_${TAG}_overlap -name '*kernel_stats.csv' | head -1) $O/${TAG}_kernel_stats_slices2.csv
+cp $(find $O/prof_${TAG}_overlap -name '*kernel_stats.csv' | head -1) $O/${TAG}_kernel_stats_overlap.csv
 cp $(find $O/prof_${TAG}_serial -name '*kernel_stats.csv' | head -1) $O/${TAG}_kernel_stats_serial.csv
 cd $R && python3 bench.py --batch $BATCH > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err && python3 tools/show_bench.py gpurun_out/${TAG}_bench.json
