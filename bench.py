@@ -203,7 +203,7 @@ def ingest_inclusive(pipe, prev, nxt, sensors, B, reps=2):
         # the same with the ingest double-buffered (FlowPipeline.run_jpeg_batches): a helper thread parses, stages and uploads batch
         # k + 1 while the GPU decodes batch k and runs its pairs
         nb = 10                                                  # enough batches for the steady state (the first one stages unhidden)
-        pipe.run_jpeg_batches([(jp, jn)], sensors); pipe.sync()
+        pipe.run_jpeg_batches([(jp, jn)] * 2, sensors); pipe.sync()        # warm-up: both staging slots allocate their pinned / device buffers
         t0 = time.perf_counter()
         pipe.run_jpeg_batches([(jp, jn)] * nb, sensors)
         pipe.sync()
