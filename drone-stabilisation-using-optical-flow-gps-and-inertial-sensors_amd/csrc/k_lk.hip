@@ -685,7 +685,14 @@ __device__ __forceinline__ void lkq_store_row(unsigned *o, unsigned *dump, int l
     }
 }
 
-__global__ __launch_bounds__(64) void k_lk15q(const uint8_t *__restrict__ prev, const uint8_t *__restrict__ next, size_t pyr_stride,
+// 120 VGPRs (amdgpu_num_vgpr counts register PAIRS of the unified file: 60): four waves per SIMD leave 32 registers, i.e. room for one
+// 32-register gray wave beside them - the compiler's own allocation after the pixel-pair packing is 124, which takes that room away
+#ifdef OFK_LK_NOCAP
+#define OFK_LKQ_ATTR
+#else
+#define OFK_LKQ_ATTR __attribute__((amdgpu_num_vgpr(60)))
+#endif
+__global__ __launch_bounds__(64) OFK_LKQ_ATTR void k_lk15q(const uint8_t *__restrict__ prev, const uint8_t *__restrict__ next, size_t pyr_stride,
                                               ofk_levels lv, const float *__restrict__ prev_pts, const int *__restrict__ counts,
                                               int pts_stride, int max_count, double eps2, float eps2_lo, float eps2_hi,
                                               double min_eig_thr, float *__restrict__ next_pts, uint8_t *__restrict__ status,
@@ -717,7 +724,11 @@ __global__ __launch_bounds__(64) void k_lk15q(const uint8_t *__restrict__ prev, 
 
     int st = 1;
     float errv = 0.f, nx = 0.f, ny = 0.f;
-    unsigned pxy[15];                                              // (Ix, Iy) of the lane's pixels, int16 pairs
+    // Ix and Iy of the lane's 15 window pixels as int16 PAIRS OF NEIGHBOURING PIXELS: pxx[j] = (Ix[2j], Ix[2j+1]), pyy likewise (the last
+    // pair's upper half is zero).  Every sum over the row is then a v_dot2_i32_i16 per pixel pair: the normal matrix (3 per pair where
+    // round 2 spent 3 multiplies + 3 adds per pixel) and the mismatch vector (pack the two interpolated values with one v_lshl_or, two
+    // dot2: 1.5 per pixel where two v_mad_i32_i16 stood) - 7 % fewer instructions per point, sums bit for bit the same integers.
+    unsigned pxx[8], pyy[8];
 
     for (int l = lv.n; l >= 0; --l) {
         const int lh = lv.h[l], lw = lv.w[l];
@@ -847,6 +858,7 @@ __global__ __launch_bounds__(64) void k_lk15q(const uint8_t *__restrict__ prev, 
                     DX[s] &= keep; DY[s] &= keep;
                 }
             }
+            int ixp = 0, iyp = 0;
 #pragma unroll
             for (int k = 0; k < 15; ++k) {
                 const unsigned qx_ = (k & 1) ? __builtin_amdgcn_alignbit(DX[(k + 1) >> 1], DX[k >> 1], 16) : DX[k >> 1];
@@ -856,17 +868,30 @@ __global__ __launch_bounds__(64) void k_lk15q(const uint8_t *__restrict__ prev, 
                 const int hy = lkq_dot2_k(qy_, W0, 1 << 13), gy = lk_dot2(qy_, W1, 0);
                 const int ix = (hx + __builtin_amdgcn_update_dpp(0, gx, 0x101, 0xF, 0xF, true)) >> 14;     // row_shl:1
                 const int iy = (hy + __builtin_amdgcn_update_dpp(0, gy, 0x101, 0xF, 0xF, true)) >> 14;
-                pxy[k] = lev && rowact ? __builtin_amdgcn_perm((unsigned)iy, (unsigned)ix, 0x05040100u) : 0u;
-                a11 += (unsigned)__mul24(ix, ix); a12 += __mul24(ix, iy); a22 += (unsigned)__mul24(iy, iy);
+                if (k & 1) {
+                    pxx[k >> 1] = __builtin_amdgcn_perm((unsigned)ix, (unsigned)ixp, 0x05040100u);
+                    pyy[k >> 1] = __builtin_amdgcn_perm((unsigned)iy, (unsigned)iyp, 0x05040100u);
+                } else if (k == 14) {
+                    pxx[7] = (unsigned)ix & 0xffffu; pyy[7] = (unsigned)iy & 0xffffu;
+                }
+                ixp = ix; iyp = iy;
             }
-            if (!(lev && rowact)) { a11 = 0; a12 = 0; a22 = 0; }
+            if (!(lev && rowact)) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { pxx[j] = 0u; pyy[j] = 0u; }
+            }
+            // |Ix|, |Iy| <= 4080: a lane's 15 squares sum below 2.5e8, so the signed dot products are exact
+            int s11 = 0, s22 = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s11 = lk_dot2(pxx[j], pxx[j], s11); s22 = lk_dot2(pyy[j], pyy[j], s22); a12 = lk_dot2(pxx[j], pyy[j], a12); }
+            a11 = (unsigned)s11; a22 = (unsigned)s22;
         }
         // c = sum(I * Ix), sum(I * Iy) over the lane's row: the constant part of the mismatch sums (pxy is zero on idle lanes)
         I_read();
 #pragma unroll
-        for (int k = 0; k < 15; ++k) {
-            const int iv = tap_value(k, W0, W1);
-            c1 = lkq_mad_lo(iv, pxy[k], c1); c2 = lkq_mad_hi(iv, pxy[k], c2);
+        for (int j = 0; j < 8; ++j) {                            // interpolated values are 13-bit and non-negative: two per register
+            const unsigned ivp = j < 7 ? (unsigned)tap_value(2 * j, W0, W1) | ((unsigned)tap_value(2 * j + 1, W0, W1) << 16) : (unsigned)tap_value(14, W0, W1);
+            c1 = lk_dot2(ivp, pxx[j], c1); c2 = lk_dot2(ivp, pyy[j], c2);
         }
         const unsigned A11u = (unsigned)lkq_row_sum((int)a11), A22u = (unsigned)lkq_row_sum((int)a22);
         float A12 = (float)lkq_row_sum(a12) * 0x1p-20f;
@@ -899,9 +924,9 @@ __global__ __launch_bounds__(64) void k_lk15q(const uint8_t *__restrict__ prev, 
             J_read(iqx, iqy, act);
             int b1 = -c1, b2 = -c2;
 #pragma unroll
-            for (int k = 0; k < 15; ++k) {
-                const int jv = tap_value(k, V0, V1);
-                b1 = lkq_mad_lo(jv, pxy[k], b1); b2 = lkq_mad_hi(jv, pxy[k], b2);
+            for (int j = 0; j < 8; ++j) {
+                const unsigned jvp = j < 7 ? (unsigned)tap_value(2 * j, V0, V1) | ((unsigned)tap_value(2 * j + 1, V0, V1) << 16) : (unsigned)tap_value(14, V0, V1);
+                b1 = lk_dot2(jvp, pxx[j], b1); b2 = lk_dot2(jvp, pyy[j], b2);
             }
             float fb1 = (float)lkq_row_sum(b1) * 0x1p-20f, fb2 = (float)lkq_row_sum(b2) * 0x1p-20f;
             if (__builtin_amdgcn_ballot_w64(act && !safe) != 0) {

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--quality", type=int, default=80)
     ap.add_argument("--h", type=int, default=1080)
     ap.add_argument("--w", type=int, default=1920)
+    ap.add_argument("--chunk", type=int, default=0, help="ofk_set_tuning('jpeg_chunk'): entropy bytes per decoder thread (64, 128, 256; 0 = built-in choice)")
     args = ap.parse_args()
     load_package()
     from of_amd import ofk, synth
@@ -34,6 +35,8 @@ def main():
     from oracle import jpeg_oracle as jo
 
     B, H, W = args.batch, args.h, args.w
+    if args.chunk:
+        ofk.set_tuning("jpeg_chunk", args.chunk)
     distinct = [synth.render_pair(H, W, 900 + k) for k in range(4)]
 
     def enc(img):
