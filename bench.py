@@ -258,6 +258,8 @@ def main():
     ap.add_argument("--comms", type=int, default=1, help="RCCL communicators per rank under a launcher: 1 (default) = one gather per step behind the "
                     "last slice - the plain usage every RCCL build supports; S = --streams: one communicator per slice, every slice gathers its own "
                     "records on its own stream (+0.8 %% at N = 1; two collectives of one rank then run concurrently)")
+    ap.add_argument("--tune", action="append", default=[], metavar="KNOB=VALUE", help="ofk_set_tuning knob for experiments (eig_rows, no_pair, "
+                    "no_pyr3, pyr3_chunks, pyr_rows, jpeg_chunk); results do not depend on them")
     ap.add_argument("--watchdog", type=float, default=90.0, help="seconds the bootstrap + first gathered step may take under a launcher before "
                     "the rank reports what it is waiting for and exits 3 (0 = off)")
     args = ap.parse_args()
@@ -267,6 +269,9 @@ def main():
     import of_amd.ofk as ofk
     from of_amd import synth, sharding
     from of_amd.pipeline import FlowPipeline, PipelineConfig
+    for kv in args.tune:
+        k, v = kv.split("=")
+        ofk.set_tuning(k, int(v))
     rank, world, local = sharding.env_ranks()                   # RANK / WORLD_SIZE / LOCAL_RANK from the launcher; (0, 1, 0) when run plainly
     launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ
     if world != args.gpus and rank == 0:

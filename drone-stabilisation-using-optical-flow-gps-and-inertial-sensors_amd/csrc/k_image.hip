@@ -424,8 +424,10 @@ bool ofk_launch_pyr3(hipStream_t s, uint8_t *pyr0, uint8_t *pyr1, size_t stride,
     int nstrips = 1;
     if (lanes > 64) { nstrips = 2; while (61 * 2 + 58 * (nstrips - 2) < lanes) ++nstrips; }
     const int total = ((h >> 1) + 3 + 3) / 4 * 4;               // steps 0 .. n1 + 2, rounded up to whole groups of four
-    int nchunks = (2048 + images * nstrips - 1) / (images * nstrips);      // >= 2048 waves x 8 KB of loads in flight covers the HBM latency;
-                                                                           // more chunks only add warm-up rows (measured: 2 chunks 71 %, 4 chunks 69 %, 8 chunks 61 % of the HBM roof)
+    // >= 2048 waves x 8 KB of loads in flight cover the HBM latency and more chunks only add warm-up rows ALONE on the chip (B = 256:
+    // 2 chunks 71 %, 4 chunks 69 %, 8 chunks 61 % of the HBM roof) - but beside the response kernel shorter-lived waves find room more
+    // often: B = 512 pairs, 1 / 4 / 8 / 16 chunks -> 123.5-125.4 / 126.8-128.0 / 126.4-127.5 / 124.4 k pairs/s (round 3).  Target 8192 waves.
+    int nchunks = (8192 + images * nstrips - 1) / (images * nstrips);
     const int maxchunks = total / 32 > 1 ? total / 32 : 1;                 // chunks of at least 32 steps (12 warm-up steps each)
     nchunks = nchunks < 1 ? 1 : nchunks > maxchunks ? maxchunks : nchunks;
     if (g_ofk_tuning.pyr3_chunks >= 1 && g_ofk_tuning.pyr3_chunks <= maxchunks) nchunks = g_ofk_tuning.pyr3_chunks;   // ofk_set_tuning("pyr3_chunks")
