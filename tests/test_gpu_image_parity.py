@@ -303,3 +303,35 @@ def test_good_features_plateau_rows_fill_the_key_buffer(gpu_ctx, bs):
     m = bs // 2 + 1
     inner = eig[40 + m:40 + ph - m, 100 + m:100 + pw - m]
     assert inner.shape[0] >= 5 and np.ptp(inner) == 0 and inner[0, 0] > 0.2 * eig.max()    # one plateau, among the strongest responses
+
+
+def test_tuning_knobs_do_not_change_results(gpu_ctx, pkg, ofk):
+    """ofk_set_tuning (include/ofk.h) moves strip lengths and picks between kernels that compute the same thing: corners, pyramid
+    levels and decoded-and-tracked records are bit-identical under every knob (what the header promises)."""
+    from of_amd import synth
+    from of_amd.pipeline import FlowPipeline, PipelineConfig
+    p = synth.render_pair(272, 448, 5)                           # width % 16 == 0, height % 8 == 0: the three-level pyramid pass applies
+    g = io.gray_bgr8(p["prev"])
+    base_pts = gpu_ctx.good_features(g, 120, 0.02, 6, 7)
+    base_pyr = gpu_ctx.pyramid(g, 3)
+    cfg = PipelineConfig(max_corners=80, quality=0.03, min_distance=7, max_level=3)
+    sensors = ofk.make_sensors(2, scaling=p["scaling"], cx=p["cx"], cy=p["cy"])
+    pipe = FlowPipeline(448, 272, 2, cfg)
+    pipe.upload(np.stack([p["prev"]] * 2), np.stack([p["next"]] * 2), sensors)
+    base_out = pipe.run()
+    assert len(base_pts) > 40
+    try:
+        for knob, values in (("no_pair", (1,)), ("eig_rows", (8, 33, 100)), ("no_pyr3", (1,)), ("pyr3_chunks", (1, 3)), ("pyr_rows", (4, 9))):
+            for v in values:
+                ofk.set_tuning(knob, v)
+                assert np.array_equal(gpu_ctx.good_features(g, 120, 0.02, 6, 7), base_pts), (knob, v)
+                for a, b in zip(gpu_ctx.pyramid(g, 3), base_pyr):
+                    assert np.array_equal(a, b), (knob, v)
+                out = pipe.run()
+                for key in ("counts", "prev_pts", "next_pts", "status", "records"):
+                    assert np.array_equal(out[key], base_out[key]), (knob, v, key)
+            ofk.set_tuning(knob, 0)
+    finally:
+        for knob in ("no_pair", "eig_rows", "no_pyr3", "pyr3_chunks", "pyr_rows", "jpeg_chunk"):
+            ofk.set_tuning(knob, 0)
+    pipe.close()

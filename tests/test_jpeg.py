@@ -185,3 +185,22 @@ def test_double_buffered_ingest_matches_the_one_shot_path(pkg, ofk, streams_per_
     with pytest.raises(ofk.OfkError):
         pipe.ctx.pairs_upload_staged(1, st)
     pipe.close()
+
+
+@pytest.mark.gpu
+def test_decoder_chunk_size_does_not_change_pixels(pkg, ofk, gold):
+    """ofk_set_tuning("jpeg_chunk"): 64 / 128 / 256 entropy bytes per decoder thread - other chunk boundaries, other synchronisation
+    histories, the same pixels."""
+    from of_amd import synth
+    streams = [_encode(synth.render_pair(480, 640, 300 + k)["prev"], 85, 2) for k in range(3)]
+    want = [jo.decode(s) for s in streams]
+    ctx = ofk.Context(0, 640, 480, 3, 64, 1)
+    try:
+        for chunk in (64, 128, 256, 0):
+            ofk.set_tuning("jpeg_chunk", chunk)
+            out = ctx.jpeg_decode(streams)
+            for k in range(3):
+                assert np.array_equal(out[k], want[k]), (chunk, k)
+    finally:
+        ofk.set_tuning("jpeg_chunk", 0)
+        ctx.close()
