@@ -1257,14 +1257,18 @@ extern __shared__ __attribute__((aligned(16))) uint8_t sel_smem[];
 // LDS map (bytes, tgtA = sel_tgt(max_corners_all)):  [0, 8 tgtA) sort buffer of the first round | [0, 4 tgtA) sorted indices,
 // sort buffer of later rounds (tgtA / 2 keys), histogram of the cut search | [4 tgtA, 6 tgtA) grid heads u16 | [6 tgtA, + 4 mc)
 // accepted corners x | y << 16 | then mc u16 chain links.  Total max(8 tgtA, 6 tgtA + 6 mc): 9.1 KB at 500 corners.
-__global__ __launch_bounds__(SEL_T) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_select_greedy(const unsigned long long *__restrict__ cand_all, int cand_cap,
+// NT = threads of the workgroup: 256 (the pipeline's: fits beside the response kernel) or 1024 (small batches of many corners - 32 4K
+// pairs with 2000 corners each leave the chip nearly empty, and a bitonic sort of 4096 keys is four times shorter on sixteen waves).
+template <int NT>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 256 ? 8 : 4, 8))) void k_select_greedy(const unsigned long long *__restrict__ cand_all, int cand_cap,
                                                          const int *__restrict__ cand_count, const unsigned int *__restrict__ maxbits,
                                                          double quality, int w, int h, int max_corners_all, float min_distance,
                                                          float *__restrict__ pts, int pts_stride, int *__restrict__ counts,
                                                          const int *__restrict__ limit, const unsigned long long *__restrict__ sel_keys,
                                                          int sel_stride, int tgtA, int cs)
 {
-    constexpr int NW = SEL_T / 64;
+    constexpr int NW = NT / 64;
+    constexpr int NB = NT > SEL_NB ? NT : SEL_NB;               // histogram bins per refinement level of the generic path (>= one per thread)
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int max_corners = limit ? min(max_corners_all, limit[b]) : max_corners_all;
     if (max_corners <= 0) { if (tid == 0) counts[b] = 0; return; }
@@ -1312,7 +1316,7 @@ __global__ __launch_bounds__(SEL_T) __attribute__((amdgpu_waves_per_eu(8, 8))) v
             T = cut < kend ? cut : kend;
             n = nsel;
             const unsigned long long *src = sel_keys + (size_t)b * sel_stride;
-            for (int i = tid; i < n; i += SEL_T) s_key[i] = src[i];
+            for (int i = tid; i < n; i += NT) s_key[i] = src[i];
         } else {
             if (!(a < kend)) break;
             // ---- choose T in (a, kend] so that 1 <= #{a <= key < T} <= cap (or detect that none is left)
@@ -1322,22 +1326,22 @@ __global__ __launch_bounds__(SEL_T) __attribute__((amdgpu_waves_per_eu(8, 8))) v
             bool have_cut = false;
             for (int level = 0; level < 9; ++level) {
                 const unsigned long long width = curB - curA;
-                const int shift = width <= SEL_NB ? 0 : 64 - __clzll((long long)(width - 1)) - 9;
+                const int shift = width <= NB ? 0 : 64 - __clzll((long long)(width - 1)) - (NB == 512 ? 9 : 10);
                 const int nb = (int)((width - 1) >> shift) + 1;
-                for (int i = tid; i < SEL_NB; i += SEL_T) s_hist[i] = 0;
+                for (int i = tid; i < NB; i += NT) s_hist[i] = 0;
                 if (tid == 0) { s_D = 0; s_cum = 0; }
                 __syncthreads();
-                for (int i0 = tid; i0 < C; i0 += 4 * SEL_T) {
+                for (int i0 = tid; i0 < C; i0 += 4 * NT) {
                     unsigned long long key[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { const int i = i0 + q * SEL_T; key[q] = i < C ? cand[i] : ~0ull; }
+                    for (int q = 0; q < 4; ++q) { const int i = i0 + q * NT; key[q] = i < C ? cand[i] : ~0ull; }
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
                         if (key[q] >= curA && key[q] < curB) atomicAdd(&s_hist[(unsigned)((key[q] - curA) >> shift)], 1u);
                 }
                 __syncthreads();
-                // inclusive prefix over the bins (SEL_NB / SEL_T per thread); D = #bins whose inclusive prefix fits the budget
-                constexpr int BPT = SEL_NB / SEL_T;
+                // inclusive prefix over the bins (NB / NT per thread); D = #bins whose inclusive prefix fits the budget
+                constexpr int BPT = NB / NT;
                 unsigned hv[BPT], loc = 0;
 #pragma unroll
                 for (int q = 0; q < BPT; ++q) { hv[q] = s_hist[BPT * tid + q]; loc += hv[q]; }
@@ -1379,10 +1383,10 @@ __global__ __launch_bounds__(SEL_T) __attribute__((amdgpu_waves_per_eu(8, 8))) v
             __syncthreads();
             if (tid == 0) s_n = 0;
             __syncthreads();
-            for (int i0 = tid; i0 < C; i0 += 4 * SEL_T) {
+            for (int i0 = tid; i0 < C; i0 += 4 * NT) {
                 unsigned long long key[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { const int i = i0 + q * SEL_T; key[q] = i < C ? cand[i] : ~0ull; }
+                for (int q = 0; q < 4; ++q) { const int i = i0 + q * NT; key[q] = i < C ? cand[i] : ~0ull; }
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     if (key[q] >= a && key[q] < T) { const int slot = atomicAdd(&s_n, 1); if (slot < cap) s_key[slot] = key[q]; }
@@ -1393,14 +1397,14 @@ __global__ __launch_bounds__(SEL_T) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         fast = false;
         int npad = 64;
         while (npad < n) npad <<= 1;
-        for (int i = n + tid; i < npad; i += SEL_T) s_key[i] = ~0ull;
+        for (int i = n + tid; i < npad; i += NT) s_key[i] = ~0ull;
         __syncthreads();
-        // ---- bitonic sort ascending.  Element i is handled by thread i % SEL_T: for j >= SEL_T both partners of a compare-exchange
+        // ---- bitonic sort ascending.  Element i is handled by thread i % NT: for j >= NT both partners of a compare-exchange
         // belong to the same thread, for j < 64 to the same wave (LDS executes a wave's accesses in order) — only the steps with
-        // 64 <= j < SEL_T exchange between waves and need the workgroup barrier, before and after.
+        // 64 <= j < NT exchange between waves and need the workgroup barrier, before and after.
         for (int kk = 2; kk <= npad; kk <<= 1)
             for (int j = kk >> 1; j > 0; j >>= 1) {
-                for (int i = tid; i < npad; i += SEL_T) {
+                for (int i = tid; i < npad; i += NT) {
                     const int p = i ^ j;
                     if (p > i) {
                         const unsigned long long x0 = s_key[i], x1 = s_key[p];
@@ -1409,28 +1413,28 @@ __global__ __launch_bounds__(SEL_T) __attribute__((amdgpu_waves_per_eu(8, 8))) v
                     }
                 }
                 const int nj = j > 1 ? (j >> 1) : kk;           // the step that follows (first step of the next stage: j = kk)
-                if ((j >= 64 && j < SEL_T) || (nj >= 64 && nj < SEL_T)) __syncthreads();
+                if ((j >= 64 && j < NT) || (nj >= 64 && nj < NT)) __syncthreads();
                 else __builtin_amdgcn_wave_barrier();
             }
         __syncthreads();
         // ---- sorted keys -> sorted pixel positions x | y << 16, in place (the key holds ~index: equal responses sort by DESCENDING
         //      index); the two divisions per candidate happen here, once, spread over the whole workgroup
         {
-            unsigned idxv[OFK_CHUNK / SEL_T];
+            unsigned idxv[OFK_CHUNK / NT];
 #pragma unroll
-            for (int q = 0; q < OFK_CHUNK / SEL_T; ++q) {
-                const int i = tid + q * SEL_T;
+            for (int q = 0; q < OFK_CHUNK / NT; ++q) {
+                const int i = tid + q * NT;
                 const unsigned idx = i < n ? ~(unsigned)(s_key[i] & 0xffffffffu) : 0u;
                 const unsigned y = idx / (unsigned)w;
                 idxv[q] = (idx - y * (unsigned)w) | (y << 16);
             }
             __syncthreads();
 #pragma unroll
-            for (int q = 0; q < OFK_CHUNK / SEL_T; ++q) { const int i = tid + q * SEL_T; if (i < n) s_idx[i] = idxv[q]; }
+            for (int q = 0; q < OFK_CHUNK / NT; ++q) { const int i = tid + q * NT; if (i < n) s_idx[i] = idxv[q]; }
         }
         if (!grid_ready) {                                      // the first sort may have run over the grid's place
             unsigned *g32 = reinterpret_cast<unsigned *>(sel_smem + 4 * (size_t)tgtA);
-            for (int i = tid; i < tgtA / 2; i += SEL_T) g32[i] = 0xffffffffu;
+            for (int i = tid; i < tgtA / 2; i += NT) g32[i] = 0xffffffffu;
             grid_ready = true;
         }
         __syncthreads();
@@ -1573,6 +1577,10 @@ void ofk_launch_select(hipStream_t s, unsigned long long *cand, int cand_cap, in
     int cs = cs0;
     while ((long long)((w + cs - 1) / cs) * ((h + cs - 1) / cs) > tgtA) cs += cs0;
     const size_t lds = (size_t)8 * tgtA > (size_t)6 * tgtA + (size_t)6 * max_corners + 16 ? (size_t)8 * tgtA : (size_t)6 * tgtA + (size_t)6 * max_corners + 16;
-    hipLaunchKernelGGL(k_select_greedy, dim3(batch), dim3(SEL_T), lds, s, cand, cand_cap, cand_count, maxbits, quality, w, h, max_corners,
-                       min_distance, pts, pts_stride, counts, limit, sel_keys, OFK_CHUNK, tgtA, cs);
+    if (batch <= 64 && tgtA >= 2048)
+        hipLaunchKernelGGL(k_select_greedy<1024>, dim3(batch), dim3(1024), lds, s, cand, cand_cap, cand_count, maxbits, quality, w, h, max_corners,
+                           min_distance, pts, pts_stride, counts, limit, sel_keys, OFK_CHUNK, tgtA, cs);
+    else
+        hipLaunchKernelGGL(k_select_greedy<SEL_T>, dim3(batch), dim3(SEL_T), lds, s, cand, cand_cap, cand_count, maxbits, quality, w, h, max_corners,
+                           min_distance, pts, pts_stride, counts, limit, sel_keys, OFK_CHUNK, tgtA, cs);
 }

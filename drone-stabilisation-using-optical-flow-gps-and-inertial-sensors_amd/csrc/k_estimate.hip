@@ -332,12 +332,89 @@ __global__ __launch_bounds__(64) void k_pairs_solve(const float *__restrict__ pr
     }
 }
 
+// The same solve as a 256-thread workgroup per pair (rounds 1-2's kernel): each of the four waves IS one of the virtual waves above, the
+// partial sums meet in LDS - bit-identical records, a quarter of the latency.  For small batches, where the chip has room for it:
+// 32 pairs of 2000 points (4K, BASELINE configs[4]) take 0.19 ms one wave per pair and 0.05 ms this way.
+__global__ __launch_bounds__(256) void k_pairs_solve_wg(const float *__restrict__ prev_pts, const float *__restrict__ next_pts,
+                                                     const uint8_t *__restrict__ status, const int *__restrict__ counts,
+                                                     int pts_stride, const double *__restrict__ sensors, int variant,
+                                                     int use_feas, double feas_T, const int *__restrict__ cand_count,
+                                                     double *__restrict__ records)
+{
+    __shared__ double s_red[4];
+    __shared__ double s_v[8];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const double *sn = sensors + (size_t)b * OFK_SENSOR_DOUBLES;
+    const double d = sn[0], nrm[3] = {sn[1], sn[2], sn[3]}, om[3] = {sn[4], sn[5], sn[6]};
+    const double scaling = sn[19], cx = sn[20], cy = sn[21], vp[3] = {sn[22], sn[23], sn[24]};
+    const int n = counts[b];
+    const float *pp = prev_pts + (size_t)b * pts_stride * 2, *np_ = next_pts + (size_t)b * pts_stride * 2;
+    const uint8_t *st = status + (size_t)b * pts_stride;
+    Acc a; acc_zero(a);
+    double tracked = 0.0;
+    for (int i = tid; i < n; i += 256) {
+        if (!st[i]) continue;
+        tracked += 1.0;
+        const double x = ((double)np_[2 * i] - cx) * scaling, y = ((double)np_[2 * i + 1] - cy) * scaling;
+        const double ux = ((double)np_[2 * i] - (double)pp[2 * i]) * scaling, uy = ((double)np_[2 * i + 1] - (double)pp[2 * i + 1]) * scaling;
+        if (use_feas) {
+            double r, dd;
+            rtilde_point(x, y, ux, uy, nrm, vp, d, r, dd);
+            if (!(r <= feas_T)) continue;
+        }
+        double q0, q1, q2, sA, sB;
+        point_terms(variant, x, y, ux, uy, nrm, om, d, 1.0, q0, q1, q2, sA, sB);
+        acc_point(a, x, y, q0, q1, q2, sA, sB);
+    }
+    acc_block_sum(a, s_red);
+    tracked = block_sum(tracked, s_red);
+    if (tid == 0) {
+        double v[3] = {0, 0, 0}, s3[3] = {0, 0, 0};
+        const int rank = a.cnt > 0.0 ? solve_from_acc(a, v, s3) : 0;
+        s_v[0] = v[0]; s_v[1] = v[1]; s_v[2] = v[2]; s_v[3] = (double)rank; s_v[4] = s3[0]; s_v[5] = s3[1]; s_v[6] = s3[2];
+    }
+    __syncthreads();
+    const double v[3] = {s_v[0], s_v[1], s_v[2]};
+    double r = 0.0;
+    for (int i = tid; i < n; i += 256) {
+        if (!st[i]) continue;
+        const double x = ((double)np_[2 * i] - cx) * scaling, y = ((double)np_[2 * i + 1] - cy) * scaling;
+        const double ux = ((double)np_[2 * i] - (double)pp[2 * i]) * scaling, uy = ((double)np_[2 * i + 1] - (double)pp[2 * i + 1]) * scaling;
+        if (use_feas) {
+            double rr, dd;
+            rtilde_point(x, y, ux, uy, nrm, vp, d, rr, dd);
+            if (!(rr <= feas_T)) continue;
+        }
+        double q0, q1, q2, sA, sB;
+        point_terms(variant, x, y, ux, uy, nrm, om, d, 1.0, q0, q1, q2, sA, sB);
+        r += resid_point(x, y, q0, q1, q2, sA, sB, v);
+    }
+    r = block_sum(r, s_red);
+    if (tid == 0) {
+        double *o = records + (size_t)b * OFK_RECORD_DOUBLES;
+        const double *R = sn + 7, *off = sn + 16;
+        // v_obs - [w]x offset, then rotate (node:258)
+        const double e0 = v[0] - (om[1] * off[2] - om[2] * off[1]);
+        const double e1 = v[1] - (om[2] * off[0] - om[0] * off[2]);
+        const double e2 = v[2] - (om[0] * off[1] - om[1] * off[0]);
+        o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = r; o[4] = s_v[3]; o[5] = s_v[4]; o[6] = s_v[5]; o[7] = s_v[6];
+        o[8] = R[0] * e0 + R[1] * e1 + R[2] * e2; o[9] = R[3] * e0 + R[4] * e1 + R[5] * e2; o[10] = R[6] * e0 + R[7] * e1 + R[8] * e2;
+        o[11] = a.cnt; o[12] = (double)n; o[13] = tracked; o[14] = cand_count ? (double)cand_count[b * OFK_CNT_STRIDE] : 0.0; o[15] = 0.0;
+    }
+}
+
 void ofk_launch_pairs_solve(hipStream_t s, const float *prev_pts, const float *next_pts, const uint8_t *status,
                             const int *counts, int pts_stride, const double *sensors, int variant, int use_feas,
                             double feas_T, const int *cand_count, double *records, int batch)
 {
-    hipLaunchKernelGGL(k_pairs_solve, dim3(batch), dim3(64), 0, s, prev_pts, next_pts, status, counts, pts_stride, sensors,
-                       variant, use_feas, feas_T, cand_count, records);
+    // Large batches run beside kernels that rent the whole register file in wave-sized pieces: only a single wave finds room at once
+    // (k_pairs_solve).  A small batch leaves the chip half empty: four waves per pair finish sooner (k_pairs_solve_wg).
+    if (batch >= 128)
+        hipLaunchKernelGGL(k_pairs_solve, dim3(batch), dim3(64), 0, s, prev_pts, next_pts, status, counts, pts_stride, sensors,
+                           variant, use_feas, feas_T, cand_count, records);
+    else
+        hipLaunchKernelGGL(k_pairs_solve_wg, dim3(batch), dim3(256), 0, s, prev_pts, next_pts, status, counts, pts_stride, sensors,
+                           variant, use_feas, feas_T, cand_count, records);
 }
 
 __global__ void k_records_f32(const double *__restrict__ rec, float *__restrict__ dst, int batch)

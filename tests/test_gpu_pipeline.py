@@ -251,3 +251,28 @@ def test_resident_pyramids_after_a_pairs_run(pkg, ofk, h, w, streams):
                 got = pipe.ctx.resident_pyramid(fs, b, h, w, len(ref) - 1)
                 for l, (g, r) in enumerate(zip(got, ref)):
                     assert np.array_equal(g, r), f"image {b} frame set {fs} level {l}: {np.argwhere(g != r)[:4]}"
+
+
+@pytest.mark.parametrize("use_feas", [False, True])
+def test_solve_kernels_agree_bit_for_bit(pkg, ofk, use_feas):
+    """ofk_pairs_run solves with one WAVE per pair from 128 pairs on (k_pairs_solve: it fits beside the response kernel) and with a
+    256-thread workgroup per pair below that (k_pairs_solve_wg).  The single wave forms its sums as the workgroup's four waves do -
+    four virtual waves, the same shuffle butterfly, (s0 + s1) + (s2 + s3) - so the records of the same pairs are the same bits."""
+    from of_amd import synth
+    from of_amd.pipeline import FlowPipeline, PipelineConfig
+    h, w, D = 240, 320, 3
+    pairs = [synth.render_pair(h, w, 20 + b, v=(0.004, -0.003 + 0.001 * b, 0.002), omega=(0.003, -0.002, 0.004)) for b in range(D)]
+    cfg = PipelineConfig(max_corners=300, quality=0.01, min_distance=4, block_size=7, max_level=2, use_feasibility=use_feas, feas_T=0.5)
+    outs = []
+    for B in (D, 128 + D):
+        prev = np.stack([pairs[b % D]["prev"] for b in range(B)]); nxt = np.stack([pairs[b % D]["next"] for b in range(B)])
+        sensors = np.concatenate([ofk.make_sensors(1, d=pairs[b % D]["d"], normal=pairs[b % D]["n"], omega=pairs[b % D]["omega"], scaling=pairs[b % D]["scaling"],
+                                                   cx=pairs[b % D]["cx"], cy=pairs[b % D]["cy"], v_prior=pairs[b % D]["v"]) for b in range(B)])
+        pipe = FlowPipeline(w, h, B, cfg)
+        pipe.upload(prev, nxt, sensors)
+        outs.append(pipe.run(points=False)["records"])
+        pipe.close()
+    small, big = outs
+    assert np.all(small[:, 11] > 100)                            # > 256 corners per pair: every virtual wave has points
+    for b in range(128 + D):
+        assert np.array_equal(big[b].view(np.uint64), small[b % D].view(np.uint64)), b

@@ -25,7 +25,7 @@ def run(name, w, h, batch, cfg, steps, kf=False):
     from of_amd.pipeline import FlowPipeline
     prev, nxt, base = synth.make_batch(batch, h, w, seed=77, distinct=4)
     sensors = ofk.make_sensors(batch, scaling=base[0]["scaling"], cx=base[0]["cx"], cy=base[0]["cy"])
-    pipe = FlowPipeline(w, h, batch, cfg, streams=int(os.environ.get("OFK_STREAMS", "2")))     # two free-running slices, like bench.py
+    pipe = FlowPipeline(w, h, batch, cfg, streams=int(os.environ.get("OFK_STREAMS", "1")))     # one stage chain + auxiliary stream, like bench.py
     pipe.upload(prev, nxt, sensors)
     if os.environ.get("OFK_NO_OVERLAP"):
         pipe.ctx.set_overlap(False)                              # every kernel alone on the chip (profiling)

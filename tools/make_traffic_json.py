@@ -26,7 +26,7 @@ import sys
 STAGE_OF = {"k_gray_bgr8": "gray", "k_pyr_down": "pyr", "k_pyr_down_stream": "pyr", "k_pyr3_stream": "pyr",
             "k_mineig": "eig", "k_mineig_stream": "eig", "k_mineig_pair": "eig", "k_zero_detect_state": "eig",
             "k_select_prep": "select", "k_select_pick": "select", "k_select": "select", "k_select_greedy": "select",
-            "k_lk15q": "lk", "k_lk15": "lk", "k_lk": "lk", "k_pairs_solve": "solve"}
+            "k_lk15q": "lk", "k_lk15": "lk", "k_lk": "lk", "k_pairs_solve": "solve", "k_pairs_solve_wg": "solve"}
 TAG = "r03"
 STEP_KERNEL = "k_pairs_solve"                                    # exactly one launch per bench step and slice
 
