@@ -1,6 +1,6 @@
 #!/bin/bash
 for r in 4 8 16 32 64 128; do
-  OFK_PYR_ROWS=$r timeout -k 10 120 python bench.py --no-overlap --steps 20 --warmup 3 --cpu-sample 0 > gpurun_out/sw_$r.log 2>&1 || exit 1
+  timeout -k 10 120 python bench.py --tune pyr_rows=$r --tune no_pyr3=1 --no-overlap --steps 20 --warmup 3 --cpu-sample 0 --no-ingest > gpurun_out/sw_$r.log 2>&1 || exit 1
   python - <<PY
 import json
 l=json.loads(open('gpurun_out/sw_$r.log').read().strip().splitlines()[-1])
