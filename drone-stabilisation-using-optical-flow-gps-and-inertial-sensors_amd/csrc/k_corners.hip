@@ -367,6 +367,22 @@ __device__ __forceinline__ int box_row(int a, int ad2, int ad4, int adl)
 #ifndef OFK_KEYS_ATOM
 #define OFK_KEYS_ATOM 0
 #endif
+#ifndef OFK_BOX_DPP
+#define OFK_BOX_DPP 0
+#endif
+// The four pure neighbour MOVES of a row of k_mineig_pair (two in the Sobel y sums, two in the 3x3 maximum: the other neighbour accesses
+// fold into v_add_u32_dpp).  OFK_MOV_LDS=1 fetches them with ds_bpermute instead of v_mov_b32_dpp: four VALU instructions fewer per row,
+// four LDS instructions more (experiment, tools/experiments/run_variants.sh).
+#ifndef OFK_MOV_LDS
+#define OFK_MOV_LDS 0
+#endif
+#if OFK_MOV_LDS
+#define OFK_NB_PREV(v) __builtin_amdgcn_ds_bpermute(adp1, (v))
+#define OFK_NB_NEXT(v) __builtin_amdgcn_ds_bpermute(adn1, (v))
+#else
+#define OFK_NB_PREV(v) DPP_SHR1(v)
+#define OFK_NB_NEXT(v) DPP_SHL1(v)
+#endif
 #if OFK_KEYS_ATOM
 // experiment (tools/experiments/eig_keys.sh): the slot of a key comes from a counter in LDS (ds_add_rtn_u32 under the candidate
 // lanes' exec mask) instead of ballot + mbcnt ranks; both slots' atomics are issued before the one wait.  The order of keys inside
@@ -615,8 +631,15 @@ __device__ __forceinline__ void box_pair(int ae, int ao, int ad2, int ad3, int &
         ho = DPP_SHR1(ao) + q;
         he = ae + DPP_SHR1(q);
     } else {
+#if OFK_BOX_DPP
+        // experiment (tools/experiments/run_variants.sh): q(l-2) by two wave shifts on the VALU instead of one gather on the LDS pipe
+        const int s1_ = DPP_SHR1(q);
+        const int P = s1_ + q;
+        const int g2q = DPP_SHR1(s1_);
+#else
         const int P = DPP_SHR1(q) + q;                                           // q(l-1) + q(l)
         const int g2q = __builtin_amdgcn_ds_bpermute(ad2, q);                    // q(l-2)
+#endif
         if constexpr (K == 2) {
             ho = P + __builtin_amdgcn_ds_bpermute(ad2, ao);
             he = (P - ao) + g2q;
@@ -679,8 +702,8 @@ __device__ __forceinline__ int lambda_min_bits(int vxx, int vxy, int vyy, float 
         const int nso = -so, nse = -se, tt = te + to;                                                                  \
         const int dxe = DPP_SHR1(nso) + so;                                                                            \
         const int dxo = DPP_SHL1(se) + nse;                                                                            \
-        const int dye = (DPP_SHR1(to) + te) + tt;                                                                      \
-        const int dyo = (DPP_SHL1(te) + to) + tt;                                                                      \
+        const int dye = (OFK_NB_PREV(to) + te) + tt;                                                                   \
+        const int dyo = (OFK_NB_NEXT(te) + to) + tt;                                                                   \
         int pxxe = __mul24(dxe, dxe), pyye = __mul24(dye, dye), pxye = __mul24(dxe, dye);                              \
         int pxxo = __mul24(dxo, dxo), pyyo = __mul24(dyo, dyo), pxyo = __mul24(dxo, dyo);                              \
         asm("" : "+v"(pxxe), "+v"(pxye), "+v"(pyye), "+v"(pxxo), "+v"(pxyo), "+v"(pyyo));                              \
@@ -712,8 +735,8 @@ __device__ __forceinline__ int lambda_min_bits(int vxx, int vxy, int vyy, float 
             }                                                                                                          \
             lmaxi = max(max(lmaxi, cme ? e2e : 0), cmo ? e2o : 0);                                                     \
         }                                                                                                              \
-        const int hm2e = max(max(DPP_SHR1(e2o), e2e), e2o);                                                            \
-        const int hm2o = max(max(DPP_SHL1(e2e), e2o), e2e);                                                            \
+        const int hm2e = max(max(OFK_NB_PREV(e2o), e2e), e2o);                                                         \
+        const int hm2o = max(max(OFK_NB_NEXT(e2e), e2o), e2e);                                                         \
         const int yn = yo - 1;                                                                                         \
         const int me = max(max(hm0e, hm1e), hm2e), mo = max(max(hm0o, hm1o), hm2o);                                    \
         bool ise = e1e >= max(me, thr1e), iso = e1o >= max(mo, thr1o);                                                 \
@@ -813,6 +836,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
     auto mirror = [&](int c) -> int { c = c < 0 ? -c : c; c = c >= w ? 2 * (w - 1) - c : c; return min(max((c - G0) >> 1, 0), 63) * 4; };
     const int mir_e = mirror(ce), mir_o = mirror(ce + 1);       // lane that holds the source of a mirrored column (else: itself)
     const int ad2 = ((lane - 2) & 63) * 4, ad3 = ((lane - 3) & 63) * 4;
+#if OFK_MOV_LDS
+    const int adp1 = ((lane - 1) & 63) * 4, adn1 = ((lane + 1) & 63) * 4;
+#endif
     constexpr int NL = (BS + 1) / 2;                            // dword loads per block of BS rows (two rows each)
     auto row_of = [&](int r) -> int {
         int gy = Yp0 - 1 + min(r, nsteps - 1);
