@@ -708,6 +708,7 @@ struct jstage {
 };
 struct jstages {
     jstage slot[2]; hipStream_t copy;
+    hipStream_t dec;                          // the decoder passes of a double-buffered frame-pair ingest: beside the pipeline run of the batch before
     int *hmap, *hmap_dev; size_t hmap_ints;   // host memory the device writes its convergence flags / end-of-stream records into (pinned,
                                               // mapped): the host reads them after a stream wait, no copy engine in the round trip - a D2H
                                               // copy queues behind the other slot's 200 MB H2D transfer and stalls the decoder for its length
@@ -735,6 +736,7 @@ static jstages *jstages_of(ofk_ctx *c)
         jstages *js = (jstages *)calloc(1, sizeof(jstages));
         if (!js) return nullptr;
         if (hipStreamCreateWithFlags(&js->copy, hipStreamNonBlocking) != hipSuccess) { free(js); return nullptr; }
+        if (hipStreamCreateWithFlags(&js->dec, hipStreamNonBlocking) != hipSuccess) { hipStreamDestroy(js->copy); free(js); return nullptr; }
         for (int k = 0; k < 2; ++k)
             if (hipEventCreateWithFlags(&js->slot[k].copied, hipEventDisableTiming) != hipSuccess) { free(js); return nullptr; }
         c->jstage = js;
@@ -752,6 +754,7 @@ void ofk_jpeg_release(ofk_ctx *c)
         if (js->slot[k].copied) hipEventDestroy(js->slot[k].copied);
     }
     if (js->copy) hipStreamDestroy(js->copy);
+    if (js->dec) hipStreamDestroy(js->dec);
     if (js->hmap) hipHostFree(js->hmap);
     free(js);
     c->jstage = nullptr;
@@ -847,7 +850,7 @@ static int jstage_fill(ofk_ctx *c, int slot, const uint8_t *const *jpeg, const s
 // Phase 2: the staged streams [0, split) go to dst ([.][dst_stride] BGR8), the streams [split, batch) to dst2 (split >= batch: all
 // to dst); with dst == NULL into the context's scratch (*out / *out_stride tell where).  Synchronous on the context's stream.
 static int jdecode_staged(ofk_ctx *c, int slot, uint8_t *dst, uint8_t *dst2, int split, size_t dst_stride, size_t dst_capacity_px,
-                          int *h_out, int *w_out, uint8_t **out, size_t *out_stride)
+                          int *h_out, int *w_out, uint8_t **out, size_t *out_stride, bool own_stream = false, hipEvent_t wait_ev = nullptr)
 {
     jstages *js = (jstages *)c->jstage;
     if (!js || slot < 0 || slot > 1 || !js->slot[slot].valid) return ofk_fail(c, OFK_E_INVALID, "ofk_jpeg: slot %d holds no staged streams (ofk_jpeg_stage)", slot);
@@ -878,7 +881,10 @@ static int jdecode_staged(ofk_ctx *c, int slot, uint8_t *dst, uint8_t *dst2, int
     int *count = (int *)(S + o_count), *base = (int *)(S + o_base), *flags = (int *)(S + o_flags), *endinfo = flags + JMAX_ITERS;
     int16_t *coef = (int16_t *)(S + o_coef), *dcarr = coef + B * g.nblk * 64;     // coefficient blocks, then the dense DC array
     uint8_t *planes = (uint8_t *)(S + o_planes);
-    hipStream_t st = c->stream;
+    // own_stream: nothing the context's streams hold touches the destination (a frame-pair set of its own) or this scratch, so the passes
+    // run on the ingest stream, beside the pipeline run of the batch before; wait_ev = the last reader of the destination
+    hipStream_t st = own_stream ? js->dec : c->stream;
+    if (wait_ev) OFK_HIP(c, hipStreamWaitEvent(st, wait_ev, 0));
     OFK_HIP(c, hipMemsetAsync(flags, 0, JMAX_ITERS * 4 + B * 8, st));
     OFK_HIP(c, hipMemsetAsync(coef, 0, B * g.nblk * 130, st));
     OFK_HIP(c, hipStreamWaitEvent(st, J.copied, 0));             // tables and entropy data are on the device from here on
@@ -934,12 +940,13 @@ int ofk_jpeg_decode_device(ofk_ctx *c, const uint8_t *const *jpeg, const size_t 
 int ofk_jpeg_stage_streams(ofk_ctx *c, int slot, const uint8_t *const *jpeg, const size_t *nbytes, int count) { return jstage_fill(c, slot, jpeg, nbytes, count); }
 
 int ofk_jpeg_decode_staged_pairs(ofk_ctx *c, int slot, uint8_t *dst_prev, uint8_t *dst_next, size_t dst_stride, size_t dst_capacity_px, int *batch_out,
-                                 int *h_out, int *w_out)
+                                 int *h_out, int *w_out, hipEvent_t wait_before_writing)
 {
     jstages *js = (jstages *)c->jstage;
     if (!js || slot < 0 || slot > 1 || !js->slot[slot].valid) return ofk_fail(c, OFK_E_INVALID, "ofk_pairs_upload_staged: slot %d holds no staged streams (ofk_jpeg_stage)", slot);
     const int count = js->slot[slot].batch;
     if (count & 1) return ofk_fail(c, OFK_E_INVALID, "ofk_pairs_upload_staged: %d staged streams are not pairs (previous frames first, then the next frames)", count);
     if (batch_out) *batch_out = count / 2;
-    return jdecode_staged(c, slot, dst_prev, dst_next, count / 2, dst_stride, dst_capacity_px, h_out, w_out, nullptr, nullptr);
+    return jdecode_staged(c, slot, dst_prev, dst_next, count / 2, dst_stride, dst_capacity_px, h_out, w_out, nullptr, nullptr, wait_before_writing != nullptr,
+                          wait_before_writing);
 }

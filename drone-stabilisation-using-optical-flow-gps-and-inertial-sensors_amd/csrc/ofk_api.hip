@@ -191,7 +191,7 @@ extern "C" int ofk_destroy(ofk_ctx *c)
     hipSetDevice(c->device);
     if (c->stream) hipDeviceSynchronize();
     ofk_comm_destroy(c);
-    for (int k = 0; k < 2; ++k) { if (c->bgr[k]) hipFree(c->bgr[k]); if (c->pyr[k]) hipFree(c->pyr[k]); }
+    for (int k = 0; k < 2; ++k) { if (c->bgr[k]) hipFree(c->bgr[k]); if (c->pyr[k]) hipFree(c->pyr[k]); if (c->bgr_alt[k]) hipFree(c->bgr_alt[k]); if (c->ev_bgr_read[k]) hipEventDestroy(c->ev_bgr_read[k]); }
     void *ptrs[] = {c->eig, c->mask, c->deriv, c->cand, c->cand_seg, c->seg_count, c->cand_count, c->sel_hist, c->sel_keys, c->maxbits, c->pts_prev, c->pts_next, c->status, c->err,
                     c->counts, c->sensors, c->records, c->dev_flags, c->scratch, c->pts_new, c->new_counts, c->limit,
                     c->imu_state, c->imu_dv, c->kf_mats, c->kf_x, c->kf_P, c->fused, c->imu_msgs, c->imu_counts};
@@ -846,10 +846,30 @@ extern "C" int ofk_pairs_upload_staged(ofk_ctx *c, int slot)
 {
     if (!c) return OFK_E_INVALID;
     if (hipSetDevice(c->device) != hipSuccess) return ofk_fail(c, OFK_E_HIP, "hipSetDevice failed");
-    TRY(join_slices(c));
+    // The decoder writes into the frame-pair set the pipeline is NOT reading (bgr_alt) on the ingest stream, so the run of the batch
+    // before goes on beside it; the sets are swapped when the frames are there.  The set being written was last read by the gray
+    // conversions of the run before the latest one (ev_bgr_read[1]).  With several slices, or when the second set cannot be had,
+    // the old way: into bgr[] on the context's stream, behind everything.
+    bool twin = c->nstreams <= 1;
+    for (int k = 0; k < 2 && twin; ++k) {
+        if (!c->bgr_alt[k] && hipMalloc((void **)&c->bgr_alt[k], (size_t)c->max_batch * c->bgr_stride) != hipSuccess) { (void)hipGetLastError(); twin = false; }
+        if (!c->ev_bgr_read[k] && hipEventCreateWithFlags(&c->ev_bgr_read[k], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); twin = false; }
+    }
     int h = 0, w = 0, batch = 0;
     c->cur_batch = 0;
-    TRY(ofk_jpeg_decode_staged_pairs(c, slot, c->bgr[0], c->bgr[1], c->bgr_stride, c->P, &batch, &h, &w));
+    if (twin) {
+        hipEvent_t wait = c->ev_bgr_read[1];
+        if (!c->bgr_read_valid[1]) {                             // nothing has read that set yet: any completed event will do
+            OFK_HIP(c, hipEventRecord(wait, c->stream));
+        }
+        TRY(ofk_jpeg_decode_staged_pairs(c, slot, c->bgr_alt[0], c->bgr_alt[1], c->bgr_stride, c->P, &batch, &h, &w, wait));
+        for (int k = 0; k < 2; ++k) { uint8_t *t = c->bgr[k]; c->bgr[k] = c->bgr_alt[k]; c->bgr_alt[k] = t; }
+        { hipEvent_t t = c->ev_bgr_read[0]; c->ev_bgr_read[0] = c->ev_bgr_read[1]; c->ev_bgr_read[1] = t; }
+        { const int t = c->bgr_read_valid[0]; c->bgr_read_valid[0] = 0; c->bgr_read_valid[1] = t; }
+    } else {
+        TRY(join_slices(c));
+        TRY(ofk_jpeg_decode_staged_pairs(c, slot, c->bgr[0], c->bgr[1], c->bgr_stride, c->P, &batch, &h, &w, nullptr));
+    }
     if (batch > c->max_batch) return ofk_fail(c, OFK_E_INVALID, "ofk_pairs_upload_staged: %d pairs exceed the context (%d)", batch, c->max_batch);
     c->cur_batch = batch; c->cur_h = h; c->cur_w = w;
     return OFK_OK;
@@ -958,6 +978,10 @@ extern "C" int ofk_pairs_run(ofk_ctx *c, const ofk_params *p)
         {
             StageTimer t(c, OFK_STAGE_GRAY, sa);
             ofk_launch_gray(sa, bgr1, c->bgr_stride, pyr1, c->pyr_stride, nb, h, w);
+        }
+        if (S == 1 && c->ev_bgr_read[0]) {                       // the compressed ingest may overwrite this frame-pair set from here on
+            OFK_HIP(c, hipEventRecord(c->ev_bgr_read[0], sa));
+            c->bgr_read_valid[0] = 1;
         }
         {
             StageTimer t(c, OFK_STAGE_PYR, sa);
