@@ -34,7 +34,13 @@
 #define JCH_MIN 64              // batches (a single 1080p frame: 7000 threads of 64 bytes), where latency counts, not throughput
 #define JB0 4                   // a symbol belongs to chunk i if the byte cursor after the refill is in [i*JCH + JB0, (i+1)*JCH + JB0)
                                 // (the guess of chunk i starts with the cursor at i*JCH + 4 after its first refill)
+#ifndef J_NOFLUSH
+#define J_NOFLUSH 0
+#endif
 #define JTPB 256                // decoder threads per workgroup (chunks of ONE image: the tables live in LDS)
+#ifndef JTPW
+#define JTPW 256                // ... of the coefficient-writing pass (its LDS rows bound the occupancy)
+#endif
 #define JMAX_ITERS 64           // flag slots; more iterations than this are read back one by one
 
 struct jpeg_tab {               // per image
@@ -65,7 +71,8 @@ static const uint8_t h_zz[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 1
 // lanes), not by the latency of the byte reads, and the 42 KB of LDS cost two thirds of the occupancy.
 // The host pads every entropy segment with zeros up to JPAD(len): the reader needs no bounds checks.
 #define JPAD(len) (((size_t)(len) + 2 * JCH + 19) / JCH * JCH)
-struct jrd { const uint8_t *d; uint32_t pos; uint64_t buf; int nb, fake; int k, blk; };   // fake: virtual zero bits buffered while parked at RSTn
+struct jrd { const uint8_t *d; uint32_t pos; uint64_t buf; int nb, fake; int k, blk;    // fake: virtual zero bits buffered while parked at RSTn
+             uint64_t w0, w1, w2; uint32_t wb; };   // read-ahead window: the 24 bytes at wb (8-aligned, wb <= pos); not part of the state
 
 struct jlds {
     uint16_t lut[6][512];
@@ -82,18 +89,52 @@ __device__ inline void jload_tables(jlds &T, const jpeg_tab *t)
     __syncthreads();
 }
 
+// Read-ahead window.  A decoder's byte reads are serially dependent (the cursor moves by what the last symbol used), and a byte
+// load per symbol put a global-memory round trip into every step of the chain (SQ counters: 83 % of the wave cycles waiting).
+// The window holds the 16 bytes at wb in w0, w1 and has the following 8 in flight in w2: w2 is only read when the window slides,
+// ~10 symbols after it was requested, so the chain sees registers.  Entropy segments start 256-aligned and are zero-padded
+// (JPAD), so the aligned 8-byte reads stay inside the buffer.
+__device__ inline uint64_t jload8(const uint8_t *d, uint32_t at) { return *reinterpret_cast<const uint64_t *>(d + at); }
+__device__ inline void jwindow(jrd &r)
+{
+    r.wb = r.pos & ~7u;
+    r.w0 = jload8(r.d, r.wb); r.w1 = jload8(r.d, r.wb + 8); r.w2 = jload8(r.d, r.wb + 16);
+}
+__device__ inline void jslide(jrd &r) { while (r.pos - r.wb >= 8) { r.w0 = r.w1; r.w1 = r.w2; r.wb += 8; r.w2 = jload8(r.d, r.wb + 16); } }
+__device__ inline uint32_t jbyte(const jrd &r, uint32_t p)      // wb <= p < wb + 16
+{
+    const uint32_t o = p - r.wb;
+    return (uint32_t)((o < 8 ? r.w0 : r.w1) >> (8 * (o & 7))) & 255u;
+}
+
 // Canonical refill: byte by byte until 32..39 bits are buffered - enough for the longest code (16) plus the longest run of extra
-// bits (15), so a symbol needs one refill.  The state after it depends on the bit position only.
+// bits (15), so a symbol needs one refill.  The state after it depends on the bit position only.  Fast path: the 1..4 bytes that
+// are due hold no FF (and no restart marker is pending), so they go in as one shift; otherwise byte by byte with the marker rules.
 __device__ inline void jrefill(jrd &r)
 {
+    if (r.nb > 31) return;
+    jslide(r);
+    {
+        const uint32_t o = r.pos - r.wb;                             // 0..7
+        const uint32_t a0 = (uint32_t)r.w0, a1 = (uint32_t)(r.w0 >> 32), a2 = (uint32_t)r.w1;
+        const uint32_t x = __builtin_amdgcn_alignbyte(o < 4 ? a1 : a2, o < 4 ? a0 : a1, o & 3);   // the next four bytes, first one lowest
+        const int n = (39 - r.nb) >> 3;                              // bytes the byte-wise loop would take: 1..4
+        const uint32_t y = ~x | (n == 4 ? 0u : 0xFFFFFFFFu << (8 * n));              // a zero byte in y = an FF among the n bytes
+        if (!r.fake && ((y - 0x01010101u) & ~y & 0x80808080u) == 0) {
+            r.buf = (r.buf << (8 * n)) | (uint64_t)(__builtin_bswap32(x) >> (32 - 8 * n));
+            r.nb += 8 * n; r.pos += n;
+            return;
+        }
+    }
     while (r.nb <= 31) {
         uint32_t b = 0;
         if (r.fake) r.fake += 8;                                  // parked in front of a restart marker: zero bits, like libjpeg
         else {
-            b = r.d[r.pos];
+            jslide(r);
+            b = jbyte(r, r.pos);
             if (b != 0xFF) ++r.pos;
             else {
-                const uint32_t n = r.d[r.pos + 1];
+                const uint32_t n = jbyte(r, r.pos + 1);
                 if (n == 0) r.pos += 2;                           // stuffed zero (an FF in front of the zero padding counts as one too)
                 else if ((n & 0xF8u) == 0xD0u) { b = 0; r.fake = 8; }      // RSTn: stay in front of it until the interval's bits are used up
                 else ++r.pos;
@@ -142,9 +183,14 @@ __device__ inline int jrun(const jlds &T, jrd &r, uint32_t bnext, const jpeg_geo
         const uint32_t e = T.lut[slot][jpeek(r, 9)];
         if (e) { len = e >> 8; sym = e & 255; }
         else {
+            // a code longer than the lookahead: the first length whose largest code is not below the prefix (jdhuff.c's loop), found
+            // with the seven comparisons side by side - some lane of a wave is here in almost every step, and seven LDS reads one
+            // after the other were the longest link of the decoder's dependency chain
             const int c16 = (int)jpeek(r, 16);
-            int l = 10;
-            while (l <= 16 && (c16 >> (16 - l)) > T.maxcode[slot][l]) ++l;
+            unsigned below = 0;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) below |= (unsigned)((c16 >> (6 - j)) > T.maxcode[slot][10 + j]) << j;
+            const int l = 10 + __builtin_ctz(~below | 0x80u);
             if (l > 16) { len = 16; sym = 0; }
             else { len = l; sym = T.vals[slot][((c16 >> (16 - l)) + T.valoff[slot][l]) & 255]; }
         }
@@ -178,6 +224,7 @@ __device__ inline void jstart(jrd &r, uint32_t chunk, int jch)
 {   // chunk 0: the true start of the scan; otherwise the guess "a block starts at the first byte of the chunk"
     r.pos = chunk * (uint32_t)jch; r.nb = 0; r.fake = 0; r.buf = 0; r.k = 0; r.blk = 0;
     if (chunk && r.d[r.pos - 1] == 0xFF && (r.d[r.pos] == 0 || (r.d[r.pos] & 0xF8u) == 0xD0u)) ++r.pos;   // second byte of FF00 / RSTn
+    jwindow(r);
     jrefill(r);
 }
 
@@ -188,11 +235,14 @@ __global__ __launch_bounds__(JTPB) void k_jpeg_sync(const jpeg_tab *__restrict__
                                                     int *__restrict__ count, int iter, int *__restrict__ flags)
 {
     __shared__ jlds T;
+    __shared__ unsigned long long elist[JTPB];
+    __shared__ uint16_t clist[JTPB];
+    __shared__ int wcount[JTPB / 64];
     const int b = blockIdx.y;
     const jpeg_tab *t = tabs + b;
     if ((int)(blockIdx.x * JTPB) >= t->nch) return;
-    const int i = blockIdx.x * JTPB + threadIdx.x;
-    const size_t o = (size_t)b * nch_max + i;
+    int i = blockIdx.x * JTPB + threadIdx.x;
+    size_t o = (size_t)b * nch_max + i;
     // who has work?  iteration 0: everybody; later: the chunks whose predecessor published a state they have not started from yet
     // (chunk 0 started from the truth and never has).  A workgroup without work leaves before it loads the tables.
     unsigned long long e = 0;
@@ -202,6 +252,20 @@ __global__ __launch_bounds__(JTPB) void k_jpeg_sync(const jpeg_tab *__restrict__
         if (work) { e = state[o - 1]; work = e != used[o]; }
     }
     if (!__syncthreads_or(work)) return;
+    if (iter >= 2) {
+        // from the third pass on only a fraction of the chunks has work, scattered over the lanes: hand the work to the first
+        // threads of the workgroup, so that whole waves leave instead of idling beside a few busy lanes
+        const unsigned long long bal = __ballot(work);
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        if (lane == 0) wcount[wv] = __popcll(bal);
+        __syncthreads();
+        int pre = 0, total = 0;
+        for (int k = 0; k < JTPB / 64; ++k) { if (k < wv) pre += wcount[k]; total += wcount[k]; }
+        if (work) { const int at = pre + __popcll(bal & ((1ull << lane) - 1ull)); clist[at] = (uint16_t)threadIdx.x; elist[at] = e; }
+        __syncthreads();
+        work = (int)threadIdx.x < total;
+        if (work) { i = blockIdx.x * JTPB + clist[threadIdx.x]; o = (size_t)b * nch_max + i; e = elist[threadIdx.x]; }
+    }
     jload_tables(T, t);
     if (!work) return;
     jrd r;
@@ -212,6 +276,7 @@ __global__ __launch_bounds__(JTPB) void k_jpeg_sync(const jpeg_tab *__restrict__
     } else {
         junpack(r, e);
         jrebuild(r);
+        jwindow(r);
     }
     used[o] = e;
     jemit_none em;
@@ -248,60 +313,91 @@ __global__ __launch_bounds__(1024) void k_jpeg_scan(const jpeg_tab *__restrict__
     if (threadIdx.x == 0) base[(size_t)b * (nch_max + 1) + nch_max] = carry;
 }
 
-// Coefficients of the block in progress are collected in the thread's LDS row and leave as one 128-byte store when the block is
-// complete (2-byte stores scattered over HBM made this kernel 3x slower than the counting pass).  A block that straddles a chunk
-// boundary is shared with the neighbouring thread: its parts are scattered element-wise onto the zeroed background instead.
-#define JBLK_PITCH 66                                             // int16 per LDS row: 33 dwords, lanes spread over the banks
+// Coefficients of the block in progress are collected in the thread's LDS row and leave as one wide store when the block is
+// complete (2-byte stores scattered over HBM - partial-line writes - made this kernel 3x slower than the counting pass).  The row
+// holds the first JROW_K zigzag positions only: the pass is bound by the latency of its per-symbol dependency chain, so its speed
+// is its occupancy, and a row of all 64 positions (33 KB of LDS per 256 threads) allowed 3 waves per SIMD, 32 positions allow 6.
+// The few coefficients behind position JROW_K (the high-frequency half: a few per cent at camera qualities) go straight to the
+// zeroed coefficient buffer.  A block that straddles a chunk boundary is shared with the neighbouring thread: its parts are
+// scattered element-wise onto the zeroed background instead.
+#ifndef JROW_K
+#define JROW_K 32
+#endif
+#define JBLK_PITCH (JROW_K + 2)                                   // int16 per LDS row: an odd number of dwords spreads the lanes over the banks
 struct jemit_store {
     int16_t *row;                                                 // this thread's LDS row (zigzag order, zero between blocks)
     int16_t *out; int n0, nblk; bool head_partial;
     int16_t *dc; int cur;                                         // DC differences go to a dense array of their own (k_jpeg_dc scans it)
     __device__ void coef(int k, int v)
     {
-        row[k] = (int16_t)v;
+        if (k < JROW_K) row[k] = (int16_t)v;
+        else if (n0 + cur < nblk) out[(size_t)(n0 + cur) * 64 + k] = (int16_t)v;
         if (k == 0 && n0 + cur < nblk) dc[n0 + cur] = (int16_t)v;
     }
     __device__ void scatter(int n)
     {
         int16_t *dst = out + (size_t)n * 64;
-        for (int k = 0; k < 64; ++k) { const int16_t v = row[k]; if (v) { dst[k] = v; row[k] = 0; } }
+        for (int k = 0; k < JROW_K; ++k) { const int16_t v = row[k]; if (v) { dst[k] = v; row[k] = 0; } }
+    }
+    // A complete block is read out of the row at once (the row is needed for the next block) but stored when the thread's NEXT
+    // block is complete: the store then finds its data long arrived, where waiting for the LDS reads in place put their latency
+    // into the dependency chain of almost every step (some lane of a wave completes a block in almost every step): 1.81 -> x ms
+    uint4 pend[JROW_K / 8]; uint4 *pend_dst;
+    __device__ void drain()
+    {
+        if (!pend_dst) return;
+#if J_NOFLUSH == 2
+        if (pend[0].x != 0x12345678u) { pend_dst = nullptr; return; }
+#endif
+#pragma unroll
+        for (int q = 0; q < JROW_K / 8; ++q) pend_dst[q] = pend[q];
+        pend_dst = nullptr;
     }
     __device__ void block(int done)
     {
         const int n = n0 + done;
         cur = done + 1;
         if (n >= nblk) return;
+#if J_NOFLUSH == 1                                               // timing experiments only (wrong pixels)
+        return;
+#endif
         if (done == 0 && head_partial) { scatter(n); return; }
-        const uint32_t *src = (const uint32_t *)row;
-        uint4 *dst = (uint4 *)(out + (size_t)n * 64);
+        drain();
+        uint32_t *src = (uint32_t *)row;
+        pend_dst = (uint4 *)(out + (size_t)n * 64);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) dst[q] = make_uint4(src[4 * q], src[4 * q + 1], src[4 * q + 2], src[4 * q + 3]);
-#pragma unroll
-        for (int q = 0; q < 32; ++q) ((uint32_t *)row)[q] = 0;
+        for (int q = 0; q < JROW_K / 8; ++q) { pend[q] = make_uint4(src[4 * q], src[4 * q + 1], src[4 * q + 2], src[4 * q + 3]);
+#if J_NOFLUSH != 3
+            src[4 * q] = src[4 * q + 1] = src[4 * q + 2] = src[4 * q + 3] = 0;
+#endif
+        }
     }
 };
 
-__global__ __launch_bounds__(JTPB) void k_jpeg_write(const jpeg_tab *__restrict__ tabs, const uint8_t *__restrict__ ent, jpeg_geom g, int nch_max,
+__global__ __launch_bounds__(JTPW) void k_jpeg_write(const jpeg_tab *__restrict__ tabs, const uint8_t *__restrict__ ent, jpeg_geom g, int nch_max,
                                                      const unsigned long long *__restrict__ state, const int *__restrict__ base,
                                                      int16_t *__restrict__ coef, int16_t *__restrict__ dcarr, int *__restrict__ endinfo)
 {
     __shared__ jlds T;
-    __shared__ int16_t rows[JTPB][JBLK_PITCH];
+    __shared__ int16_t rows[JTPW][JBLK_PITCH];
     const int b = blockIdx.y;
     const jpeg_tab *t = tabs + b;
-    if ((int)(blockIdx.x * JTPB) >= t->nch) return;
+    if ((int)(blockIdx.x * JTPW) >= t->nch) return;
     jload_tables(T, t);
-    const int i = blockIdx.x * JTPB + threadIdx.x;
+    const int i = blockIdx.x * JTPW + threadIdx.x;
     if (i >= t->nch) return;
     const int n0 = base[(size_t)b * (nch_max + 1) + i];
     if (n0 >= g.nblk) return;
     jrd r;
     r.d = ent + t->ent_off;
     if (i == 0) jstart(r, 0, g.jch);
-    else { junpack(r, state[(size_t)b * nch_max + i - 1]); jrebuild(r); }
+    else { junpack(r, state[(size_t)b * nch_max + i - 1]); jrebuild(r); jwindow(r); }
     for (int q = 0; q < JBLK_PITCH / 2; ++q) ((uint32_t *)rows[threadIdx.x])[q] = 0;
-    jemit_store em = {rows[threadIdx.x], coef + (size_t)b * g.nblk * 64, n0, g.nblk, r.k != 0, dcarr + (size_t)b * g.nblk, 0};
+    jemit_store em;
+    em.row = rows[threadIdx.x]; em.out = coef + (size_t)b * g.nblk * 64; em.n0 = n0; em.nblk = g.nblk; em.head_partial = r.k != 0;
+    em.dc = dcarr + (size_t)b * g.nblk; em.cur = 0; em.pend_dst = nullptr;
     const int n = jrun(T, r, (uint32_t)(i + 1) * (uint32_t)g.jch + JB0, g, g.nblk - n0, em);
+    em.drain();
     if (r.k != 0 && n0 + n < g.nblk) em.scatter(n0 + n);          // the block still in progress continues in the next chunk
     if (n0 + n == g.nblk && n > 0) {                              // this thread finished the last block: where the scan ended
         endinfo[b * 2] = (int)(r.pos - (uint32_t)(r.nb >> 3));
@@ -911,7 +1007,7 @@ static int jdecode_staged(ofk_ctx *c, int slot, uint8_t *dst, uint8_t *dst2, int
         if (!converged && iter > nch_max + 2) return ofk_fail(c, OFK_E_INVALID, "ofk_jpeg: entropy decoders did not converge");
     }
     hipLaunchKernelGGL(k_jpeg_scan, dim3(batch), dim3(1024), 0, st, dt, nch_max, count, base);
-    hipLaunchKernelGGL(k_jpeg_write, dgrid, dim3(JTPB), 0, st, dt, dent, g, nch_max, state, base, coef, dcarr, endinfo);
+    hipLaunchKernelGGL(k_jpeg_write, dim3((nch_max + JTPW - 1) / JTPW, batch), dim3(JTPW), 0, st, dt, dent, g, nch_max, state, base, coef, dcarr, endinfo);
     hipLaunchKernelGGL(k_jpeg_dc, dim3(batch, g.ncomp), dim3(1024), 0, st, dt, g, dcarr);
     hipLaunchKernelGGL(k_jpeg_idct, dim3((g.nblk + 31) / 32, batch), dim3(256), 0, st, dt, g, coef, dcarr, planes);
     hipLaunchKernelGGL(k_jpeg_color, dim3((g.w + 511) / 512, (g.h + 3) / 4, batch), dim3(64, 4), 0, st, g, planes, dst, dst2, split, dst_stride);
