@@ -602,8 +602,11 @@ __device__ inline void jchroma8(const uint8_t *__restrict__ pl, int pitch, int c
 }
 
 // eight pixels per thread: 8 bytes of luma in, 24 bytes of BGR out as dwords (bytes when the row pitch is not a dword multiple)
+// as_gray: bgr / bgr2 are gray planes (rows of g.w bytes) and receive what k_gray_bgr8 (k_image.hip: cv2.cvtColor BGR2GRAY) makes of the
+// pixel - the pipeline's first stage fused into the decoder's last, the BGR frame (three times the bytes, written here and read there)
+// never exists.
 __global__ __launch_bounds__(256) void k_jpeg_color(jpeg_geom g, const uint8_t *__restrict__ planes, uint8_t *__restrict__ bgr, uint8_t *__restrict__ bgr2, int split,
-                                                    size_t bgr_stride)
+                                                    size_t bgr_stride, int as_gray)
 {
     const int b = blockIdx.z;
     const int x0 = (blockIdx.x * 64 + threadIdx.x) * 8, y = blockIdx.y * 4 + threadIdx.y;
@@ -628,6 +631,21 @@ __global__ __launch_bounds__(256) void k_jpeg_color(jpeg_geom g, const uint8_t *
             px[3 * k + 1] = (uint8_t)jclamp8(Y + ((-22554 * u + 32768 - 46802 * v) >> 16));
             px[3 * k + 2] = (uint8_t)jclamp8(Y + ((91881 * v + 32768) >> 16));
         }
+    }
+    if (as_gray) {
+        uint8_t *og = (b < split ? bgr + (size_t)b * bgr_stride : bgr2 + (size_t)(b - split) * bgr_stride) + (size_t)y * g.w + x0;
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                               // k_image.hip gray1(): (3735 b + 19235 g + 9798 r + 16384) >> 15
+            lo |= ((px[3 * k] * 3735u + px[3 * k + 1] * 19235u + px[3 * k + 2] * 9798u + 16384u) >> 15) << (8 * k);
+            hi |= ((px[3 * k + 12] * 3735u + px[3 * k + 13] * 19235u + px[3 * k + 14] * 9798u + 16384u) >> 15) << (8 * k);
+        }
+        if ((g.w & 7) == 0 && (bgr_stride & 7) == 0) *(uint2 *)og = make_uint2(lo, hi);
+        else {
+            const int n = g.w - x0 < 8 ? g.w - x0 : 8;
+            for (int k = 0; k < n; ++k) og[k] = (uint8_t)((k < 4 ? lo : hi) >> (8 * (k & 3)));
+        }
+        return;
     }
     if ((g.w & 7) == 0 && (bgr_stride & 3) == 0) {
         uint32_t *o4 = (uint32_t *)o;
@@ -946,7 +964,8 @@ static int jstage_fill(ofk_ctx *c, int slot, const uint8_t *const *jpeg, const s
 // Phase 2: the staged streams [0, split) go to dst ([.][dst_stride] BGR8), the streams [split, batch) to dst2 (split >= batch: all
 // to dst); with dst == NULL into the context's scratch (*out / *out_stride tell where).  Synchronous on the context's stream.
 static int jdecode_staged(ofk_ctx *c, int slot, uint8_t *dst, uint8_t *dst2, int split, size_t dst_stride, size_t dst_capacity_px,
-                          int *h_out, int *w_out, uint8_t **out, size_t *out_stride, bool own_stream = false, hipEvent_t wait_ev = nullptr)
+                          int *h_out, int *w_out, uint8_t **out, size_t *out_stride, bool own_stream = false, const hipEvent_t *wait_ev = nullptr, int nwait = 0,
+                          int as_gray = 0)
 {
     jstages *js = (jstages *)c->jstage;
     if (!js || slot < 0 || slot > 1 || !js->slot[slot].valid) return ofk_fail(c, OFK_E_INVALID, "ofk_jpeg: slot %d holds no staged streams (ofk_jpeg_stage)", slot);
@@ -980,7 +999,7 @@ static int jdecode_staged(ofk_ctx *c, int slot, uint8_t *dst, uint8_t *dst2, int
     // own_stream: nothing the context's streams hold touches the destination (a frame-pair set of its own) or this scratch, so the passes
     // run on the ingest stream, beside the pipeline run of the batch before; wait_ev = the last reader of the destination
     hipStream_t st = own_stream ? js->dec : c->stream;
-    if (wait_ev) OFK_HIP(c, hipStreamWaitEvent(st, wait_ev, 0));
+    for (int k = 0; wait_ev && k < nwait; ++k) if (wait_ev[k]) OFK_HIP(c, hipStreamWaitEvent(st, wait_ev[k], 0));
     OFK_HIP(c, hipMemsetAsync(flags, 0, JMAX_ITERS * 4 + B * 8, st));
     OFK_HIP(c, hipMemsetAsync(coef, 0, B * g.nblk * 130, st));
     OFK_HIP(c, hipStreamWaitEvent(st, J.copied, 0));             // tables and entropy data are on the device from here on
@@ -1010,7 +1029,7 @@ static int jdecode_staged(ofk_ctx *c, int slot, uint8_t *dst, uint8_t *dst2, int
     hipLaunchKernelGGL(k_jpeg_write, dim3((nch_max + JTPW - 1) / JTPW, batch), dim3(JTPW), 0, st, dt, dent, g, nch_max, state, base, coef, dcarr, endinfo);
     hipLaunchKernelGGL(k_jpeg_dc, dim3(batch, g.ncomp), dim3(1024), 0, st, dt, g, dcarr);
     hipLaunchKernelGGL(k_jpeg_idct, dim3((g.nblk + 31) / 32, batch), dim3(256), 0, st, dt, g, coef, dcarr, planes);
-    hipLaunchKernelGGL(k_jpeg_color, dim3((g.w + 511) / 512, (g.h + 3) / 4, batch), dim3(64, 4), 0, st, g, planes, dst, dst2, split, dst_stride);
+    hipLaunchKernelGGL(k_jpeg_color, dim3((g.w + 511) / 512, (g.h + 3) / 4, batch), dim3(64, 4), 0, st, g, planes, dst, dst2, split, dst_stride, as_gray);
     hipLaunchKernelGGL(k_jpeg_ints_to_host, dim3(4), dim3(256), 0, st, endinfo, js->hmap_dev + JMAX_ITERS, 2 * batch);
     hipError_t e = hipStreamSynchronize(st);
     if (e == hipSuccess) e = hipGetLastError();
@@ -1036,7 +1055,7 @@ int ofk_jpeg_decode_device(ofk_ctx *c, const uint8_t *const *jpeg, const size_t 
 int ofk_jpeg_stage_streams(ofk_ctx *c, int slot, const uint8_t *const *jpeg, const size_t *nbytes, int count) { return jstage_fill(c, slot, jpeg, nbytes, count); }
 
 int ofk_jpeg_decode_staged_pairs(ofk_ctx *c, int slot, uint8_t *dst_prev, uint8_t *dst_next, size_t dst_stride, size_t dst_capacity_px, int *batch_out,
-                                 int *h_out, int *w_out, hipEvent_t wait_before_writing)
+                                 int *h_out, int *w_out, const hipEvent_t *wait_before_writing, int nwait, int as_gray)
 {
     jstages *js = (jstages *)c->jstage;
     if (!js || slot < 0 || slot > 1 || !js->slot[slot].valid) return ofk_fail(c, OFK_E_INVALID, "ofk_pairs_upload_staged: slot %d holds no staged streams (ofk_jpeg_stage)", slot);
@@ -1044,5 +1063,5 @@ int ofk_jpeg_decode_staged_pairs(ofk_ctx *c, int slot, uint8_t *dst_prev, uint8_
     if (count & 1) return ofk_fail(c, OFK_E_INVALID, "ofk_pairs_upload_staged: %d staged streams are not pairs (previous frames first, then the next frames)", count);
     if (batch_out) *batch_out = count / 2;
     return jdecode_staged(c, slot, dst_prev, dst_next, count / 2, dst_stride, dst_capacity_px, h_out, w_out, nullptr, nullptr, wait_before_writing != nullptr,
-                          wait_before_writing);
+                          wait_before_writing, nwait, as_gray);
 }

@@ -142,6 +142,7 @@ extern "C" int ofk_create(int device, int max_w, int max_h, int max_batch, int m
     c->nstreams = 1;
     c->streams[0] = c->stream;
     c->overlap = 1;
+    c->gray_direct_set = -1;
     // Slice and auxiliary streams are created when a call first needs them (need_streams): the runtime multiplexes HIP streams
     // onto a few hardware queues (4 by default), and two streams of one queue run in order - an idle stream would cost a real one
     // its concurrency.
@@ -191,7 +192,7 @@ extern "C" int ofk_destroy(ofk_ctx *c)
     hipSetDevice(c->device);
     if (c->stream) hipDeviceSynchronize();
     ofk_comm_destroy(c);
-    for (int k = 0; k < 2; ++k) { if (c->bgr[k]) hipFree(c->bgr[k]); if (c->pyr[k]) hipFree(c->pyr[k]); if (c->bgr_alt[k]) hipFree(c->bgr_alt[k]); if (c->ev_bgr_read[k]) hipEventDestroy(c->ev_bgr_read[k]); }
+    for (int k = 0; k < 2; ++k) { if (c->bgr[k]) hipFree(c->bgr[k]); if (c->pyr[k]) hipFree(c->pyr[k]); }
     void *ptrs[] = {c->eig, c->mask, c->deriv, c->cand, c->cand_seg, c->seg_count, c->cand_count, c->sel_hist, c->sel_keys, c->maxbits, c->pts_prev, c->pts_next, c->status, c->err,
                     c->counts, c->sensors, c->records, c->dev_flags, c->scratch, c->pts_new, c->new_counts, c->limit,
                     c->imu_state, c->imu_dv, c->kf_mats, c->kf_x, c->kf_P, c->fused, c->imu_msgs, c->imu_counts};
@@ -811,6 +812,7 @@ extern "C" int ofk_pairs_upload(ofk_ctx *c, const uint8_t *prev_bgr, const uint8
     TRY(h2d(c, c->bgr[1], c->bgr_stride, next_bgr, px * 3, batch));
     OFK_HIP(c, hipStreamSynchronize(c->stream));
     c->cur_batch = batch; c->cur_h = h; c->cur_w = w;
+    c->gray_direct_set = -1;
     return OFK_OK;
 }
 
@@ -846,29 +848,25 @@ extern "C" int ofk_pairs_upload_staged(ofk_ctx *c, int slot)
 {
     if (!c) return OFK_E_INVALID;
     if (hipSetDevice(c->device) != hipSuccess) return ofk_fail(c, OFK_E_HIP, "hipSetDevice failed");
-    // The decoder writes into the frame-pair set the pipeline is NOT reading (bgr_alt) on the ingest stream, so the run of the batch
-    // before goes on beside it; the sets are swapped when the frames are there.  The set being written was last read by the gray
-    // conversions of the run before the latest one (ev_bgr_read[1]).  With several slices, or when the second set cannot be had,
-    // the old way: into bgr[] on the context's stream, behind everything.
-    bool twin = c->nstreams <= 1;
-    for (int k = 0; k < 2 && twin; ++k) {
-        if (!c->bgr_alt[k] && hipMalloc((void **)&c->bgr_alt[k], (size_t)c->max_batch * c->bgr_stride) != hipSuccess) { (void)hipGetLastError(); twin = false; }
-        if (!c->ev_bgr_read[k] && hipEventCreateWithFlags(&c->ev_bgr_read[k], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); twin = false; }
-    }
+    // With one slice and the double-buffered pyramid sets of the overlapped schedule the decoder's colour kernel writes GRAY straight
+    // into level 0 of the set the next ofk_pairs_run will take (the one the run in flight is NOT reading), on the ingest stream: the
+    // decoder passes of batch k + 1 go on beside the run of batch k, and that run's first stage is already done (gray_direct_set).  The
+    // set was last read by the LK of the run before the latest one (ev_lkdone).  With several slices, or without the second set, the
+    // old way: BGR into bgr[] on the context's stream, behind everything.
+    bool direct = c->nstreams <= 1 && c->overlap != 0;
+    for (int k = 0; k < 2 && direct; ++k)
+        if (!c->pyr_alt[k] && hipMalloc((void **)&c->pyr_alt[k], (size_t)c->max_batch * c->pyr_stride) != hipSuccess) { (void)hipGetLastError(); direct = false; }
     int h = 0, w = 0, batch = 0;
     c->cur_batch = 0;
-    if (twin) {
-        hipEvent_t wait = c->ev_bgr_read[1];
-        if (!c->bgr_read_valid[1]) {                             // nothing has read that set yet: any completed event will do
-            OFK_HIP(c, hipEventRecord(wait, c->stream));
-        }
-        TRY(ofk_jpeg_decode_staged_pairs(c, slot, c->bgr_alt[0], c->bgr_alt[1], c->bgr_stride, c->P, &batch, &h, &w, wait));
-        for (int k = 0; k < 2; ++k) { uint8_t *t = c->bgr[k]; c->bgr[k] = c->bgr_alt[k]; c->bgr_alt[k] = t; }
-        { hipEvent_t t = c->ev_bgr_read[0]; c->ev_bgr_read[0] = c->ev_bgr_read[1]; c->ev_bgr_read[1] = t; }
-        { const int t = c->bgr_read_valid[0]; c->bgr_read_valid[0] = 0; c->bgr_read_valid[1] = t; }
+    c->gray_direct_set = -1;
+    if (direct) {
+        const int set = c->pyr_set;
+        uint8_t *const P0 = set ? c->pyr_alt[0] : c->pyr[0], *const P1 = set ? c->pyr_alt[1] : c->pyr[1];
+        TRY(ofk_jpeg_decode_staged_pairs(c, slot, P0, P1, c->pyr_stride, c->P, &batch, &h, &w, c->ev_lkdone[set], OFK_MAX_STREAMS, 1));
+        c->gray_direct_set = set;
     } else {
         TRY(join_slices(c));
-        TRY(ofk_jpeg_decode_staged_pairs(c, slot, c->bgr[0], c->bgr[1], c->bgr_stride, c->P, &batch, &h, &w, nullptr));
+        TRY(ofk_jpeg_decode_staged_pairs(c, slot, c->bgr[0], c->bgr[1], c->bgr_stride, c->P, &batch, &h, &w, nullptr, 0, 0));
     }
     if (batch > c->max_batch) return ofk_fail(c, OFK_E_INVALID, "ofk_pairs_upload_staged: %d pairs exceed the context (%d)", batch, c->max_batch);
     c->cur_batch = batch; c->cur_h = h; c->cur_w = w;
@@ -942,6 +940,8 @@ extern "C" int ofk_pairs_run(ofk_ctx *c, const ofk_params *p)
     }
     int set = 0;
     if (overlap) { set = c->pyr_set; c->pyr_set ^= 1; }
+    const bool have_gray = c->gray_direct_set >= 0;               // compressed ingest: the frames came in as gray level 0 of that set (and only there)
+    if (have_gray) { set = c->gray_direct_set; c->pyr_set = set ^ 1; }
     c->pyr_last = set;
     uint8_t *const P0 = set ? c->pyr_alt[0] : c->pyr[0], *const P1 = set ? c->pyr_alt[1] : c->pyr[1];
     // Slices are forked off the context's stream once and then free-run over consecutive calls: nothing joins them until an
@@ -970,18 +970,14 @@ extern "C" int ofk_pairs_run(ofk_ctx *c, const ofk_params *p)
         float *err = c->err + (size_t)b0 * c->max_pts;
         int *counts = c->counts + b0;
         int nseg = 0, segcap = 0;
-        {
+        if (!have_gray) {
             StageTimer t(c, OFK_STAGE_GRAY, sa);
             ofk_launch_gray(sa, bgr0, c->bgr_stride, pyr0, c->pyr_stride, nb, h, w);
         }
         if (overlap) OFK_HIP(c, hipEventRecord(c->ev_g0[k], sa));
-        {
+        if (!have_gray) {
             StageTimer t(c, OFK_STAGE_GRAY, sa);
             ofk_launch_gray(sa, bgr1, c->bgr_stride, pyr1, c->pyr_stride, nb, h, w);
-        }
-        if (S == 1 && c->ev_bgr_read[0]) {                       // the compressed ingest may overwrite this frame-pair set from here on
-            OFK_HIP(c, hipEventRecord(c->ev_bgr_read[0], sa));
-            c->bgr_read_valid[0] = 1;
         }
         {
             StageTimer t(c, OFK_STAGE_PYR, sa);

@@ -46,9 +46,8 @@ struct ofk_ctx {
     int cand_cap;                   // candidate keys per image
 
     uint8_t *bgr[2];                // [B][bgr_stride]            prev / next BGR frames
-    uint8_t *bgr_alt[2];            // second frame-pair set of the compressed ingest (lazily allocated): batch k + 1 is decoded into it while
-                                    // ofk_pairs_run of batch k still reads bgr[]; ofk_pairs_upload_staged swaps the two
-    hipEvent_t ev_bgr_read[2]; int bgr_read_valid[2];   // [0]: the latest run's gray conversions have read bgr[]; [1]: likewise for the set that is bgr_alt[] now
+    int gray_direct_set;            // >= 0: the resident frame pairs exist as gray level 0 of this pyramid set only (compressed ingest,
+                                    // ofk_pairs_upload_staged): ofk_pairs_run takes that set and skips its BGR -> gray conversions; -1: bgr[] holds them
     uint8_t *pyr[2];                // [B][pyr_stride]            gray pyramids (level 0 = gray frame)
     float *eig;                     // [B][img_stride]            Shi-Tomasi response
     uint8_t *mask;                  // [B][img_stride]            optional detection mask (lazily allocated)
@@ -108,7 +107,9 @@ int ofk_export_records_stream(ofk_ctx *c, float *device_dst, int batch, hipStrea
 void ofk_jpeg_release(ofk_ctx *c);
 int ofk_jpeg_stage_streams(ofk_ctx *c, int slot, const uint8_t *const *jpeg, const size_t *nbytes, int count);
 int ofk_jpeg_decode_staged_pairs(ofk_ctx *c, int slot, uint8_t *dst_prev, uint8_t *dst_next, size_t dst_stride, size_t dst_capacity_px, int *batch_out,
-                                 int *h_out, int *w_out, hipEvent_t wait_before_writing);   // non-NULL event: decode on the ingest stream, beside whatever runs on the context's
+                                 int *h_out, int *w_out, const hipEvent_t *wait_before_writing, int nwait, int as_gray);
+                                 // wait_before_writing != NULL: decode on the ingest stream, beside whatever runs on the context's, behind those events;
+                                 // as_gray: dst_* are gray planes (rows of w bytes; what k_gray_bgr8 would make of the decoded BGR frame), no BGR is written
 int ofk_jpeg_decode_device(ofk_ctx *c, const uint8_t *const *jpeg, const size_t *nbytes, int batch, uint8_t *dst, size_t dst_stride,
                            size_t dst_capacity_px, int *h_out, int *w_out, uint8_t **out, size_t *out_stride);   // k_jpeg.hip
 

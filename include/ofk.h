@@ -225,8 +225,11 @@ typedef struct ofk_params {
 int ofk_pairs_upload(ofk_ctx *ctx, const uint8_t *prev_bgr, const uint8_t *next_bgr, int batch, int h, int w);
 /* The same from compressed frames: jpeg[i] / nbytes[i] = one baseline JPEG stream per frame (the payload of a
  * sensor_msgs/CompressedImage; the reference decodes it with cv_bridge.compressed_imgmsg_to_cv2 = cv::imdecode,
- * velocity_measurment_node.py:112).  All frames of a call must share size and chroma sampling.  Decoded on the device straight
- * into the resident buffers; pixels identical to libjpeg's default decompressor (see ofk_jpeg_decode_bgr8). */
+ * velocity_measurment_node.py:112).  All frames of a call must share size and chroma sampling.  Decoded on the device; pixels
+ * identical to libjpeg's default decompressor (see ofk_jpeg_decode_bgr8).  On the default schedule (one slice, overlap on) the
+ * decoder's colour kernel applies the pipeline's BGR -> gray conversion (node:113 cv2.cvtColor) to every pixel itself and writes the
+ * gray frame straight into the pyramid set the next ofk_pairs_run takes: the BGR frame is never stored and that run skips its
+ * first stage - same bytes in the gray level as after ofk_pairs_upload of the decoded frames. */
 int ofk_pairs_upload_jpeg(ofk_ctx *ctx, const uint8_t *const *prev_jpeg, const size_t *prev_bytes, const uint8_t *const *next_jpeg,
                           const size_t *next_bytes, int batch);
 /* The same in two phases, so that a camera loop can hide the host's share of the ingest (marker parse, staging copy, PCIe) behind
@@ -237,7 +240,8 @@ int ofk_pairs_upload_jpeg(ofk_ctx *ctx, const uint8_t *const *prev_jpeg, const s
  *       other entry point - as long as that is not the decode of the same slot.
  *   ofk_pairs_upload_staged(ctx, slot)               device: decodes the 2 B streams staged in `slot` - the B previous frames
  *       first, then the B next frames - into the resident frame-pair buffers (what ofk_pairs_upload_jpeg does after staging
- *       slot 0 itself).  A slot is decoded once.
+ *       slot 0 itself).  A slot is decoded once.  On the default schedule the decoder runs on a stream of its own and writes the
+ *       pyramid set the ofk_pairs_run in flight is not using, so it overlaps that run.
  * Loop: stage(0, batch 0); for k: { stage(k+1 & 1, batch k+1) on the helper thread; upload_staged(k & 1); ofk_pairs_run; }.
  * pipeline.FlowPipeline.run_jpeg_batches does exactly that; bench.py reports its rate as ingest_inclusive.jpeg_double_buffered. */
 int ofk_jpeg_stage(ofk_ctx *ctx, int slot, const uint8_t *const *jpeg, const size_t *nbytes, int count);

@@ -112,6 +112,26 @@ def test_device_decoder_vs_oracle_large(pkg, ofk, h, w, ss, q):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("h,w,ss,q,opts", [(240, 320, 0, 100, {}), (480, 640, 2, 98, {}), (360, 488, 1, 100, {"optimize": True}),
+                                           (480, 640, 2, 100, {"restart_marker_blocks": 3}), (1080, 1920, 2, 85, {"optimize": True})])
+def test_device_decoder_high_entropy(pkg, ofk, h, w, ss, q, opts):
+    """White noise at the top qualities: every zigzag position of almost every block is non-zero (the write pass's direct path behind
+    position 32 carries half of the coefficients), FF bytes and stuffed zeros are as frequent as they get (the byte-wise refill),
+    codes run past the 9-bit look-ahead all the time (the long-code search), and `optimize` swaps the standard Huffman tables
+    for ones fitted to the image."""
+    rng = np.random.default_rng(h * 7 + w + q)
+    frames = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for _ in range(2)]
+    from of_amd import synth
+    frames.append(np.ascontiguousarray(synth.render_pair(h, w, 760)["prev"]))
+    streams = [_encode(f, q, ss, **opts) for f in frames]
+    ctx = ofk.Context(0, w, h, 3, 64, 1)
+    out = ctx.jpeg_decode(streams)
+    for k in range(3):
+        assert np.array_equal(out[k], jo.decode(streams[k])), k
+    ctx.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("h,w,ss,opts", [(1080, 1920, 2, {"restart_marker_rows": 1}), (720, 1280, 2, {"restart_marker_blocks": 7}),
                                          (480, 640, 1, {"restart_marker_blocks": 1}), (1080, 1920, None, {"restart_marker_rows": 4})])
 def test_device_decoder_restart_intervals(pkg, ofk, h, w, ss, opts):
