@@ -24,6 +24,34 @@ __global__ void k_check(unsigned long long *bad_total, unsigned *bad_per_exp, un
     if (bad) atomicAdd(bad_total, (unsigned long long)bad);
 }
 
+// The product's fix-up (k_corners.hip sqrt_rn_normal: v_sqrt_f32, two fused residuals, two v_med3_i32 + v_add3_u32 on the bit patterns)
+// over every input it can meet: x = 0 and the normal range from 2^-100 up.
+__device__ __forceinline__ float sqrt_rn_normal(float x)
+{
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float dn = __int_as_float(__float_as_int(s) - 1), up = __int_as_float(__float_as_int(s) + 1);
+    const float rdn = __builtin_fmaf(-dn, s, x), rup = __builtin_fmaf(-up, s, x);
+    int idn, iup, r;
+    asm("v_med3_i32 %0, %1, 0, 1" : "=v"(idn) : "v"(rdn));
+    asm("v_med3_i32 %0, %1, 0, 1" : "=v"(iup) : "v"(rup));
+    asm("v_add3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(dn), "v"(idn), "v"(iup));
+    return __int_as_float(r);
+}
+
+__global__ void k_check_fixup(unsigned long long *bad_total, unsigned *first_bad)
+{
+    const unsigned long long i0 = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) * 256ull;
+    unsigned bad = 0;
+    for (unsigned k = 0; k < 256; ++k) {
+        const unsigned bits = (unsigned)(i0 + k);
+        if (bits >= 0x7f000000u) break;                          // the fix-up's s + 1 ulp must stay finite
+        if (bits != 0 && bits < (27u << 23)) continue;           // below 2^-100: outside the contract
+        const float x = __uint_as_float(bits);
+        if (__float_as_uint(sqrt_rn_normal(x)) != __float_as_uint((float)sqrt((double)x))) { ++bad; atomicMin(first_bad, bits); }
+    }
+    if (bad) atomicAdd(bad_total, (unsigned long long)bad);
+}
+
 int main()
 {
     unsigned long long *d_total, total = 0;
@@ -40,5 +68,11 @@ int main()
     int shown = 0;
     for (int e = 0; e < 255 && shown < 12; ++e)
         if (per_exp[e]) { printf("  biased exponent %3d: %u mismatches of 8388608\n", e, per_exp[e]); ++shown; }
-    return 0;
+    total = 0; first = 0xffffffffu;
+    hipMemset(d_total, 0, 8); hipMemcpy(d_first, &first, 4, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_check_fixup, dim3(blocks), dim3(256), 0, 0, d_total, d_first);
+    hipDeviceSynchronize();
+    hipMemcpy(&total, d_total, 8, hipMemcpyDeviceToHost); hipMemcpy(&first, d_first, 4, hipMemcpyDeviceToHost);
+    printf("sqrt_rn_normal (product fix-up) != correctly rounded: %llu (first at bits 0x%08x)\n", total, first);
+    return total ? 1 : 0;
 }
