@@ -376,6 +376,11 @@ __device__ __forceinline__ int box_row(int a, int ad2, int ad4, int adl)
 #define OFK_SEG_KEY(bits, idx) (((unsigned long long)(unsigned)(bits) << 32) | (unsigned)(idx))
 #define OFK_SEG_KEY_DECODE(k) (~(k))
 #ifndef OFK_KEYS_ATOM
+// experiment: interior rows take the pair sums of the products from one v_mad_i32_i24 each instead of multiply + add: 21 VALU instructions
+// fewer per 7 rows and 2.3 % SLOWER alone (1.913 against 1.869 ms per 512 frames): the three-operand multiply issues slower than the pair
+#ifndef OFK_PAIR_MAD
+#define OFK_PAIR_MAD 0
+#endif
 #ifndef OFK_SQRT_SELECT
 #define OFK_SQRT_SELECT 0
 #endif
@@ -638,9 +643,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 //     only) — no byte-load path.
 // Integer sums and the f32 formula are those of k_mineig_stream (and of the oracle), so results are bit-identical.
 template <int K>
-__device__ __forceinline__ void box_pair(int ae, int ao, int ad2, int ad3, int &he, int &ho)
+__device__ __forceinline__ void box_pair_q(int ae, int ao, int q, int ad2, int ad3, int &he, int &ho);
+template <int K>
+__device__ __forceinline__ void box_pair(int ae, int ao, int ad2, int ad3, int &he, int &ho) { box_pair_q<K>(ae, ao, ae + ao, ad2, ad3, he, ho); }
+// ... with the pair sum q = a_e + a_o handed in (interior rows get it from one v_mad_i32_i24; a_e itself is only needed for K == 1)
+template <int K>
+__device__ __forceinline__ void box_pair_q(int ae, int ao, int q, int ad2, int ad3, int &he, int &ho)
 {
-    const int q = ae + ao;
     if constexpr (K == 1) {
         ho = DPP_SHR1(ao) + q;
         he = ae + DPP_SHR1(q);
@@ -720,19 +729,32 @@ __device__ __forceinline__ int lambda_min_bits(int vxx, int vxy, int vyy, float 
         asm("" : "+v"(uye), "+v"(uyo));                               /* where the compiler forms v_mov_b32_dpp + v_add3_u32 (8) */ \
         const int dye = uye + tt;                                                                                      \
         const int dyo = uyo + tt;                                                                                      \
-        int pxxe = __mul24(dxe, dxe), pyye = __mul24(dye, dye), pxye = __mul24(dxe, dye);                              \
-        int pxxo = __mul24(dxo, dxo), pyyo = __mul24(dyo, dyo), pxyo = __mul24(dxo, dyo);                              \
-        asm("" : "+v"(pxxe), "+v"(pxye), "+v"(pyye), "+v"(pxxo), "+v"(pxyo), "+v"(pyyo));                              \
-        if (!(IN)) {                                                                                                   \
-            const int Y = Yp0 + r - 2;                                                                                 \
-            const bool rowflip = (Y < 0) | (Y >= h);                                                                   \
-            pxye = (rowflip != flip_e) ? -pxye : pxye;                                                                 \
-            pxyo = (rowflip != flip_o) ? -pxyo : pxyo;                                                                 \
-        }                                                                                                              \
         int hxxe, hxxo, hxye, hxyo, hyye, hyyo;                                                                        \
-        box_pair<BS / 2>(pxxe, pxxo, ad2, ad3, hxxe, hxxo);                                                            \
-        box_pair<BS / 2>(pxye, pxyo, ad2, ad3, hxye, hxyo);                                                            \
-        box_pair<BS / 2>(pyye, pyyo, ad2, ad3, hyye, hyyo);                                                            \
+        if ((IN) && BS > 3 && OFK_PAIR_MAD) {                                                                      \
+            /* experiment OFK_PAIR_MAD: the box sums only take the odd product and the pair sum; the pair sum from ONE v_mad_i32_i24 */ \
+            int pxxo = __mul24(dxo, dxo), pyyo = __mul24(dyo, dyo), pxyo = __mul24(dxo, dyo);                          \
+            asm("" : "+v"(pxxo), "+v"(pxyo), "+v"(pyyo));                                                              \
+            int qxx, qyy, qxy;                                                                                         \
+            asm("v_mad_i32_i24 %0, %1, %1, %2" : "=v"(qxx) : "v"(dxe), "v"(pxxo));                                     \
+            asm("v_mad_i32_i24 %0, %1, %1, %2" : "=v"(qyy) : "v"(dye), "v"(pyyo));                                     \
+            asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(qxy) : "v"(dxe), "v"(dye), "v"(pxyo));                           \
+            box_pair_q<BS / 2>(0, pxxo, qxx, ad2, ad3, hxxe, hxxo);                                                    \
+            box_pair_q<BS / 2>(0, pxyo, qxy, ad2, ad3, hxye, hxyo);                                                    \
+            box_pair_q<BS / 2>(0, pyyo, qyy, ad2, ad3, hyye, hyyo);                                                    \
+        } else {                                                                                                       \
+            int pxxe = __mul24(dxe, dxe), pyye = __mul24(dye, dye), pxye = __mul24(dxe, dye);                          \
+            int pxxo = __mul24(dxo, dxo), pyyo = __mul24(dyo, dyo), pxyo = __mul24(dxo, dyo);                          \
+            asm("" : "+v"(pxxe), "+v"(pxye), "+v"(pyye), "+v"(pxxo), "+v"(pxyo), "+v"(pyyo));                          \
+            if (!(IN)) {                                                                                               \
+                const int Y = Yp0 + r - 2;                                                                             \
+                const bool rowflip = (Y < 0) | (Y >= h);                                                               \
+                pxye = (rowflip != flip_e) ? -pxye : pxye;                                                             \
+                pxyo = (rowflip != flip_o) ? -pxyo : pxyo;                                                             \
+            }                                                                                                          \
+            box_pair<BS / 2>(pxxe, pxxo, ad2, ad3, hxxe, hxxo);                                                        \
+            box_pair<BS / 2>(pxye, pxyo, ad2, ad3, hxye, hxyo);                                                        \
+            box_pair<BS / 2>(pyye, pyyo, ad2, ad3, hyye, hyyo);                                                        \
+        }                                                                                                              \
         vxxe += hxxe - rxxe[i]; vxye += hxye - oxye; vyye += hyye - oyye;                                              \
         vxxo += hxxo - rxxo[i]; vxyo += hxyo - oxyo; vyyo += hyyo - oyyo;                                              \
         rxxe[i] = hxxe; rxxo[i] = hxxo;                                                                                \
