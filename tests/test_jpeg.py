@@ -208,6 +208,47 @@ def test_double_buffered_ingest_matches_the_one_shot_path(pkg, ofk, streams_per_
 
 
 @pytest.mark.gpu
+def test_gray_direct_ingest_state_machine(pkg, ofk):
+    """The compressed ingest writes the gray frames straight into one pyramid set and no BGR frame (ofk_pairs_upload_staged on the
+    default schedule): a second run without a new upload, a run after the schedule changed to two slices, odd frame sizes (the byte
+    store path of the colour kernel), the resident gray level itself, and a raw upload afterwards must all behave as if the decoded
+    frames had been uploaded."""
+    from of_amd import synth
+    from of_amd.pipeline import FlowPipeline, PipelineConfig
+    for (h, w) in ((480, 640), (250, 332)):
+        B = 3
+        pairs = [synth.render_pair(h, w, 140 + b) for b in range(B)]
+        sp = [_encode(p["prev"], 90, 2) for p in pairs]
+        sn = [_encode(p["next"], 90, 2) for p in pairs]
+        dp, dn = np.stack([jo.decode(s) for s in sp]), np.stack([jo.decode(s) for s in sn])
+        sensors = ofk.make_sensors(B, scaling=pairs[0]["scaling"], cx=pairs[0]["cx"], cy=pairs[0]["cy"])
+        cfg = PipelineConfig(max_corners=100, quality=0.03, min_distance=7, max_level=2)
+        pipe = FlowPipeline(w, h, B, cfg)
+        pipe.upload(dp, dn, sensors)
+        ref = pipe.run()
+        ref_pyr = pipe.ctx.resident_pyramid(0, 1, h, w, 2)
+        keys = ("counts", "prev_pts", "next_pts", "status", "records")
+        same = lambda out, what: [np.testing.assert_array_equal(out[k], ref[k], err_msg=f"{what}: {k} ({h}x{w})") for k in keys]
+        pipe.ctx.pairs_upload_jpeg(sp, sn)
+        same(pipe.run(), "first run")
+        got_pyr = pipe.ctx.resident_pyramid(0, 1, h, w, 2)                       # level 0 = the gray frame the decoder wrote
+        assert all(np.array_equal(a, b) for a, b in zip(got_pyr, ref_pyr))
+        same(pipe.run(), "second run on the same upload")
+        same(pipe.run(), "third run")
+        pipe.ctx.pairs_upload_jpeg(sp, sn)
+        pipe.ctx.set_streams(2)
+        same(pipe.run(), "two slices after a one-slice ingest")
+        pipe.ctx.pairs_upload_jpeg(sp, sn)                                      # two slices: the BGR way
+        same(pipe.run(), "ingest under two slices")
+        pipe.ctx.set_streams(1)
+        pipe.ctx.pairs_upload_jpeg(sp[::-1], sn[::-1])                          # other frames in between
+        pipe.run()
+        pipe.upload(dp, dn, sensors)
+        same(pipe.run(), "raw upload after a gray-direct ingest")
+        pipe.close()
+
+
+@pytest.mark.gpu
 def test_decoder_chunk_size_does_not_change_pixels(pkg, ofk, gold):
     """ofk_set_tuning("jpeg_chunk"): 64 / 128 / 256 entropy bytes per decoder thread - other chunk boundaries, other synchronisation
     histories, the same pixels."""
