@@ -498,9 +498,13 @@ __device__ inline void jidct8(const int *in, int *o)
 }
 
 __device__ inline uint32_t jrange_limit(int x)
-{   // jdmaster.c prepare_range_limit_table, post-IDCT half, index x & 1023
-    const int i = x & 1023;
-    return (uint32_t)(i < 128 ? i + 128 : i < 512 ? 255 : i < 896 ? 0 : i - 896);
+{   // jdmaster.c prepare_range_limit_table, post-IDCT half, index i = x & 1023: i < 128 -> i + 128, < 512 -> 255, < 896 -> 0, else i - 896.
+    // With t = the index read as a signed 10-bit number that is clamp(t + 128, 0, 255) in every one of the four ranges: one
+    // sign-extending field extract, one add, one v_med3_i32 instead of three compares and three selects (eight times per lane).
+    const int v = ((x << 22) >> 22) + 128;
+    int r;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(v), "v"(255));
+    return (uint32_t)r;
 }
 
 // 8 lanes per block, 32 blocks per workgroup
@@ -532,7 +536,7 @@ __global__ __launch_bounds__(256) void k_jpeg_idct(const jpeg_tab *__restrict__ 
         by = (m / g.mcux) * (comp == 0 ? g.vmax : 1) + jj / hs;
         int in[8], o[8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) in[r] = (int)cz[lb][izz[r * 8 + c]] * (int)qs[comp][r * 8 + c];
+        for (int r = 0; r < 8; ++r) in[r] = __mul24((int)cz[lb][izz[r * 8 + c]], (int)qs[comp][r * 8 + c]);   // 16 x 16 bits: exact in the 24-bit multiplier
         jidct8(in, o);
 #pragma unroll
         for (int r = 0; r < 8; ++r) ws[lb][r * 9 + c] = (o[r] + (1 << 10)) >> 11;
