@@ -507,55 +507,73 @@ __device__ inline uint32_t jrange_limit(int x)
     return (uint32_t)r;
 }
 
-// 8 lanes per block, 32 blocks per workgroup
+// 8 lanes per block, 32 blocks per step; a workgroup walks along ONE MCU row of one image: the block's place in the planes follows from
+// the step counter with one multiply-shift (the divisions by blocks-per-MCU and MCUs-per-row of a flat block index were 15 % of the
+// kernel's instructions), the quantiser tables are loaded once per row, and the next step's coefficients are in flight during both passes.
 __global__ __launch_bounds__(256) void k_jpeg_idct(const jpeg_tab *__restrict__ tabs, jpeg_geom g, const int16_t *__restrict__ coef,
-                                                   const int16_t *__restrict__ dcarr, uint8_t *__restrict__ planes)
+                                                   const int16_t *__restrict__ dcarr, uint8_t *__restrict__ planes, unsigned bpm_magic)
 {
     __shared__ int ws[32][72];
     __shared__ int16_t cz[32][72];                                // the blocks as stored (zigzag order), one 16-byte load per lane
     __shared__ uint16_t qs[3][64];
-    __shared__ uint8_t izz[64];
-    const int b = blockIdx.y;
+    const int b = blockIdx.y, mrow = blockIdx.x;
     const int lb = threadIdx.x >> 3, c = threadIdx.x & 7;
-    const int n = blockIdx.x * 32 + lb;
-    const bool live = n < g.nblk;
-    int comp = 0, bx = 0, by = 0;
     if (threadIdx.x < 192) qs[threadIdx.x >> 6][threadIdx.x & 63] = tabs[b].q[threadIdx.x >> 6][threadIdx.x & 63];
-    else izz[threadIdx.x - 192] = c_izz[threadIdx.x - 192];
-    if (live) {
-        *reinterpret_cast<uint4 *>(&cz[lb][8 * c]) = reinterpret_cast<const uint4 *>(coef + ((size_t)b * g.nblk + n) * 64)[c];
-        if (c == 0) cz[lb][0] = dcarr[(size_t)b * g.nblk + n];     // the predicted DC (the block holds the difference)
+    unsigned zlo = 0, zhi = 0;                                    // zigzag positions of this lane's column, rows 0..3 / 4..7
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { zlo |= (unsigned)c_izz[r * 8 + c] << (8 * r); zhi |= (unsigned)c_izz[(r + 4) * 8 + c] << (8 * r); }
+    const int nrow = g.mcux * g.bpm, ny = g.comp_nb[0];
+    const size_t nbase = (size_t)b * g.nblk + (size_t)mrow * nrow;
+    uint4 nv = make_uint4(0, 0, 0, 0);
+    int16_t ndc = 0;
+    if (lb < nrow) {
+        nv = reinterpret_cast<const uint4 *>(coef + (nbase + lb) * 64)[c];
+        if (c == 0) ndc = dcarr[nbase + lb];
     }
-    __syncthreads();
-    if (live) {
-        const int m = n / g.bpm, j = n % g.bpm, ny = g.comp_nb[0];
-        comp = j < ny ? 0 : j - ny + 1;
-        const int jj = comp == 0 ? j : 0;
-        const int hs = comp == 0 ? g.hmax : 1;
-        bx = (m % g.mcux) * hs + jj % hs;
-        by = (m / g.mcux) * (comp == 0 ? g.vmax : 1) + jj / hs;
-        int in[8], o[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) in[r] = __mul24((int)cz[lb][izz[r * 8 + c]], (int)qs[comp][r * 8 + c]);   // 16 x 16 bits: exact in the 24-bit multiplier
-        jidct8(in, o);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) ws[lb][r * 9 + c] = (o[r] + (1 << 10)) >> 11;
-    }
-    __syncthreads();
-    if (live) {
-        int in[8], o[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) in[k] = ws[lb][c * 9 + k];                    // this lane's row = c
-        jidct8(in, o);
-        uint32_t lo = 0, hi = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            lo |= jrange_limit((o[k] + (1 << 17)) >> 18) << (8 * k);
-            hi |= jrange_limit((o[k + 4] + (1 << 17)) >> 18) << (8 * k);
+    for (int l0 = 0; l0 < nrow; l0 += 32) {
+        const int local = l0 + lb;
+        const bool live = local < nrow;
+        *reinterpret_cast<uint4 *>(&cz[lb][8 * c]) = nv;
+        if (c == 0) cz[lb][0] = ndc;                               // the predicted DC (the block holds the difference)
+        __syncthreads();
+        if (local + 32 < nrow) {
+            nv = reinterpret_cast<const uint4 *>(coef + (nbase + local + 32) * 64)[c];
+            if (c == 0) ndc = dcarr[nbase + local + 32];
         }
-        uint8_t *pl = planes + (size_t)b * g.plane_stride + g.plane_off[comp];
-        uint2 *dst = (uint2 *)(pl + (size_t)(by * 8 + c) * g.pw[comp] + bx * 8);
-        *dst = make_uint2(lo, hi);
+        int comp = 0, bx = 0, by = 0;
+        if (live) {
+            const int mx = (int)(((unsigned)local * bpm_magic) >> 20), j = local - mx * g.bpm;
+            comp = j < ny ? 0 : j - ny + 1;
+            const int jj = comp == 0 ? j : 0;
+            const int hs = comp == 0 ? g.hmax : 1;                // 1 or 2
+            bx = mx * hs + (jj & (hs - 1));
+            by = mrow * (comp == 0 ? g.vmax : 1) + (jj >> (hs - 1));
+            int in[8], o[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int zp = (int)(((r < 4 ? zlo : zhi) >> (8 * (r & 3))) & 255u);
+                in[r] = __mul24((int)cz[lb][zp], (int)qs[comp][r * 8 + c]);   // 16 x 16 bits: exact in the 24-bit multiplier
+            }
+            jidct8(in, o);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) ws[lb][r * 9 + c] = (o[r] + (1 << 10)) >> 11;
+        }
+        __syncthreads();
+        if (live) {
+            int in[8], o[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) in[k] = ws[lb][c * 9 + k];                // this lane's row = c
+            jidct8(in, o);
+            uint32_t lo = 0, hi = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                lo |= jrange_limit((o[k] + (1 << 17)) >> 18) << (8 * k);
+                hi |= jrange_limit((o[k + 4] + (1 << 17)) >> 18) << (8 * k);
+            }
+            uint8_t *pl = planes + (size_t)b * g.plane_stride + g.plane_off[comp];
+            uint2 *dst = (uint2 *)(pl + (size_t)(by * 8 + c) * g.pw[comp] + bx * 8);
+            *dst = make_uint2(lo, hi);
+        }
     }
 }
 
@@ -1044,7 +1062,7 @@ static int jdecode_staged(ofk_ctx *c, int slot, uint8_t *dst, uint8_t *dst2, int
     OFK_HIP(c, hipStreamWaitEvent(st, js->zeroed, 0));
     hipLaunchKernelGGL(k_jpeg_write, dim3((nch_max + JTPW - 1) / JTPW, batch), dim3(JTPW), 0, st, dt, dent, g, nch_max, state, base, coef, dcarr, endinfo);
     hipLaunchKernelGGL(k_jpeg_dc, dim3(batch, g.ncomp), dim3(1024), 0, st, dt, g, dcarr);
-    hipLaunchKernelGGL(k_jpeg_idct, dim3((g.nblk + 31) / 32, batch), dim3(256), 0, st, dt, g, coef, dcarr, planes);
+    hipLaunchKernelGGL(k_jpeg_idct, dim3(g.mcuy, batch), dim3(256), 0, st, dt, g, coef, dcarr, planes, (unsigned)(((1u << 20) + g.bpm - 1) / g.bpm));
     hipLaunchKernelGGL(k_jpeg_color, dim3((g.w + 511) / 512, (g.h + 3) / 4, batch), dim3(64, 4), 0, st, g, planes, dst, dst2, split, dst_stride, as_gray);
     hipLaunchKernelGGL(k_jpeg_ints_to_host, dim3(4), dim3(256), 0, st, endinfo, js->hmap_dev + JMAX_ITERS, 2 * batch);
     hipError_t e = hipStreamSynchronize(st);
