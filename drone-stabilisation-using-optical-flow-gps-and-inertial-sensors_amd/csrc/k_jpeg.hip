@@ -583,9 +583,9 @@ __device__ inline int jclamp8(int x) { return x < 0 ? 0 : x > 255 ? 255 : x; }
 // (jdsample.c h2v1_fancy_upsample / h2v2_fancy_upsample; context rows replicated at the top and bottom edge as jdmainct.c does).
 // The four chroma columns under the pixels come in as one dword per row, their two neighbours as bytes.
 __device__ inline void jchroma8(const uint8_t *__restrict__ pl, int pitch, int cw, int ch, int hmax, int vmax, int x0, int y, int *out)
-{
+{   // (offsets inside a plane are 32-bit: the plane base is uniform, so the loads take it from scalar registers)
     if (hmax == 1) {
-        const uint2 v = *(const uint2 *)(pl + (size_t)y * pitch + x0);
+        const uint2 v = *(const uint2 *)(pl + (unsigned)(y * pitch + x0));
 #pragma unroll
         for (int k = 0; k < 4; ++k) { out[k] = (v.x >> (8 * k)) & 255; out[k + 4] = (v.y >> (8 * k)) & 255; }
         return;
@@ -594,9 +594,9 @@ __device__ inline void jchroma8(const uint8_t *__restrict__ pl, int pitch, int c
     const int cl = cx0 > 0 ? cx0 - 1 : 0, cr = cx0 + 4 < cw ? cx0 + 4 : cw - 1;
     int t[6];
     if (vmax == 1) {
-        const uint8_t *in = pl + (size_t)y * pitch;
-        const uint32_t m = *(const uint32_t *)(in + cx0);
-        t[0] = in[cl]; t[5] = in[cr];
+        const unsigned ro = (unsigned)(y * pitch);
+        const uint32_t m = *(const uint32_t *)(pl + (ro + cx0));
+        t[0] = pl[ro + cl]; t[5] = pl[ro + cr];
 #pragma unroll
         for (int k = 0; k < 4; ++k) t[k + 1] = (m >> (8 * k)) & 255;
 #pragma unroll
@@ -610,9 +610,9 @@ __device__ inline void jchroma8(const uint8_t *__restrict__ pl, int pitch, int c
     const int r0 = y >> 1;
     int r1 = (y & 1) ? r0 + 1 : r0 - 1;
     r1 = r1 < 0 ? 0 : r1 > ch - 1 ? ch - 1 : r1;
-    const uint8_t *i0 = pl + (size_t)r0 * pitch, *i1 = pl + (size_t)r1 * pitch;
-    const uint32_t m0 = *(const uint32_t *)(i0 + cx0), m1 = *(const uint32_t *)(i1 + cx0);
-    t[0] = i0[cl] * 3 + i1[cl]; t[5] = i0[cr] * 3 + i1[cr];
+    const unsigned o0 = (unsigned)(r0 * pitch), o1 = (unsigned)(r1 * pitch);
+    const uint32_t m0 = *(const uint32_t *)(pl + (o0 + cx0)), m1 = *(const uint32_t *)(pl + (o1 + cx0));
+    t[0] = pl[o0 + cl] * 3 + pl[o1 + cl]; t[5] = pl[o0 + cr] * 3 + pl[o1 + cr];
 #pragma unroll
     for (int k = 0; k < 4; ++k) t[k + 1] = (int)((m0 >> (8 * k)) & 255) * 3 + (int)((m1 >> (8 * k)) & 255);
 #pragma unroll
@@ -635,13 +635,13 @@ __global__ __launch_bounds__(256) void k_jpeg_color(jpeg_geom g, const uint8_t *
     if (x0 >= g.w || y >= g.h) return;
     const uint8_t *pl = planes + (size_t)b * g.plane_stride;
     uint8_t *o = (b < split ? bgr + (size_t)b * bgr_stride : bgr2 + (size_t)(b - split) * bgr_stride) + ((size_t)y * g.w + x0) * 3;   // pairs: previous frames | next frames
-    const uint2 y8 = *(const uint2 *)(pl + g.plane_off[0] + (size_t)y * g.pw[0] + x0);              // pw is a multiple of 8
+    const uint2 y8 = *(const uint2 *)(pl + g.plane_off[0] + (unsigned)(y * g.pw[0] + x0));           // pw is a multiple of 8
     uint8_t px[24];
     if (g.ncomp == 1) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) px[3 * k] = px[3 * k + 1] = px[3 * k + 2] = (uint8_t)(((k < 4 ? y8.x : y8.y) >> (8 * (k & 3))) & 255);
     } else {
-        const int cw = (g.w + g.hmax - 1) / g.hmax, ch = (g.h + g.vmax - 1) / g.vmax;
+        const int cw = (g.w + g.hmax - 1) >> (g.hmax - 1), ch = (g.h + g.vmax - 1) >> (g.vmax - 1);    // sampling factors are 1 or 2
         int cb[8], cr[8];
         jchroma8(pl + g.plane_off[1], g.pw[1], cw, ch, g.hmax, g.vmax, x0, y, cb);
         jchroma8(pl + g.plane_off[2], g.pw[2], cw, ch, g.hmax, g.vmax, x0, y, cr);
@@ -649,9 +649,10 @@ __global__ __launch_bounds__(256) void k_jpeg_color(jpeg_geom g, const uint8_t *
         for (int k = 0; k < 8; ++k) {
             const int Y = ((k < 4 ? y8.x : y8.y) >> (8 * (k & 3))) & 255, u = cb[k] - 128, v = cr[k] - 128;
             // jdcolor.c build_ycc_rgb_table: SCALEBITS 16, FIX(1.40200) = 91881, FIX(1.77200) = 116130, FIX(0.71414) = 46802, FIX(0.34414) = 22554
-            px[3 * k] = (uint8_t)jclamp8(Y + ((116130 * u + 32768) >> 16));
-            px[3 * k + 1] = (uint8_t)jclamp8(Y + ((-22554 * u + 32768 - 46802 * v) >> 16));
-            px[3 * k + 2] = (uint8_t)jclamp8(Y + ((91881 * v + 32768) >> 16));
+            // (17-bit constants x 9-bit chroma: exact in the 24-bit multiplier, half the issue cost of v_mul_lo_u32)
+            px[3 * k] = (uint8_t)jclamp8(Y + ((__mul24(116130, u) + 32768) >> 16));
+            px[3 * k + 1] = (uint8_t)jclamp8(Y + ((__mul24(-22554, u) + 32768 + __mul24(-46802, v)) >> 16));
+            px[3 * k + 2] = (uint8_t)jclamp8(Y + ((__mul24(91881, v) + 32768) >> 16));
         }
     }
     if (as_gray) {
