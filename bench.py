@@ -33,7 +33,9 @@ The JSON line also carries
                  kernel is bound by VALU issue, so `bound` is "valu": achieved = wave-level VALU instructions per launch
                  (committed SQ_INSTS_VALU count, profiles/r02_valu_pmc.json) / that duration, peak = one wave instruction per
                  2 clocks per SIMD at 2.4 GHz on 1024 SIMDs (MI355X_MICROARCH.md) = 1228.8 G/s; `isa_mix` prices the same
-                 kernel against the issue cycles of its own instruction mix (profiles/r02_isa_mix.json); `hbm` keeps the
+                 kernel against the issue cycles of its own instruction mix (profiles/<tag>_isa_mix.json), once at 2.4 GHz and
+                 once at the rate the chip sustains (v_add_u32 back to back on every SIMD: tools/valu_rates.hip,
+                 profiles/<tag>_valu_rates.txt: 0.96 ns per wave-instruction per SIMD, 86 % of the 2.4 GHz figure); `hbm` keeps the
                  HBM view (SURVEY.md §8(d) algorithmic bytes per launch / the same duration) and `traffic` the HBM bytes per
                  launch from the committed PMC passes (profiles/r02_traffic_pmc.json).
   north_star_group : SURVEY.md §8(d)'s "pyramid + LK group" = (G_pyr + G_lk) x B / (t_pyr + t_lk), serial-pass times.
@@ -159,8 +161,20 @@ def isa_mix_roof(stage, pairs_per_launch, isolated_ms):
     try:
         cyc = t["stages"][stage]["valu_issue_cycles_per_pair"] * pairs_per_launch
         floor_ms = cyc / (1024 * 2.4e9) * 1e3
-        return {"issue_floor_ms": round(floor_ms, 4), "frac": round(floor_ms / isolated_ms, 4),
-                "mean_cycles_per_valu_instr": t["stages"][stage].get("mean_cycles_per_valu_instr"), "source": f"profiles/{tag}_isa_mix.json"}
+        out = {"issue_floor_ms": round(floor_ms, 4), "frac": round(floor_ms / isolated_ms, 4),
+               "mean_cycles_per_valu_instr": t["stages"][stage].get("mean_cycles_per_valu_instr"), "source": f"profiles/{tag}_isa_mix.json"}
+        # the same against the rate the chip SUSTAINS: tools/valu_rates.hip measures v_add_u32 (2 issue clocks) back to back on every
+        # SIMD at 0.95 ns per wave-instruction per SIMD, i.e. 1.05 T/s chip-wide where 2.4 GHz would give 1.2288 T/s
+        rates = os.path.join(ROOT, "profiles", f"{tag}_valu_rates.txt")
+        if os.path.exists(rates):
+            import re
+            m = re.search(r"^v_add_u32\s+[\d.]+ ms\s+([\d.]+) ns/instr/SIMD", open(rates).read(), re.M)
+            if m:
+                ns_per_clock = float(m.group(1)) / 2.0
+                sustained_ms = cyc / 1024 * ns_per_clock * 1e-6
+                out.update({"issue_floor_ms_at_measured_rate": round(sustained_ms, 4), "frac_at_measured_rate": round(sustained_ms / isolated_ms, 4),
+                            "measured_full_rate_ns_per_wave_instr_per_simd": float(m.group(1)), "rates_source": f"profiles/{tag}_valu_rates.txt"})
+        return out
     except Exception:
         return None
 

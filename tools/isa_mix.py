@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Instruction mix of the VALU-bound kernels' hot loops and the issue-cycle floor that mix implies (runs without a GPU).
 
-  python tools/isa_mix.py [--rates profiles/r02_valu_rates.txt] [--valu profiles/r03_valu_pmc.json] > profiles/r03_isa_mix.json
+  python tools/isa_mix.py [--rates profiles/r03_valu_rates.txt] [--valu profiles/r03_valu_pmc.json] > profiles/r03_isa_mix.json
 
 1. hipcc -S (device only, the product's flags) of k_corners.hip and k_lk.hip.
 2. k_mineig_pair<7,false>: the main loop holds 7 unrolled rows twice (border version, interior version; 2 v_sqrt_f32 per row).
@@ -139,7 +139,7 @@ def pair_interior_rows(body):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--rates", default=os.path.join(ROOT, "profiles", "r02_valu_rates.txt"))
+    ap.add_argument("--rates", default=os.path.join(ROOT, "profiles", "r03_valu_rates.txt"))
     ap.add_argument("--valu", default=os.path.join(ROOT, "profiles", "r03_valu_pmc.json"))
     args = ap.parse_args()
     rates = load_rates(args.rates)

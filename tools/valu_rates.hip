@@ -179,6 +179,24 @@ KERNEL(k_add_sdwa, A_ADD_SDWA)
 KERNEL(k_alignbyte_v, A_ALIGNBYTE_V)
 KERNEL(k_dot2_s, A_DOT2_S)
 
+// Which clock does the chip hold while every SIMD issues VALU instructions back to back?  One lane per workgroup reads the shader
+// cycle counter (s_memtime) and the constant-rate counter (s_memrealtime) around ITER x 32 x 8 dependent-free v_add_u32 per wave.
+__global__ __launch_bounds__(256) void k_clock_probe(long long *ticks, int seed)
+{
+    int r0 = seed + threadIdx.x, r1 = r0 * 3, r2 = r0 * 5, r3 = r0 * 7, r4 = r0 * 11, r5 = r0 * 13, r6 = r0 * 17, r7 = r0 * 19;
+    const long long c0 = clock64(), w0 = wall_clock64();
+    for (int it = 0; it < ITER * 8; ++it) {
+        asm volatile(A_ADD("%0") A_ADD("%1") A_ADD("%2") A_ADD("%3") A_ADD("%4") A_ADD("%5") A_ADD("%6") A_ADD("%7")
+                     A_ADD("%0") A_ADD("%1") A_ADD("%2") A_ADD("%3") A_ADD("%4") A_ADD("%5") A_ADD("%6") A_ADD("%7")
+                     A_ADD("%0") A_ADD("%1") A_ADD("%2") A_ADD("%3") A_ADD("%4") A_ADD("%5") A_ADD("%6") A_ADD("%7")
+                     A_ADD("%0") A_ADD("%1") A_ADD("%2") A_ADD("%3") A_ADD("%4") A_ADD("%5") A_ADD("%6") A_ADD("%7")
+                     : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7));
+    }
+    const long long c1 = clock64(), w1 = wall_clock64();
+    if (threadIdx.x == 0) { ticks[2 * blockIdx.x] = c1 - c0; ticks[2 * blockIdx.x + 1] = w1 - w0; }
+    if (r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7 == 0x7fffffff) ticks[0] = 0;
+}
+
 int main()
 {
     hipDeviceProp_t p;
@@ -211,6 +229,30 @@ int main()
     hipEventCreate(&e0); hipEventCreate(&e1);
     double base = 0;
     printf("%d CUs, clockRate %d kHz, %d blocks of 256\n", p.multiProcessorCount, p.clockRate, blocks);
+    {
+        long long *ticks, *h = (long long *)malloc((size_t)blocks * 16);
+        int wall_khz = 0;
+        hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, 0);
+        hipMalloc(&ticks, (size_t)blocks * 16);
+        hipLaunchKernelGGL(k_clock_probe, dim3(blocks), dim3(256), 0, 0, ticks, 1);
+        hipDeviceSynchronize();
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(k_clock_probe, dim3(blocks), dim3(256), 0, 0, ticks, 2);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        hipMemcpy(h, ticks, (size_t)blocks * 16, hipMemcpyDeviceToHost);
+        double sc = 0, sw = 0;
+        for (int b = 0; b < blocks; ++b) { sc += (double)h[2 * b]; sw += (double)h[2 * b + 1]; }
+        const double instr_per_simd = (double)ITER * 8 * 32 * waves_per_simd;     // wave-instructions one SIMD issues in the probe
+        const double wall_ms = sw / blocks / wall_khz, ns_each = wall_ms * 1e6 / instr_per_simd;
+        printf("clock probe: kernel %.3f ms by events; per workgroup %.0f shader-counter ticks and %.0f ticks of the %d kHz wall counter (%.3f ms)\n"
+               "  shader counter / wall time = %.1f MHz\n"
+               "  v_add_u32: %.4f ns per wave-instruction per SIMD = %.2f clocks at 2400 MHz, or a sustained clock of %.0f MHz at 2 clocks each\n",
+               ms, sc / blocks, sw / blocks, wall_khz, wall_ms, (sc / blocks) / wall_ms / 1e3, ns_each, ns_each * 2.4, 2.0 / ns_each * 1e3);
+        hipFree(ticks); free(h);
+    }
     for (auto &t : tab) {
         hipLaunchKernelGGL(t.fn, dim3(blocks), dim3(256), 0, 0, out, 1);
         hipDeviceSynchronize();
