@@ -378,6 +378,9 @@ __device__ __forceinline__ int box_row(int a, int ad2, int ad4, int adl)
 #ifndef OFK_KEYS_ATOM
 // experiment: interior rows take the pair sums of the products from one v_mad_i32_i24 each instead of multiply + add: 21 VALU instructions
 // fewer per 7 rows and 2.3 % SLOWER alone (1.913 against 1.869 ms per 512 frames): the three-operand multiply issues slower than the pair
+#ifndef OFK_PAIR_LDS_PAD
+#define OFK_PAIR_LDS_PAD 0
+#endif
 #ifndef OFK_PAIR_MAD
 #define OFK_PAIR_MAD 0
 #endif
@@ -820,6 +823,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
     // registers: 168 VGPRs, three waves).  Alone on the chip 1.03 -> 0.96 ms; with the yy ring only (150 VGPRs, three waves, room
     // for a gray wave beside them) the kernel alone was no faster but the step 2.4 % shorter — four waves are another 1 % on top.
     __shared__ int s_ring[4 * BS * 64];
+#if OFK_PAIR_LDS_PAD
+    // experiment: LDS padded so that THREE waves per SIMD fit a CU instead of four - a quarter of every SIMD's registers stays free for
+    // the gray / pyramid waves that run beside this kernel, which otherwise only get in when one of its waves retires
+    __shared__ int s_pad[OFK_PAIR_LDS_PAD / 4];
+    if (threadIdx.x == 0) s_pad[0] = 0;
+#endif
 #if OFK_KEYS_ATOM
     __shared__ int s_kcnt;                                      // == cnt whenever a row takes key slots from it
     const unsigned cnt_addr = (unsigned)(size_t)&s_kcnt, buf_addr = (unsigned)(size_t)s_buf;
