@@ -378,6 +378,9 @@ __device__ __forceinline__ int box_row(int a, int ad2, int ad4, int adl)
 #ifndef OFK_KEYS_ATOM
 // experiment: interior rows take the pair sums of the products from one v_mad_i32_i24 each instead of multiply + add: 21 VALU instructions
 // fewer per 7 rows and 2.3 % SLOWER alone (1.913 against 1.869 ms per 512 frames): the three-operand multiply issues slower than the pair
+#ifndef OFK_KEYS_FLAT
+#define OFK_KEYS_FLAT 0
+#endif
 #ifndef OFK_PAIR_LDS_PAD
 #define OFK_PAIR_LDS_PAD 0
 #endif
@@ -429,6 +432,16 @@ __device__ __forceinline__ int box_row(int a, int ad2, int ad4, int adl)
                      : [se] "=&v"(se_), [so] "=&v"(so_)                                                                \
                      : [ca] "v"(cnt_addr), [one] "v"(one_v), [ba] "v"(buf_addr), [ke] "v"(ke_), [ko] "v"(ko_), [me] "s"(bale), [mo] "s"(balo) \
                      : "memory", "s30", "s31");                                                                        \
+    }
+#elif OFK_KEYS_FLAT
+// experiment: no branch around the key stores - a lane without a candidate writes its key into a dump slot behind the buffer (entries
+// NBUF + lane, never read as keys), so the seven rows of a block are straight-line code between the spill checks
+#define OFK_PAIR_KEY_STORE()                                                                                           \
+    {                                                                                                                  \
+        const int pe_ = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bale >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bale, 0u)); \
+        const int po_ = ne + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(balo >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)balo, 0u)); \
+        buf[ise ? cnt + pe_ : NBUF + lane] = OFK_SEG_KEY(e1e, yn * w + xo_e);                                          \
+        buf[iso ? cnt + po_ : NBUF + lane] = OFK_SEG_KEY(e1o, yn * w + xo_o);                                          \
     }
 #else
 #define OFK_PAIR_KEY_STORE()                                                                                           \
