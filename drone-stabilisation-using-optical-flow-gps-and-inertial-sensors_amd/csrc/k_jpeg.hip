@@ -101,47 +101,52 @@ __device__ inline void jwindow(jrd &r)
     r.w0 = jload8(r.d, r.wb); r.w1 = jload8(r.d, r.wb + 8); r.w2 = jload8(r.d, r.wb + 16);
 }
 __device__ inline void jslide(jrd &r) { while (r.pos - r.wb >= 8) { r.w0 = r.w1; r.w1 = r.w2; r.wb += 8; r.w2 = jload8(r.d, r.wb + 16); } }
-__device__ inline uint32_t jbyte(const jrd &r, uint32_t p)      // wb <= p < wb + 16
-{
-    const uint32_t o = p - r.wb;
-    return (uint32_t)((o < 8 ? r.w0 : r.w1) >> (8 * (o & 7))) & 255u;
-}
-
 // Canonical refill: byte by byte until 32..39 bits are buffered - enough for the longest code (16) plus the longest run of extra
-// bits (15), so a symbol needs one refill.  The state after it depends on the bit position only.  Fast path: the 1..4 bytes that
-// are due hold no FF (and no restart marker is pending), so they go in as one shift; otherwise byte by byte with the marker rules.
+// bits (15), so a symbol needs one refill.  The state after it depends on the bit position only.  Both paths work on a register
+// view of the stream at the cursor (x0 = bytes pos..pos+3, first one lowest).  Fast path: the 1..4 bytes that are due hold no FF
+// (and no restart marker is pending), so they go in as one byte-reversed shift.  Otherwise byte by byte with the marker rules, the
+// view shifted by what each step consumed: some lane of a wave is here in every fifth step, and the first version of this path
+// (a window slide and two 64-bit byte extractions per byte) was a third of the synchronisation pass's instructions.
 __device__ inline void jrefill(jrd &r)
 {
     if (r.nb > 31) return;
     jslide(r);
+    const uint32_t o = r.pos - r.wb;                                 // 0..7
+    const uint32_t a0 = (uint32_t)r.w0, a1 = (uint32_t)(r.w0 >> 32), a2 = (uint32_t)r.w1, a3 = (uint32_t)(r.w1 >> 32);
+    const bool up = o >= 4;
+    const uint32_t b0 = up ? a1 : a0, b1 = up ? a2 : a1, sh = o & 3;
+    uint32_t x0 = __builtin_amdgcn_alignbyte(b1, b0, sh);
     {
-        const uint32_t o = r.pos - r.wb;                             // 0..7
-        const uint32_t a0 = (uint32_t)r.w0, a1 = (uint32_t)(r.w0 >> 32), a2 = (uint32_t)r.w1;
-        const uint32_t x = __builtin_amdgcn_alignbyte(o < 4 ? a1 : a2, o < 4 ? a0 : a1, o & 3);   // the next four bytes, first one lowest
         const int n = (39 - r.nb) >> 3;                              // bytes the byte-wise loop would take: 1..4
-        const uint32_t y = ~x | (n == 4 ? 0u : 0xFFFFFFFFu << (8 * n));              // a zero byte in y = an FF among the n bytes
+        const uint32_t y = ~x0 | (n == 4 ? 0u : 0xFFFFFFFFu << (8 * n));             // a zero byte in y = an FF among the n bytes
         if (!r.fake && ((y - 0x01010101u) & ~y & 0x80808080u) == 0) {
-            r.buf = (r.buf << (8 * n)) | (uint64_t)(__builtin_bswap32(x) >> (32 - 8 * n));
+            r.buf = (r.buf << (8 * n)) | (uint64_t)(__builtin_bswap32(x0) >> (32 - 8 * n));
             r.nb += 8 * n; r.pos += n;
             return;
         }
     }
-    while (r.nb <= 31) {
-        uint32_t b = 0;
-        if (r.fake) r.fake += 8;                                  // parked in front of a restart marker: zero bits, like libjpeg
-        else {
-            jslide(r);
-            b = jbyte(r, r.pos);
-            if (b != 0xFF) ++r.pos;
+    // at most 4 bytes go in, each may be followed by a stuffed zero: 8 bytes of the view plus one to look at, pos + 8 <= wb + 15
+    const uint32_t b2 = up ? a3 : a2, b3 = up ? 0u : a3;
+    uint32_t x1 = __builtin_amdgcn_alignbyte(b2, b1, sh), x2 = __builtin_amdgcn_alignbyte(b3, b2, sh);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (r.nb <= 31) {
+            uint32_t b = 0;
+            if (r.fake) r.fake += 8;                              // parked in front of a restart marker: zero bits, like libjpeg
             else {
-                const uint32_t n = jbyte(r, r.pos + 1);
-                if (n == 0) r.pos += 2;                           // stuffed zero (an FF in front of the zero padding counts as one too)
-                else if ((n & 0xF8u) == 0xD0u) { b = 0; r.fake = 8; }      // RSTn: stay in front of it until the interval's bits are used up
-                else ++r.pos;
+                uint32_t adv = 1;
+                b = x0 & 255u;
+                if (b == 0xFF) {
+                    const uint32_t nx = (x0 >> 8) & 255u;
+                    if (nx == 0) adv = 2;                         // stuffed zero (an FF in front of the zero padding counts as one too)
+                    else if ((nx & 0xF8u) == 0xD0u) { b = 0; r.fake = 8; adv = 0; }   // RSTn: stay in front of it until the interval's bits are used up
+                }
+                r.pos += adv;
+                x0 = __builtin_amdgcn_alignbyte(x1, x0, adv); x1 = __builtin_amdgcn_alignbyte(x2, x1, adv); x2 >>= 8 * adv;
             }
+            r.buf = (r.buf << 8) | b;
+            r.nb += 8;
         }
-        r.buf = (r.buf << 8) | b;
-        r.nb += 8;
     }
 }
 
