@@ -105,8 +105,8 @@ __device__ inline void jslide(jrd &r) { while (r.pos - r.wb >= 8) { r.w0 = r.w1;
 // bits (15), so a symbol needs one refill.  The state after it depends on the bit position only.  Both paths work on a register
 // view of the stream at the cursor (x0 = bytes pos..pos+3, first one lowest).  Fast path: the 1..4 bytes that are due hold no FF
 // (and no restart marker is pending), so they go in as one byte-reversed shift.  Otherwise byte by byte with the marker rules, the
-// view shifted by what each step consumed: some lane of a wave is here in every fifth step, and the first version of this path
-// (a window slide and two 64-bit byte extractions per byte) was a third of the synchronisation pass's instructions.
+// view shifted by what each step consumed (some lane of a wave is here in every fifth step; one window slide per refill instead of
+// one per byte - the passes take the same time as with the per-byte version, the code is a third of the size).
 __device__ inline void jrefill(jrd &r)
 {
     if (r.nb > 31) return;
