@@ -725,6 +725,23 @@ __device__ __forceinline__ int lambda_min_bits(int vxx, int vxy, int vyy, float 
 #else
 #define OFK_PAIR_KCNT_SYNC()
 #endif
+#ifndef OFK_RING_AHEAD
+#define OFK_RING_AHEAD 0
+#endif
+#if OFK_RING_AHEAD
+// experiment: the ring reads of row i + 1 are issued at the top of row i, one whole row ahead of their use
+#define OFK_RING_READ(i)                                                                                               \
+        const int oyye = n_oyye, oyyo = n_oyyo, oxye = n_oxye, oxyo = n_oxyo;                                          \
+        {                                                                                                              \
+            const int i1_ = ((i) + 1) % BS;                                                                            \
+            n_oyye = s_ring[(4 * i1_) * 64 + lane]; n_oyyo = s_ring[(4 * i1_ + 1) * 64 + lane];                        \
+            n_oxye = s_ring[(4 * i1_ + 2) * 64 + lane]; n_oxyo = s_ring[(4 * i1_ + 3) * 64 + lane];                    \
+        }
+#else
+#define OFK_RING_READ(i)                                                                                               \
+        const int oyye = s_ring[(4 * (i)) * 64 + lane], oyyo = s_ring[(4 * (i) + 1) * 64 + lane];                      \
+        const int oxye = s_ring[(4 * (i) + 2) * 64 + lane], oxyo = s_ring[(4 * (i) + 3) * 64 + lane];
+#endif
 // One block of BS rows (expanded twice: IN = true for interior blocks); see OFK_EIG_ROWS for the conventions.
 #define OFK_PAIR_ROWS(IN)                                                                                             \
     _Pragma("unroll") for (int i = 0; i < BS; ++i) {                                                                   \
@@ -734,8 +751,7 @@ __device__ __forceinline__ int lambda_min_bits(int vxx, int vxy, int vyy, float 
             if (edge_strip) { ge2 = __builtin_amdgcn_ds_bpermute(mir_e, ge2); go2 = __builtin_amdgcn_ds_bpermute(mir_o, go2); } \
         }                                                                                                              \
         if (i > 0 && (i & 1) == 0 && cnt >= 64) OFK_PAIR_SPILL_KEYS()                                                  \
-        const int oyye = s_ring[(4 * i) * 64 + lane], oyyo = s_ring[(4 * i + 1) * 64 + lane];      /* the yy and xy box sums of BS rows ago (LDS ring) */ \
-        const int oxye = s_ring[(4 * i + 2) * 64 + lane], oxyo = s_ring[(4 * i + 3) * 64 + lane];                      \
+        OFK_RING_READ(i)                                           /* the yy and xy box sums of BS rows ago (LDS ring) */ \
         const int r12e = g1e + ge2, r12o = g1o + go2;              /* Sobel column sums from row-pair sums: s = (g0+g1) + (g1+g2), */ \
         const int se = r01e + r12e, so = r01o + r12o, te = r12e - r01e, to = r12o - r01o;   /* t = g2 - g0 = (g1+g2) - (g0+g1): three full-rate adds */ \
         const int nso = -so, nse = -se, tt = te + to;                                                                  \
@@ -821,7 +837,12 @@ template <int BS> struct pair_geom {
 // Wave-granular workgroups fill every slot: SQ counters put the wave-slot utilisation of the old launch at 66 %
 // (profiles/r02a_valu_pmc.json: 6.1 G live wave-cycles in 9.3 G slot-cycles).
 template <int BS, bool MASK>
+#if OFK_RING_AHEAD
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_mineig_pair(
+#else
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void k_mineig_pair(
+#endif
+
     const uint8_t *__restrict__ gray, size_t gray_stride, int h, int w, int rows_per_strip, float kd, float ko,
     unsigned int *__restrict__ maxbits, const uint8_t *__restrict__ mask, size_t mask_stride, double quality,
     unsigned long long *__restrict__ seg, int seg_cap, int *__restrict__ seg_count, int *__restrict__ flags)
@@ -923,6 +944,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
     int e1e = 0, e1o = 0, hm0e = 0, hm0o = 0, hm1e = 0, hm1o = 0;
     int nextg[NL];
     OFK_PAIR_LOAD(0, nextg)
+#if OFK_RING_AHEAD
+    int n_oyye = 0, n_oyyo = 0, n_oxye = 0, n_oxyo = 0;          // ring slot 0 holds zeros at the start
+#endif
 
     for (int base = 0; base < nsteps; base += BS) {
         int curv[BS];
