@@ -61,10 +61,52 @@ __global__ __launch_bounds__(256) void k_gray_bgr8(const uint8_t *__restrict__ b
     }
 }
 
+// experiment (ofk_set_tuning "gray_px" = 16 / 32 / 64 -> one-WAVE workgroups of NPX pixels per thread, all loads of the thread in
+// flight before the first use): a single wave fits the hole one retiring response wave leaves, whatever its register count
+template <int NPX>
+__global__ __launch_bounds__(64) void k_gray_bgr8_wide(const uint8_t *__restrict__ bgr, size_t bgr_stride, uint8_t *__restrict__ gray, size_t gray_stride, int npx)
+{
+    constexpr unsigned HI = 29u | (150u << 8) | (76u << 16), LO = 46u | (70u << 8) | (140u << 16);
+    const int b = blockIdx.y;
+    const uint8_t *src = bgr + (size_t)b * bgr_stride;
+    uint8_t *dst = gray + (size_t)b * gray_stride;
+    const int p0 = min((int)(blockIdx.x * blockDim.x + threadIdx.x) * NPX, npx - NPX);    // the last thread overlaps its neighbour (npx % 16 == 0, npx >= NPX)
+    const uint4 *s4 = reinterpret_cast<const uint4 *>(src + (size_t)p0 * 3);
+    uint4 v[NPX * 3 / 16];
+#pragma unroll
+    for (int i = 0; i < NPX * 3 / 16; ++i) v[i] = s4[i];
+#pragma unroll
+    for (int g = 0; g < NPX / 16; ++g) {
+        const uint4 a = v[3 * g], c = v[3 * g + 1], d = v[3 * g + 2];
+        const unsigned wv[13] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w, 0u};
+        unsigned t[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int byte = 3 * k;
+            const unsigned px = (byte & 3) ? __builtin_amdgcn_alignbit(wv[(byte >> 2) + 1], wv[byte >> 2], (byte & 3) * 8) : wv[byte >> 2];
+            t[k] = (__builtin_amdgcn_udot4(px, HI, 0u, false) << 8) + __builtin_amdgcn_udot4(px, LO, 32768u, false);
+        }
+        unsigned out[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            out[q] = __builtin_amdgcn_perm(t[4 * q + 1], t[4 * q], 0x0c0c0602u) | __builtin_amdgcn_perm(t[4 * q + 3], t[4 * q + 2], 0x06020c0cu);
+        *reinterpret_cast<uint4 *>(dst + p0 + 16 * g) = make_uint4(out[0], out[1], out[2], out[3]);
+    }
+}
+
 void ofk_launch_gray(hipStream_t s, const uint8_t *bgr, size_t bgr_stride, uint8_t *gray, size_t gray_stride, int batch,
                      int h, int w)
 {
     const int npx = h * w;
+    const int wide = g_ofk_tuning.gray_px;
+    if ((wide == 16 || wide == 32 || wide == 64) && (npx & 15) == 0 && npx >= 64 && (bgr_stride & 15) == 0 && (gray_stride & 15) == 0) {
+        const int threads = (npx + wide - 1) / wide;
+        dim3 grid((threads + 63) / 64, batch);
+        if (wide == 16) hipLaunchKernelGGL((k_gray_bgr8_wide<16>), grid, dim3(64), 0, s, bgr, bgr_stride, gray, gray_stride, npx);
+        else if (wide == 32) hipLaunchKernelGGL((k_gray_bgr8_wide<32>), grid, dim3(64), 0, s, bgr, bgr_stride, gray, gray_stride, npx);
+        else hipLaunchKernelGGL((k_gray_bgr8_wide<64>), grid, dim3(64), 0, s, bgr, bgr_stride, gray, gray_stride, npx);
+        return;
+    }
     const int groups = (npx + 15) / 16;
     dim3 grid((groups + 255) / 256, batch);
     hipLaunchKernelGGL(k_gray_bgr8, grid, dim3(256), 0, s, bgr, bgr_stride, gray, gray_stride, npx);

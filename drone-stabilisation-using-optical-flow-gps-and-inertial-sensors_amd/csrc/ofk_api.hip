@@ -53,7 +53,7 @@ static size_t levels_bytes(int h, int w, int max_level)
 // getenv on other threads and changes every other HIP user of the process (rounds 1-2 did that).  ofk_set_streams warns when the
 // value in effect is too small.
 
-ofk_tuning g_ofk_tuning = {0, 0, 0, 0, 0, 0};
+ofk_tuning g_ofk_tuning = {0, 0, 0, 0, 0, 0, 0};
 
 static int *tuning_slot(const char *knob, int *lo, int *hi)
 {
@@ -64,6 +64,7 @@ static int *tuning_slot(const char *knob, int *lo, int *hi)
         {"pyr3_chunks", &g_ofk_tuning.pyr3_chunks, 1, 4096},  // row chunks per strip of k_pyr3_stream
         {"pyr_rows", &g_ofk_tuning.pyr_rows, 1, 4096},        // rows per strip of k_pyr_down_stream
         {"jpeg_chunk", &g_ofk_tuning.jpeg_chunk, 64, 256},    // bytes of entropy data per decoder thread (64, 128, 256)
+        {"gray_px", &g_ofk_tuning.gray_px, 16, 64},           // experiment: one-wave workgroups of 16 / 32 / 64 pixels per thread in the BGR -> gray conversion
     };
     for (auto &t : tab)
         if (knob && strcmp(knob, t.name) == 0) { *lo = t.lo; *hi = t.hi; return t.slot; }
