@@ -402,7 +402,8 @@ int ofk_set_overlap(ofk_ctx *ctx, int on);
  * runs the parity cases under them).  Knobs: "eig_rows" 8..4096 rows per strip of the streaming response kernels; "no_pair" 1 = one
  * column per lane (k_mineig_stream) where k_mineig_pair would run; "no_pyr3" 1 = pyramid level by level; "pyr3_chunks" row chunks per
  * strip of the three-level pyramid pass; "pyr_rows" rows per strip of the one-level pass; "jpeg_chunk" 64/128/256 bytes of entropy
- * data per decoder thread.  (Rounds 1-2 read OFK_* environment variables in the launch code instead.) */
+ * data per decoder thread; "gray_px" 16/32/64 = the BGR -> gray conversion as one-wave workgroups of that many pixels per thread (an
+ * experiment of DESIGN.md section 8: slower in the pipeline).  (Rounds 1-2 read OFK_* environment variables in the launch code instead.) */
 int ofk_set_tuning(const char *knob, int value);
 int ofk_get_tuning(const char *knob, int *value);
 /* Completion marks (slots 0..7): ofk_mark records one behind everything queued so far on every slice, ofk_mark_wait
