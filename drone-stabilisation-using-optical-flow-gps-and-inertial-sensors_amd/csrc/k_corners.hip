@@ -317,11 +317,6 @@ __device__ __forceinline__ float sqrt_rn_normal(float x)
     const float s = __builtin_amdgcn_sqrtf(x);
     const float dn = __int_as_float(__float_as_int(s) - 1), up = __int_as_float(__float_as_int(s) + 1);
     const float rdn = __builtin_fmaf(-dn, s, x), rup = __builtin_fmaf(-up, s, x);
-#if OFK_SQRT_SELECT
-    float r = rdn <= 0.f ? dn : s;
-    r = rup > 0.f ? up : r;
-    return r;
-#else
     // result = dn + [rdn > 0] + [rup > 0] on the bit patterns (rup > 0 implies rdn > 0).  A float is > 0 exactly when its pattern
     // is >= 1 as a signed integer, and clamping the pattern to [0, 1] (v_med3_i32) turns that into the increment: two clamps and one
     // three-operand add instead of two compares and two selects - 12 issue clocks instead of 16, twice per row.
@@ -330,7 +325,6 @@ __device__ __forceinline__ float sqrt_rn_normal(float x)
     asm("v_med3_i32 %0, %1, 0, 1" : "=v"(iup) : "v"(rup));
     asm("v_add3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(dn), "v"(idn), "v"(iup));
     return __int_as_float(r);
-#endif
 }
 
 // Horizontal box sum of BS consecutive lanes (x-BS+1 .. x).  A Horner chain of wave shifts costs BS-1 VALU slots, and the
@@ -375,81 +369,11 @@ __device__ __forceinline__ int box_row(int a, int ad2, int ad4, int adl)
 // response kernels' row loop, which is bound by VALU issue, for one 64-bit NOT per key in a kernel that waits for memory.
 #define OFK_SEG_KEY(bits, idx) (((unsigned long long)(unsigned)(bits) << 32) | (unsigned)(idx))
 #define OFK_SEG_KEY_DECODE(k) (~(k))
-#ifndef OFK_KEYS_ATOM
-// experiment: interior rows take the pair sums of the products from one v_mad_i32_i24 each instead of multiply + add: 21 VALU instructions
-// fewer per 7 rows and 2.3 % SLOWER alone (1.913 against 1.869 ms per 512 frames): the three-operand multiply issues slower than the pair
-#ifndef OFK_KEYS_FLAT
-#define OFK_KEYS_FLAT 0
-#endif
-#ifndef OFK_PAIR_LDS_PAD
-#define OFK_PAIR_LDS_PAD 0
-#endif
-#ifndef OFK_PAIR_MAD
-#define OFK_PAIR_MAD 0
-#endif
-#ifndef OFK_SQRT_SELECT
-#define OFK_SQRT_SELECT 0
-#endif
-#define OFK_KEYS_ATOM 0
-#endif
-#ifndef OFK_BOX_DPP
-#define OFK_BOX_DPP 0
-#endif
-// The four pure neighbour MOVES of a row of k_mineig_pair (two in the Sobel y sums, two in the 3x3 maximum: the other neighbour accesses
-// fold into v_add_u32_dpp).  OFK_MOV_LDS=1 fetches them with ds_bpermute instead of v_mov_b32_dpp: four VALU instructions fewer per row,
-// four LDS instructions more (experiment, tools/experiments/run_variants.sh).
-#ifndef OFK_MOV_LDS
-#define OFK_MOV_LDS 0
-#endif
-#if OFK_MOV_LDS
-#define OFK_NB_PREV(v) __builtin_amdgcn_ds_bpermute(adp1, (v))
-#define OFK_NB_NEXT(v) __builtin_amdgcn_ds_bpermute(adn1, (v))
-#else
-#define OFK_NB_PREV(v) DPP_SHR1(v)
-#define OFK_NB_NEXT(v) DPP_SHL1(v)
-#endif
-#if OFK_KEYS_ATOM
-// experiment (tools/experiments/eig_keys.sh): the slot of a key comes from a counter in LDS (ds_add_rtn_u32 under the candidate
-// lanes' exec mask) instead of ballot + mbcnt ranks; both slots' atomics are issued before the one wait.  The order of keys inside
-// a segment is irrelevant (k_select_greedy sorts).  Written as ONE asm statement: the compiler's atomic optimizer would turn a
-// uniform-value LDS atomic back into ballot + mbcnt + one atomic per wave.
-#define OFK_PAIR_KEY_STORE()                                                                                           \
-    {                                                                                                                  \
-        const unsigned long long ke_ = OFK_SEG_KEY(e1e, yn * w + xo_e), ko_ = OFK_SEG_KEY(e1o, yn * w + xo_o);         \
-        int se_, so_;                                                                                                  \
-        asm volatile("s_mov_b64 s[30:31], exec\n\t"                                                                    \
-                     "s_mov_b64 exec, %[me]\n\t"                                                                       \
-                     "ds_add_rtn_u32 %[se], %[ca], %[one]\n\t"                                                         \
-                     "s_mov_b64 exec, %[mo]\n\t"                                                                       \
-                     "ds_add_rtn_u32 %[so], %[ca], %[one]\n\t"                                                         \
-                     "s_waitcnt lgkmcnt(0)\n\t"                                                                        \
-                     "v_lshl_add_u32 %[so], %[so], 3, %[ba]\n\t"                                                       \
-                     "ds_write_b64 %[so], %[ko]\n\t"                                                                   \
-                     "s_mov_b64 exec, %[me]\n\t"                                                                       \
-                     "v_lshl_add_u32 %[se], %[se], 3, %[ba]\n\t"                                                       \
-                     "ds_write_b64 %[se], %[ke]\n\t"                                                                   \
-                     "s_mov_b64 exec, s[30:31]"                                                                        \
-                     : [se] "=&v"(se_), [so] "=&v"(so_)                                                                \
-                     : [ca] "v"(cnt_addr), [one] "v"(one_v), [ba] "v"(buf_addr), [ke] "v"(ke_), [ko] "v"(ko_), [me] "s"(bale), [mo] "s"(balo) \
-                     : "memory", "s30", "s31");                                                                        \
-    }
-#elif OFK_KEYS_FLAT
-// experiment: no branch around the key stores - a lane without a candidate writes its key into a dump slot behind the buffer (entries
-// NBUF + lane, never read as keys), so the seven rows of a block are straight-line code between the spill checks
-#define OFK_PAIR_KEY_STORE()                                                                                           \
-    {                                                                                                                  \
-        const int pe_ = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bale >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bale, 0u)); \
-        const int po_ = ne + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(balo >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)balo, 0u)); \
-        buf[ise ? cnt + pe_ : NBUF + lane] = OFK_SEG_KEY(e1e, yn * w + xo_e);                                          \
-        buf[iso ? cnt + po_ : NBUF + lane] = OFK_SEG_KEY(e1o, yn * w + xo_o);                                          \
-    }
-#else
 #define OFK_PAIR_KEY_STORE()                                                                                           \
         if (ise) buf[cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bale >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bale, 0u))] =   \
             OFK_SEG_KEY(e1e, yn * w + xo_e);                                                                           \
         if (iso) buf[cnt + ne + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(balo >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)balo, 0u))] = \
             OFK_SEG_KEY(e1o, yn * w + xo_o);
-#endif
 #define OFK_EIG_ROWS(IN)                                                                                               \
     _Pragma("unroll") for (int i = 0; i < BS; ++i) {                                                                   \
         const int r = base + i;                                                                                        \
@@ -662,7 +586,6 @@ template <int K>
 __device__ __forceinline__ void box_pair_q(int ae, int ao, int q, int ad2, int ad3, int &he, int &ho);
 template <int K>
 __device__ __forceinline__ void box_pair(int ae, int ao, int ad2, int ad3, int &he, int &ho) { box_pair_q<K>(ae, ao, ae + ao, ad2, ad3, he, ho); }
-// ... with the pair sum q = a_e + a_o handed in (interior rows get it from one v_mad_i32_i24; a_e itself is only needed for K == 1)
 template <int K>
 __device__ __forceinline__ void box_pair_q(int ae, int ao, int q, int ad2, int ad3, int &he, int &ho)
 {
@@ -670,15 +593,8 @@ __device__ __forceinline__ void box_pair_q(int ae, int ao, int q, int ad2, int a
         ho = DPP_SHR1(ao) + q;
         he = ae + DPP_SHR1(q);
     } else {
-#if OFK_BOX_DPP
-        // experiment (tools/experiments/run_variants.sh): q(l-2) by two wave shifts on the VALU instead of one gather on the LDS pipe
-        const int s1_ = DPP_SHR1(q);
-        const int P = s1_ + q;
-        const int g2q = DPP_SHR1(s1_);
-#else
         const int P = DPP_SHR1(q) + q;                                           // q(l-1) + q(l)
         const int g2q = __builtin_amdgcn_ds_bpermute(ad2, q);                    // q(l-2)
-#endif
         if constexpr (K == 2) {
             ho = P + __builtin_amdgcn_ds_bpermute(ad2, ao);
             he = (P - ao) + g2q;
@@ -718,35 +634,51 @@ __device__ __forceinline__ int lambda_min_bits(int vxx, int vxy, int vyy, float 
         __builtin_amdgcn_wave_barrier();                                                                               \
         buf[lane] = rest;                                                                                              \
         cnt -= nchunk * 64;                                                                                            \
-        OFK_PAIR_KCNT_SYNC()                                                                                           \
     }
-#if OFK_KEYS_ATOM
-#define OFK_PAIR_KCNT_SYNC() { if (lane == 0) s_kcnt = cnt; __builtin_amdgcn_wave_barrier(); }
-#else
-#define OFK_PAIR_KCNT_SYNC()
-#endif
-#ifndef OFK_RING_AHEAD
-#define OFK_RING_AHEAD 0
-#endif
-#if OFK_RING_AHEAD
-// experiment: the ring reads of row i + 1 are issued at the top of row i, one whole row ahead of their use
-#define OFK_RING_READ(i)                                                                                               \
-        const int oyye = n_oyye, oyyo = n_oyyo, oxye = n_oxye, oxyo = n_oxyo;                                          \
-        {                                                                                                              \
-            const int i1_ = ((i) + 1) % BS;                                                                            \
-            n_oyye = s_ring[(4 * i1_) * 64 + lane]; n_oyyo = s_ring[(4 * i1_ + 1) * 64 + lane];                        \
-            n_oxye = s_ring[(4 * i1_ + 2) * 64 + lane]; n_oxyo = s_ring[(4 * i1_ + 3) * 64 + lane];                    \
-        }
-#else
 #define OFK_RING_READ(i)                                                                                               \
         const int oyye = s_ring[(4 * (i)) * 64 + lane], oyyo = s_ring[(4 * (i) + 1) * 64 + lane];                      \
         const int oxye = s_ring[(4 * (i) + 2) * 64 + lane], oxyo = s_ring[(4 * (i) + 3) * 64 + lane];
+// BGR = true (the pipeline's first stage, round 4): the kernel reads the BGR frame itself.  The loader lane (lrow, lk) fetches the
+// 12 bytes = 4 pixels whose gray bytes it fetched as one dword before (one dwordx3 per row pair), converts them with k_gray_bgr8's integer
+// formula (k_image.hip) and holds exactly the dword the gray frame would have delivered - everything behind the ds_bpermute that hands
+// the lanes their byte pairs is unchanged, so are the results.  The strip's own 4-pixel groups of its own rows are stored as level 0 of
+// the pyramid on the way (every gray pixel by exactly one strip): the separate conversion launch of the previous frames is gone.
+//   2 (3735 B + 19235 G + 9798 R) + 32768 = 256 H + L' with H = dot(px, HI), L' = dot(px, LO) + 32768 in byte-sized coefficients;
+//   gray = (256 H + L') >> 16 = (H + (L' >> 8)) >> 8 (nested floors): v_dot4 -> v_lshrrev -> v_dot4 per pixel, the result is byte 1.
+//   Pixels 1 and 2 of the four straddle two dwords (one v_alignbit each); pixel 3 sits in bytes 1..3 of the third dword and meets
+//   coefficients shifted by one byte instead.
+__device__ __forceinline__ unsigned bgr4_to_gray4(unsigned d0, unsigned d1, unsigned d2)
+{
+    constexpr unsigned HI = 29u | (150u << 8) | (76u << 16), LO = 46u | (70u << 8) | (140u << 16);
+    const unsigned p1 = __builtin_amdgcn_alignbit(d1, d0, 24), p2 = __builtin_amdgcn_alignbit(d2, d1, 16);
+    const unsigned t0 = __builtin_amdgcn_udot4(d0, HI, __builtin_amdgcn_udot4(d0, LO, 32768u, false) >> 8, false);
+    const unsigned t1 = __builtin_amdgcn_udot4(p1, HI, __builtin_amdgcn_udot4(p1, LO, 32768u, false) >> 8, false);
+    const unsigned t2 = __builtin_amdgcn_udot4(p2, HI, __builtin_amdgcn_udot4(p2, LO, 32768u, false) >> 8, false);
+    const unsigned t3 = __builtin_amdgcn_udot4(d2, HI << 8, __builtin_amdgcn_udot4(d2, LO << 8, 32768u, false) >> 8, false);
+    return __builtin_amdgcn_perm(t1, t0, 0x0c0c0501u) | __builtin_amdgcn_perm(t3, t2, 0x05010c0cu);       // byte 1 of t0..t3
+}
+struct bgr_raw { unsigned x, y, z; };
+#ifndef OFK_BGR_RD
+#define OFK_BGR_RD 2        // TEMPORARY (measurement of the ring depth)
 #endif
+// Row pair q of the block: rows base + 2q (lanes 0-31) and base + 2q + 1 (lanes 32-63; for q = NL - 1 that row belongs to the next block
+// and is stored there).  RD row pairs are in flight: the slot is refilled with the pair RD pairs further down the march.
+#define OFK_PAIR_BGR_SLOT(q)                                                                                           \
+        {                                                                                                              \
+            const int q_ = (q), s_ = q_ % RD, pn_ = q_ + RD;                                                           \
+            cvt = bgr4_to_gray4(raw[s_].x, raw[s_].y, raw[s_].z);                                                      \
+            const int gyu_ = Yp0 - 1 + base + 2 * q_ + lrow;                                                           \
+            if (st_col && (unsigned)(gyu_ - ya) < (unsigned)(yb - ya) && !(2 * q_ + 1 == BS && lrow))                  \
+                *reinterpret_cast<unsigned *>(gout + ((unsigned)(Yp0 - 1 + base + 2 * q_) * (unsigned)w + st_off)) = cvt; \
+            OFK_PAIR_LOAD3(pn_ < NL ? base + 2 * pn_ : base + BS + 2 * (pn_ - NL), raw[s_])                            \
+        }
 // One block of BS rows (expanded twice: IN = true for interior blocks); see OFK_EIG_ROWS for the conventions.
 #define OFK_PAIR_ROWS(IN)                                                                                             \
     _Pragma("unroll") for (int i = 0; i < BS; ++i) {                                                                   \
         const int r = base + i;                                                                                        \
-        int ge2 = (int)__builtin_amdgcn_ubfe((unsigned)curv[i], bsh, 8u), go2 = (int)__builtin_amdgcn_ubfe((unsigned)curv[i], bsh + 8u, 8u); \
+        if (BGR && (i & 1) == 0) OFK_PAIR_BGR_SLOT(i >> 1)             /* convert the row pair (r, r + 1), store its gray, load one ahead */ \
+        const unsigned cur_ = BGR ? (unsigned)__builtin_amdgcn_ds_bpermute(srcsel + 128 * (i & 1), (int)cvt) : (unsigned)curv[i]; \
+        int ge2 = (int)__builtin_amdgcn_ubfe(cur_, bsh, 8u), go2 = (int)__builtin_amdgcn_ubfe(cur_, bsh + 8u, 8u);     \
         if (!(IN)) {                                                                                                   \
             if (edge_strip) { ge2 = __builtin_amdgcn_ds_bpermute(mir_e, ge2); go2 = __builtin_amdgcn_ds_bpermute(mir_o, go2); } \
         }                                                                                                              \
@@ -757,36 +689,23 @@ __device__ __forceinline__ int lambda_min_bits(int vxx, int vxy, int vyy, float 
         const int nso = -so, nse = -se, tt = te + to;                                                                  \
         const int dxe = DPP_SHR1(nso) + so;                                                                            \
         const int dxo = DPP_SHL1(se) + nse;                                                                            \
-        int uye = OFK_NB_PREV(to) + te, uyo = OFK_NB_NEXT(te) + to;   /* kept apart from "+ tt": v_add_u32_dpp + v_add_u32 (6 issue clocks) */ \
+        int uye = DPP_SHR1(to) + te, uyo = DPP_SHL1(te) + to;   /* kept apart from "+ tt": v_add_u32_dpp + v_add_u32 (6 issue clocks) */ \
         asm("" : "+v"(uye), "+v"(uyo));                               /* where the compiler forms v_mov_b32_dpp + v_add3_u32 (8) */ \
         const int dye = uye + tt;                                                                                      \
         const int dyo = uyo + tt;                                                                                      \
         int hxxe, hxxo, hxye, hxyo, hyye, hyyo;                                                                        \
-        if ((IN) && BS > 3 && OFK_PAIR_MAD) {                                                                      \
-            /* experiment OFK_PAIR_MAD: the box sums only take the odd product and the pair sum; the pair sum from ONE v_mad_i32_i24 */ \
-            int pxxo = __mul24(dxo, dxo), pyyo = __mul24(dyo, dyo), pxyo = __mul24(dxo, dyo);                          \
-            asm("" : "+v"(pxxo), "+v"(pxyo), "+v"(pyyo));                                                              \
-            int qxx, qyy, qxy;                                                                                         \
-            asm("v_mad_i32_i24 %0, %1, %1, %2" : "=v"(qxx) : "v"(dxe), "v"(pxxo));                                     \
-            asm("v_mad_i32_i24 %0, %1, %1, %2" : "=v"(qyy) : "v"(dye), "v"(pyyo));                                     \
-            asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(qxy) : "v"(dxe), "v"(dye), "v"(pxyo));                           \
-            box_pair_q<BS / 2>(0, pxxo, qxx, ad2, ad3, hxxe, hxxo);                                                    \
-            box_pair_q<BS / 2>(0, pxyo, qxy, ad2, ad3, hxye, hxyo);                                                    \
-            box_pair_q<BS / 2>(0, pyyo, qyy, ad2, ad3, hyye, hyyo);                                                    \
-        } else {                                                                                                       \
-            int pxxe = __mul24(dxe, dxe), pyye = __mul24(dye, dye), pxye = __mul24(dxe, dye);                          \
-            int pxxo = __mul24(dxo, dxo), pyyo = __mul24(dyo, dyo), pxyo = __mul24(dxo, dyo);                          \
-            asm("" : "+v"(pxxe), "+v"(pxye), "+v"(pyye), "+v"(pxxo), "+v"(pxyo), "+v"(pyyo));                          \
-            if (!(IN)) {                                                                                               \
-                const int Y = Yp0 + r - 2;                                                                             \
-                const bool rowflip = (Y < 0) | (Y >= h);                                                               \
-                pxye = (rowflip != flip_e) ? -pxye : pxye;                                                             \
-                pxyo = (rowflip != flip_o) ? -pxyo : pxyo;                                                             \
-            }                                                                                                          \
-            box_pair<BS / 2>(pxxe, pxxo, ad2, ad3, hxxe, hxxo);                                                        \
-            box_pair<BS / 2>(pxye, pxyo, ad2, ad3, hxye, hxyo);                                                        \
-            box_pair<BS / 2>(pyye, pyyo, ad2, ad3, hyye, hyyo);                                                        \
-        }                                                                                                              \
+        int pxxe = __mul24(dxe, dxe), pyye = __mul24(dye, dye), pxye = __mul24(dxe, dye);                          \
+        int pxxo = __mul24(dxo, dxo), pyyo = __mul24(dyo, dyo), pxyo = __mul24(dxo, dyo);                          \
+        asm("" : "+v"(pxxe), "+v"(pxye), "+v"(pyye), "+v"(pxxo), "+v"(pxyo), "+v"(pyyo));                          \
+        if (!(IN)) {                                                                                               \
+            const int Y = Yp0 + r - 2;                                                                             \
+            const bool rowflip = (Y < 0) | (Y >= h);                                                               \
+            pxye = (rowflip != flip_e) ? -pxye : pxye;                                                             \
+            pxyo = (rowflip != flip_o) ? -pxyo : pxyo;                                                             \
+        }                                                                                                          \
+        box_pair<BS / 2>(pxxe, pxxo, ad2, ad3, hxxe, hxxo);                                                        \
+        box_pair<BS / 2>(pxye, pxyo, ad2, ad3, hxye, hxyo);                                                        \
+        box_pair<BS / 2>(pyye, pyyo, ad2, ad3, hyye, hyyo);                                                        \
         vxxe += hxxe - rxxe[i]; vxye += hxye - oxye; vyye += hyye - oyye;                                              \
         vxxo += hxxo - rxxo[i]; vxyo += hxyo - oxyo; vyyo += hyyo - oyyo;                                              \
         rxxe[i] = hxxe; rxxo[i] = hxxo;                                                                                \
@@ -805,8 +724,8 @@ __device__ __forceinline__ int lambda_min_bits(int vxx, int vxy, int vyy, float 
             }                                                                                                          \
             lmaxi = max(max(lmaxi, cme ? e2e : 0), cmo ? e2o : 0);                                                     \
         }                                                                                                              \
-        const int hm2e = max(max(OFK_NB_PREV(e2o), e2e), e2o);                                                         \
-        const int hm2o = max(max(OFK_NB_NEXT(e2e), e2o), e2e);                                                         \
+        const int hm2e = max(max(DPP_SHR1(e2o), e2e), e2o);                                                         \
+        const int hm2o = max(max(DPP_SHL1(e2e), e2o), e2e);                                                         \
         const int yn = yo - 1;                                                                                         \
         const int me = max(max(hm0e, hm1e), hm2e), mo = max(max(hm0o, hm1o), hm2o);                                    \
         bool ise = e1e >= max(me, thr1e), iso = e1o >= max(mo, thr1o);                                                 \
@@ -836,16 +755,12 @@ template <int BS> struct pair_geom {
 // had marched down its 540 rows, and the 2560 workgroups of a 256-frame launch made 3.33 rounds over the chip's 768 slots.
 // Wave-granular workgroups fill every slot: SQ counters put the wave-slot utilisation of the old launch at 66 %
 // (profiles/r02a_valu_pmc.json: 6.1 G live wave-cycles in 9.3 G slot-cycles).
-template <int BS, bool MASK>
-#if OFK_RING_AHEAD
+template <int BS, bool MASK, bool BGR>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_mineig_pair(
-#else
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void k_mineig_pair(
-#endif
-
     const uint8_t *__restrict__ gray, size_t gray_stride, int h, int w, int rows_per_strip, float kd, float ko,
     unsigned int *__restrict__ maxbits, const uint8_t *__restrict__ mask, size_t mask_stride, double quality,
-    unsigned long long *__restrict__ seg, int seg_cap, int *__restrict__ seg_count, int *__restrict__ flags)
+    unsigned long long *__restrict__ seg, int seg_cap, int *__restrict__ seg_count, int *__restrict__ flags,
+    const uint8_t *__restrict__ bgr, size_t bgr_stride, uint8_t *__restrict__ gray_out)
 {
     static_assert(BS == 3 || BS == 5 || BS == 7, "pair sums are written for odd boxes up to 7");
     constexpr int AN = pair_geom<BS>::AN, PAD = pair_geom<BS>::PAD, D = pair_geom<BS>::D, SW = pair_geom<BS>::SW;
@@ -857,19 +772,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
     // registers: 168 VGPRs, three waves).  Alone on the chip 1.03 -> 0.96 ms; with the yy ring only (150 VGPRs, three waves, room
     // for a gray wave beside them) the kernel alone was no faster but the step 2.4 % shorter — four waves are another 1 % on top.
     __shared__ int s_ring[4 * BS * 64];
-#if OFK_PAIR_LDS_PAD
-    // experiment: LDS padded so that THREE waves per SIMD fit a CU instead of four - a quarter of every SIMD's registers stays free for
-    // the gray / pyramid waves that run beside this kernel, which otherwise only get in when one of its waves retires
-    __shared__ int s_pad[OFK_PAIR_LDS_PAD / 4];
-    if (threadIdx.x == 0) s_pad[0] = 0;
-#endif
-#if OFK_KEYS_ATOM
-    __shared__ int s_kcnt;                                      // == cnt whenever a row takes key slots from it
-    const unsigned cnt_addr = (unsigned)(size_t)&s_kcnt, buf_addr = (unsigned)(size_t)s_buf;
-    int one_v = 1;
-    asm volatile("" : "+v"(one_v));
-    if (threadIdx.x == 0) s_kcnt = 0;
-#endif
     const int lane = threadIdx.x;
     // XCD-aware block -> (image, chunk, strip block) map: workgroups are dealt round-robin over the 8 XCDs (blocks n and
     // n + 8 share one L2); an image's strips and chunks go to ONE XCD, so the halo columns and rows they share are fetched once.
@@ -917,19 +819,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
     auto mirror = [&](int c) -> int { c = c < 0 ? -c : c; c = c >= w ? 2 * (w - 1) - c : c; return min(max((c - G0) >> 1, 0), 63) * 4; };
     const int mir_e = mirror(ce), mir_o = mirror(ce + 1);       // lane that holds the source of a mirrored column (else: itself)
     const int ad2 = ((lane - 2) & 63) * 4, ad3 = ((lane - 3) & 63) * 4;
-#if OFK_MOV_LDS
-    const int adp1 = ((lane - 1) & 63) * 4, adn1 = ((lane + 1) & 63) * 4;
-#endif
     constexpr int NL = (BS + 1) / 2;                            // dword loads per block of BS rows (two rows each)
     auto row_of = [&](int r) -> int {
         int gy = Yp0 - 1 + min(r, nsteps - 1);
         gy = gy < 0 ? -gy : gy;
         return gy >= h ? 2 * (h - 1) - gy : gy;
     };
+    // 32-bit byte offsets from the image's (wave-uniform) base: the row products are scalar, the lane adds its own part - a 64-bit
+    // per-lane address would cost two quarter-rate v_mad_u64_u32 per load
 #define OFK_PAIR_LOAD(R0, OUT)                                                                                         \
     _Pragma("unroll") for (int q_ = 0; q_ < NL; ++q_) {                                                                \
-        const int a_ = row_of((R0) + 2 * q_), b_ = row_of((R0) + 2 * q_ + 1);                                          \
-        OUT[q_] = (int)*reinterpret_cast<const unsigned *>(img + (size_t)(lrow ? b_ : a_) * w + ldoff);                \
+        const unsigned a_ = (unsigned)row_of((R0) + 2 * q_) * (unsigned)w, b_ = (unsigned)row_of((R0) + 2 * q_ + 1) * (unsigned)w; \
+        OUT[q_] = (int)*reinterpret_cast<const unsigned *>(img + ((lrow ? b_ : a_) + ldoff));                          \
     }
 
     float kdv = kd;
@@ -943,15 +844,34 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
     int vxxe = 0, vxye = 0, vyye = 0, vxxo = 0, vxyo = 0, vyyo = 0;
     int e1e = 0, e1o = 0, hm0e = 0, hm0o = 0, hm1e = 0, hm1o = 0;
     int nextg[NL];
-    OFK_PAIR_LOAD(0, nextg)
-#if OFK_RING_AHEAD
-    int n_oyye = 0, n_oyyo = 0, n_oxye = 0, n_oxyo = 0;          // ring slot 0 holds zeros at the start
-#endif
+    // BGR: RD row pairs (12 bytes per lane each) in flight, converted when their rows come up (OFK_PAIR_BGR_SLOT)
+    constexpr int RD = (NL % 2 == 0 && OFK_BGR_RD < NL) ? OFK_BGR_RD : NL;   // a ring shorter than the block must divide it
+    bgr_raw raw[RD];
+    unsigned cvt = 0;
+    const uint8_t *bimg = BGR ? bgr + (size_t)b * bgr_stride : nullptr;
+    uint8_t *gout = BGR ? gray_out + (size_t)b * gray_stride : nullptr;
+    const unsigned ldoff3 = 3u * ldoff, w3 = 3u * (unsigned)w;
+    const unsigned st_off = ldoff + (lrow ? (unsigned)w : 0u);
+    const bool st_col = BGR && 4 * lk >= PAD && 4 * lk < PAD + SW && G0 + 4 * lk < w;      // this strip's own 4-pixel groups
+#define OFK_PAIR_LOAD3(R, OUT)                                                                                         \
+    {                                                                                                                  \
+        const unsigned a_ = (unsigned)row_of(R) * w3, b_ = (unsigned)row_of((R) + 1) * w3;                             \
+        const unsigned *p_ = reinterpret_cast<const unsigned *>(bimg + ((lrow ? b_ : a_) + ldoff3));                   \
+        OUT.x = p_[0]; OUT.y = p_[1]; OUT.z = p_[2];                                                                   \
+    }
+    if constexpr (BGR) {
+#pragma unroll
+        for (int q = 0; q < RD; ++q) OFK_PAIR_LOAD3(2 * q, raw[q])
+    } else {
+        OFK_PAIR_LOAD(0, nextg)
+    }
 
     for (int base = 0; base < nsteps; base += BS) {
         int curv[BS];
+        if constexpr (!BGR) {
 #pragma unroll
-        for (int i = 0; i < BS; ++i) curv[i] = __builtin_amdgcn_ds_bpermute(srcsel + 128 * (i & 1), nextg[i >> 1]);
+            for (int i = 0; i < BS; ++i) curv[i] = __builtin_amdgcn_ds_bpermute(srcsel + 128 * (i & 1), nextg[i >> 1]);
+        }
         {
             unsigned cur_seen = (unsigned)__builtin_amdgcn_readfirstlane((int)mb_seen);
             if (__float_as_uint(published) > cur_seen) cur_seen = __float_as_uint(published);
@@ -966,7 +886,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
             }
             mb_seen = __hip_atomic_load(maxbits + b * OFK_MAX_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        OFK_PAIR_LOAD(base + BS, nextg)                         // prefetch the next block of rows
+        if constexpr (!BGR) OFK_PAIR_LOAD(base + BS, nextg)     // prefetch the next block of rows
         const int r1 = base + BS - 1;
         const bool interior = !edge_strip && Yp0 + base - 2 >= 0 && Yp0 + r1 - 2 < h && base >= BS + 3 && ya - 3 + base - BS >= 1 &&
                               ya - 2 + r1 - BS < yb && ya - 3 + r1 - BS < h - 1;
@@ -986,6 +906,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
 }
 
 #undef OFK_PAIR_LOAD
+#undef OFK_PAIR_LOAD3
+#undef OFK_PAIR_BGR_SLOT
 #undef OFK_PAIR_ROWS
 #undef OFK_PAIR_SPILL_KEYS
 #undef OFK_LOAD_BLOCK
@@ -1050,7 +972,7 @@ template <int BS>
 static int launch_mineig_pair(hipStream_t s, const uint8_t *gray, size_t gray_stride, int h, int w, unsigned int *maxbits,
                               const uint8_t *mask, size_t mask_stride, double quality, unsigned long long *seg,
                               size_t seg_keys_per_image, int *seg_count, int seg_count_cap, int *flags, int batch, int *nseg_out,
-                              int *segcap_out)
+                              int *segcap_out, const uint8_t *bgr = nullptr, size_t bgr_stride = 0, uint8_t *gray_out = nullptr)
 {
     constexpr int SW = pair_geom<BS>::SW, D = pair_geom<BS>::D;
     int rows, nseg, seg_cap;
@@ -1061,14 +983,35 @@ static int launch_mineig_pair(hipStream_t s, const uint8_t *gray, size_t gray_st
     const float kd = (float)(0.5 * scale * scale), ko = (float)(scale * scale);
     if (ko != 2.f * kd) return -1;                              // lambda_min_bits relies on it (always true: power-of-two scaling)
     dim3 grid(strips, (h + rows - 1) / rows, batch);
-    if (mask)
-        hipLaunchKernelGGL((k_mineig_pair<BS, true>), grid, dim3(64), 0, s, gray, gray_stride, h, w, rows, kd, ko, maxbits, mask,
-                           mask_stride, quality, seg, seg_cap, seg_count, flags);
+#define PAIR_ARGS gray, gray_stride, h, w, rows, kd, ko, maxbits, mask, mask_stride, quality, seg, seg_cap, seg_count, flags, bgr, bgr_stride, gray_out
+    if (bgr) {
+        if (mask || !gray_out || (bgr_stride & 3) != 0) return -1;
+        hipLaunchKernelGGL((k_mineig_pair<BS, false, true>), grid, dim3(64), 0, s, PAIR_ARGS);
+    } else if (mask)
+        hipLaunchKernelGGL((k_mineig_pair<BS, true, false>), grid, dim3(64), 0, s, PAIR_ARGS);
     else
-        hipLaunchKernelGGL((k_mineig_pair<BS, false>), grid, dim3(64), 0, s, gray, gray_stride, h, w, rows, kd, ko, maxbits, mask,
-                           mask_stride, quality, seg, seg_cap, seg_count, flags);
+        hipLaunchKernelGGL((k_mineig_pair<BS, false, false>), grid, dim3(64), 0, s, PAIR_ARGS);
+#undef PAIR_ARGS
     *nseg_out = nseg; *segcap_out = seg_cap;
     return 0;
+}
+
+// The pipeline's first stage: response + NMS + candidate keys straight from the BGR frames, gray level 0 written as a by-product
+// (k_mineig_pair<BS, false, true>).  false: the geometry / block size needs the gray-reading kernels (the caller converts first).
+bool ofk_mineig_bgr_ok(int w, int block) { return pair_ok(w, block) && !g_ofk_tuning.no_bgr_eig; }
+int ofk_launch_mineig_cand_bgr(hipStream_t s, const uint8_t *bgr, size_t bgr_stride, uint8_t *gray_out, size_t gray_stride, int h, int w,
+                               int block, unsigned int *maxbits, double quality, unsigned long long *seg, size_t seg_keys_per_image,
+                               int *seg_count, int seg_count_cap, int *flags, int batch, int *nseg_out, int *segcap_out)
+{
+    *nseg_out = 0; *segcap_out = 0;
+    if (!ofk_mineig_bgr_ok(w, block)) return -1;
+#define ST_ARGS s, gray_out, gray_stride, h, w, maxbits, nullptr, 0, quality, seg, seg_keys_per_image, seg_count, seg_count_cap, flags, batch, nseg_out, segcap_out, bgr, bgr_stride, gray_out
+    switch (block) {
+        case 3: return launch_mineig_pair<3>(ST_ARGS);
+        case 5: return launch_mineig_pair<5>(ST_ARGS);
+        default: return launch_mineig_pair<7>(ST_ARGS);
+    }
+#undef ST_ARGS
 }
 
 // Response + 3x3 NMS + candidate keys + image maximum; no map.  Block sizes 3/5/7/12 run the streaming kernel, which
