@@ -273,7 +273,7 @@ def main():
                     "last slice - the plain usage every RCCL build supports; S = --streams: one communicator per slice, every slice gathers its own "
                     "records on its own stream (+0.8 %% at N = 1; two collectives of one rank then run concurrently)")
     ap.add_argument("--tune", action="append", default=[], metavar="KNOB=VALUE", help="ofk_set_tuning knob for experiments (eig_rows, no_pair, "
-                    "no_pyr3, pyr3_chunks, pyr_rows, jpeg_chunk, no_bgr_eig); results do not depend on them")
+                    "no_pyr3, pyr3_chunks, pyr_rows, jpeg_chunk); results do not depend on them")
     ap.add_argument("--watchdog", type=float, default=90.0, help="seconds the bootstrap + first gathered step may take under a launcher before "
                     "the rank reports what it is waiting for and exits 3 (0 = off)")
     args = ap.parse_args()

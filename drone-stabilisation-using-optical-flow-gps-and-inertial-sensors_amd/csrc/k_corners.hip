@@ -638,47 +638,11 @@ __device__ __forceinline__ int lambda_min_bits(int vxx, int vxy, int vyy, float 
 #define OFK_RING_READ(i)                                                                                               \
         const int oyye = s_ring[(4 * (i)) * 64 + lane], oyyo = s_ring[(4 * (i) + 1) * 64 + lane];                      \
         const int oxye = s_ring[(4 * (i) + 2) * 64 + lane], oxyo = s_ring[(4 * (i) + 3) * 64 + lane];
-// BGR = true (the pipeline's first stage, round 4): the kernel reads the BGR frame itself.  The loader lane (lrow, lk) fetches the
-// 12 bytes = 4 pixels whose gray bytes it fetched as one dword before (one dwordx3 per row pair), converts them with k_gray_bgr8's integer
-// formula (k_image.hip) and holds exactly the dword the gray frame would have delivered - everything behind the ds_bpermute that hands
-// the lanes their byte pairs is unchanged, so are the results.  The strip's own 4-pixel groups of its own rows are stored as level 0 of
-// the pyramid on the way (every gray pixel by exactly one strip): the separate conversion launch of the previous frames is gone.
-//   2 (3735 B + 19235 G + 9798 R) + 32768 = 256 H + L' with H = dot(px, HI), L' = dot(px, LO) + 32768 in byte-sized coefficients;
-//   gray = (256 H + L') >> 16 = (H + (L' >> 8)) >> 8 (nested floors): v_dot4 -> v_lshrrev -> v_dot4 per pixel, the result is byte 1.
-//   Pixels 1 and 2 of the four straddle two dwords (one v_alignbit each); pixel 3 sits in bytes 1..3 of the third dword and meets
-//   coefficients shifted by one byte instead.
-__device__ __forceinline__ unsigned bgr4_to_gray4(unsigned d0, unsigned d1, unsigned d2)
-{
-    constexpr unsigned HI = 29u | (150u << 8) | (76u << 16), LO = 46u | (70u << 8) | (140u << 16);
-    const unsigned p1 = __builtin_amdgcn_alignbit(d1, d0, 24), p2 = __builtin_amdgcn_alignbit(d2, d1, 16);
-    const unsigned t0 = __builtin_amdgcn_udot4(d0, HI, __builtin_amdgcn_udot4(d0, LO, 32768u, false) >> 8, false);
-    const unsigned t1 = __builtin_amdgcn_udot4(p1, HI, __builtin_amdgcn_udot4(p1, LO, 32768u, false) >> 8, false);
-    const unsigned t2 = __builtin_amdgcn_udot4(p2, HI, __builtin_amdgcn_udot4(p2, LO, 32768u, false) >> 8, false);
-    const unsigned t3 = __builtin_amdgcn_udot4(d2, HI << 8, __builtin_amdgcn_udot4(d2, LO << 8, 32768u, false) >> 8, false);
-    return __builtin_amdgcn_perm(t1, t0, 0x0c0c0501u) | __builtin_amdgcn_perm(t3, t2, 0x05010c0cu);       // byte 1 of t0..t3
-}
-struct bgr_raw { unsigned x, y, z; };
-#ifndef OFK_BGR_RD
-#define OFK_BGR_RD 2        // TEMPORARY (measurement of the ring depth)
-#endif
-// Row pair q of the block: rows base + 2q (lanes 0-31) and base + 2q + 1 (lanes 32-63; for q = NL - 1 that row belongs to the next block
-// and is stored there).  RD row pairs are in flight: the slot is refilled with the pair RD pairs further down the march.
-#define OFK_PAIR_BGR_SLOT(q)                                                                                           \
-        {                                                                                                              \
-            const int q_ = (q), s_ = q_ % RD, pn_ = q_ + RD;                                                           \
-            cvt = bgr4_to_gray4(raw[s_].x, raw[s_].y, raw[s_].z);                                                      \
-            const int gyu_ = Yp0 - 1 + base + 2 * q_ + lrow;                                                           \
-            if (st_col && (unsigned)(gyu_ - ya) < (unsigned)(yb - ya) && !(2 * q_ + 1 == BS && lrow))                  \
-                *reinterpret_cast<unsigned *>(gout + ((unsigned)(Yp0 - 1 + base + 2 * q_) * (unsigned)w + st_off)) = cvt; \
-            OFK_PAIR_LOAD3(pn_ < NL ? base + 2 * pn_ : base + BS + 2 * (pn_ - NL), raw[s_])                            \
-        }
 // One block of BS rows (expanded twice: IN = true for interior blocks); see OFK_EIG_ROWS for the conventions.
 #define OFK_PAIR_ROWS(IN)                                                                                             \
     _Pragma("unroll") for (int i = 0; i < BS; ++i) {                                                                   \
         const int r = base + i;                                                                                        \
-        if (BGR && (i & 1) == 0) OFK_PAIR_BGR_SLOT(i >> 1)             /* convert the row pair (r, r + 1), store its gray, load one ahead */ \
-        const unsigned cur_ = BGR ? (unsigned)__builtin_amdgcn_ds_bpermute(srcsel + 128 * (i & 1), (int)cvt) : (unsigned)curv[i]; \
-        int ge2 = (int)__builtin_amdgcn_ubfe(cur_, bsh, 8u), go2 = (int)__builtin_amdgcn_ubfe(cur_, bsh + 8u, 8u);     \
+        int ge2 = (int)__builtin_amdgcn_ubfe((unsigned)curv[i], bsh, 8u), go2 = (int)__builtin_amdgcn_ubfe((unsigned)curv[i], bsh + 8u, 8u); \
         if (!(IN)) {                                                                                                   \
             if (edge_strip) { ge2 = __builtin_amdgcn_ds_bpermute(mir_e, ge2); go2 = __builtin_amdgcn_ds_bpermute(mir_o, go2); } \
         }                                                                                                              \
@@ -755,12 +719,11 @@ template <int BS> struct pair_geom {
 // had marched down its 540 rows, and the 2560 workgroups of a 256-frame launch made 3.33 rounds over the chip's 768 slots.
 // Wave-granular workgroups fill every slot: SQ counters put the wave-slot utilisation of the old launch at 66 %
 // (profiles/r02a_valu_pmc.json: 6.1 G live wave-cycles in 9.3 G slot-cycles).
-template <int BS, bool MASK, bool BGR>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_mineig_pair(
+template <int BS, bool MASK>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void k_mineig_pair(
     const uint8_t *__restrict__ gray, size_t gray_stride, int h, int w, int rows_per_strip, float kd, float ko,
     unsigned int *__restrict__ maxbits, const uint8_t *__restrict__ mask, size_t mask_stride, double quality,
-    unsigned long long *__restrict__ seg, int seg_cap, int *__restrict__ seg_count, int *__restrict__ flags,
-    const uint8_t *__restrict__ bgr, size_t bgr_stride, uint8_t *__restrict__ gray_out)
+    unsigned long long *__restrict__ seg, int seg_cap, int *__restrict__ seg_count, int *__restrict__ flags)
 {
     static_assert(BS == 3 || BS == 5 || BS == 7, "pair sums are written for odd boxes up to 7");
     constexpr int AN = pair_geom<BS>::AN, PAD = pair_geom<BS>::PAD, D = pair_geom<BS>::D, SW = pair_geom<BS>::SW;
@@ -844,34 +807,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     int vxxe = 0, vxye = 0, vyye = 0, vxxo = 0, vxyo = 0, vyyo = 0;
     int e1e = 0, e1o = 0, hm0e = 0, hm0o = 0, hm1e = 0, hm1o = 0;
     int nextg[NL];
-    // BGR: RD row pairs (12 bytes per lane each) in flight, converted when their rows come up (OFK_PAIR_BGR_SLOT)
-    constexpr int RD = (NL % 2 == 0 && OFK_BGR_RD < NL) ? OFK_BGR_RD : NL;   // a ring shorter than the block must divide it
-    bgr_raw raw[RD];
-    unsigned cvt = 0;
-    const uint8_t *bimg = BGR ? bgr + (size_t)b * bgr_stride : nullptr;
-    uint8_t *gout = BGR ? gray_out + (size_t)b * gray_stride : nullptr;
-    const unsigned ldoff3 = 3u * ldoff, w3 = 3u * (unsigned)w;
-    const unsigned st_off = ldoff + (lrow ? (unsigned)w : 0u);
-    const bool st_col = BGR && 4 * lk >= PAD && 4 * lk < PAD + SW && G0 + 4 * lk < w;      // this strip's own 4-pixel groups
-#define OFK_PAIR_LOAD3(R, OUT)                                                                                         \
-    {                                                                                                                  \
-        const unsigned a_ = (unsigned)row_of(R) * w3, b_ = (unsigned)row_of((R) + 1) * w3;                             \
-        const unsigned *p_ = reinterpret_cast<const unsigned *>(bimg + ((lrow ? b_ : a_) + ldoff3));                   \
-        OUT.x = p_[0]; OUT.y = p_[1]; OUT.z = p_[2];                                                                   \
-    }
-    if constexpr (BGR) {
-#pragma unroll
-        for (int q = 0; q < RD; ++q) OFK_PAIR_LOAD3(2 * q, raw[q])
-    } else {
-        OFK_PAIR_LOAD(0, nextg)
-    }
+    OFK_PAIR_LOAD(0, nextg)
 
     for (int base = 0; base < nsteps; base += BS) {
         int curv[BS];
-        if constexpr (!BGR) {
 #pragma unroll
-            for (int i = 0; i < BS; ++i) curv[i] = __builtin_amdgcn_ds_bpermute(srcsel + 128 * (i & 1), nextg[i >> 1]);
-        }
+        for (int i = 0; i < BS; ++i) curv[i] = __builtin_amdgcn_ds_bpermute(srcsel + 128 * (i & 1), nextg[i >> 1]);
         {
             unsigned cur_seen = (unsigned)__builtin_amdgcn_readfirstlane((int)mb_seen);
             if (__float_as_uint(published) > cur_seen) cur_seen = __float_as_uint(published);
@@ -886,7 +827,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
             }
             mb_seen = __hip_atomic_load(maxbits + b * OFK_MAX_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if constexpr (!BGR) OFK_PAIR_LOAD(base + BS, nextg)     // prefetch the next block of rows
+        OFK_PAIR_LOAD(base + BS, nextg)                         // prefetch the next block of rows
         const int r1 = base + BS - 1;
         const bool interior = !edge_strip && Yp0 + base - 2 >= 0 && Yp0 + r1 - 2 < h && base >= BS + 3 && ya - 3 + base - BS >= 1 &&
                               ya - 2 + r1 - BS < yb && ya - 3 + r1 - BS < h - 1;
@@ -906,8 +847,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 }
 
 #undef OFK_PAIR_LOAD
-#undef OFK_PAIR_LOAD3
-#undef OFK_PAIR_BGR_SLOT
 #undef OFK_PAIR_ROWS
 #undef OFK_PAIR_SPILL_KEYS
 #undef OFK_LOAD_BLOCK
@@ -972,7 +911,7 @@ template <int BS>
 static int launch_mineig_pair(hipStream_t s, const uint8_t *gray, size_t gray_stride, int h, int w, unsigned int *maxbits,
                               const uint8_t *mask, size_t mask_stride, double quality, unsigned long long *seg,
                               size_t seg_keys_per_image, int *seg_count, int seg_count_cap, int *flags, int batch, int *nseg_out,
-                              int *segcap_out, const uint8_t *bgr = nullptr, size_t bgr_stride = 0, uint8_t *gray_out = nullptr)
+                              int *segcap_out)
 {
     constexpr int SW = pair_geom<BS>::SW, D = pair_geom<BS>::D;
     int rows, nseg, seg_cap;
@@ -983,35 +922,14 @@ static int launch_mineig_pair(hipStream_t s, const uint8_t *gray, size_t gray_st
     const float kd = (float)(0.5 * scale * scale), ko = (float)(scale * scale);
     if (ko != 2.f * kd) return -1;                              // lambda_min_bits relies on it (always true: power-of-two scaling)
     dim3 grid(strips, (h + rows - 1) / rows, batch);
-#define PAIR_ARGS gray, gray_stride, h, w, rows, kd, ko, maxbits, mask, mask_stride, quality, seg, seg_cap, seg_count, flags, bgr, bgr_stride, gray_out
-    if (bgr) {
-        if (mask || !gray_out || (bgr_stride & 3) != 0) return -1;
-        hipLaunchKernelGGL((k_mineig_pair<BS, false, true>), grid, dim3(64), 0, s, PAIR_ARGS);
-    } else if (mask)
-        hipLaunchKernelGGL((k_mineig_pair<BS, true, false>), grid, dim3(64), 0, s, PAIR_ARGS);
+    if (mask)
+        hipLaunchKernelGGL((k_mineig_pair<BS, true>), grid, dim3(64), 0, s, gray, gray_stride, h, w, rows, kd, ko, maxbits, mask,
+                           mask_stride, quality, seg, seg_cap, seg_count, flags);
     else
-        hipLaunchKernelGGL((k_mineig_pair<BS, false, false>), grid, dim3(64), 0, s, PAIR_ARGS);
-#undef PAIR_ARGS
+        hipLaunchKernelGGL((k_mineig_pair<BS, false>), grid, dim3(64), 0, s, gray, gray_stride, h, w, rows, kd, ko, maxbits, mask,
+                           mask_stride, quality, seg, seg_cap, seg_count, flags);
     *nseg_out = nseg; *segcap_out = seg_cap;
     return 0;
-}
-
-// The pipeline's first stage: response + NMS + candidate keys straight from the BGR frames, gray level 0 written as a by-product
-// (k_mineig_pair<BS, false, true>).  false: the geometry / block size needs the gray-reading kernels (the caller converts first).
-bool ofk_mineig_bgr_ok(int w, int block) { return pair_ok(w, block) && !g_ofk_tuning.no_bgr_eig; }
-int ofk_launch_mineig_cand_bgr(hipStream_t s, const uint8_t *bgr, size_t bgr_stride, uint8_t *gray_out, size_t gray_stride, int h, int w,
-                               int block, unsigned int *maxbits, double quality, unsigned long long *seg, size_t seg_keys_per_image,
-                               int *seg_count, int seg_count_cap, int *flags, int batch, int *nseg_out, int *segcap_out)
-{
-    *nseg_out = 0; *segcap_out = 0;
-    if (!ofk_mineig_bgr_ok(w, block)) return -1;
-#define ST_ARGS s, gray_out, gray_stride, h, w, maxbits, nullptr, 0, quality, seg, seg_keys_per_image, seg_count, seg_count_cap, flags, batch, nseg_out, segcap_out, bgr, bgr_stride, gray_out
-    switch (block) {
-        case 3: return launch_mineig_pair<3>(ST_ARGS);
-        case 5: return launch_mineig_pair<5>(ST_ARGS);
-        default: return launch_mineig_pair<7>(ST_ARGS);
-    }
-#undef ST_ARGS
 }
 
 // Response + 3x3 NMS + candidate keys + image maximum; no map.  Block sizes 3/5/7/12 run the streaming kernel, which

@@ -53,7 +53,7 @@ static size_t levels_bytes(int h, int w, int max_level)
 // getenv on other threads and changes every other HIP user of the process (rounds 1-2 did that).  ofk_set_streams warns when the
 // value in effect is too small.
 
-ofk_tuning g_ofk_tuning = {0, 0, 0, 0, 0, 0, 0, 0};
+ofk_tuning g_ofk_tuning = {0, 0, 0, 0, 0, 0, 0};
 
 static int *tuning_slot(const char *knob, int *lo, int *hi)
 {
@@ -65,7 +65,6 @@ static int *tuning_slot(const char *knob, int *lo, int *hi)
         {"pyr_rows", &g_ofk_tuning.pyr_rows, 1, 4096},        // rows per strip of k_pyr_down_stream
         {"jpeg_chunk", &g_ofk_tuning.jpeg_chunk, 64, 256},    // bytes of entropy data per decoder thread (64, 128, 256)
         {"gray_px", &g_ofk_tuning.gray_px, 16, 64},           // experiment: one-wave workgroups of 16 / 32 / 64 pixels per thread in the BGR -> gray conversion
-        {"no_bgr_eig", &g_ofk_tuning.no_bgr_eig, 0, 1},       // 1: ofk_pairs_run converts the previous frames first and the response kernel reads gray (rounds 1-3)
     };
     for (auto &t : tab)
         if (knob && strcmp(knob, t.name) == 0) { *lo = t.lo; *hi = t.hi; return t.slot; }
@@ -153,8 +152,6 @@ extern "C" int ofk_create(int device, int max_w, int max_h, int max_batch, int m
     for (int k = 0; k < OFK_MAX_STREAMS && ok; ++k)
         ok = hipEventCreateWithFlags(&c->ev_g0[k], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&c->ev_aux[k], hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&c->ev_resp[k], hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&c->ev_pp[k], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&c->ev_lkdone[0][k], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&c->ev_lkdone[1][k], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&c->ev_end[k], hipEventDisableTiming) == hipSuccess &&
@@ -209,11 +206,8 @@ extern "C" int ofk_destroy(ofk_ctx *c)
     for (int k = 1; k < OFK_MAX_STREAMS; ++k) if (c->streams[k]) hipStreamDestroy(c->streams[k]);
     for (int k = 0; k < OFK_MAX_STREAMS; ++k) {
         if (c->aux[k]) hipStreamDestroy(c->aux[k]);
-        if (c->aux2[k]) hipStreamDestroy(c->aux2[k]);
         if (c->ev_g0[k]) hipEventDestroy(c->ev_g0[k]);
         if (c->ev_aux[k]) hipEventDestroy(c->ev_aux[k]);
-        if (c->ev_resp[k]) hipEventDestroy(c->ev_resp[k]);
-        if (c->ev_pp[k]) hipEventDestroy(c->ev_pp[k]);
         for (int s = 0; s < 2; ++s) if (c->ev_lkdone[s][k]) hipEventDestroy(c->ev_lkdone[s][k]);
     }
     for (int k = 0; k < 2; ++k) if (c->pyr_alt[k]) hipFree(c->pyr_alt[k]);
@@ -237,9 +231,6 @@ static int need_streams(ofk_ctx *c, int slices, bool overlap)
         if (!c->streams[k]) OFK_HIP(c, hipStreamCreateWithFlags(&c->streams[k], hipStreamNonBlocking));
     for (int k = 0; k < slices && overlap; ++k)
         if (!c->aux[k]) OFK_HIP(c, hipStreamCreateWithFlags(&c->aux[k], hipStreamNonBlocking));
-    // one slice: a third stream builds the previous frames' pyramid beside the selection (ofk_pairs_run); with several slices
-    // that pass stays on the slice's own stream - 3 S streams would outnumber the hardware queues
-    if (slices == 1 && overlap && !c->aux2[0]) OFK_HIP(c, hipStreamCreateWithFlags(&c->aux2[0], hipStreamNonBlocking));
     return OFK_OK;
 }
 
@@ -289,7 +280,6 @@ static int drain_all(ofk_ctx *c)
     for (int k = 0; k < OFK_MAX_STREAMS; ++k) {
         if (k && c->streams[k]) OFK_HIP(c, hipStreamSynchronize(c->streams[k]));
         if (c->aux[k]) OFK_HIP(c, hipStreamSynchronize(c->aux[k]));
-        if (c->aux2[k]) OFK_HIP(c, hipStreamSynchronize(c->aux2[k]));
     }
     return OFK_OK;
 }
@@ -981,51 +971,32 @@ extern "C" int ofk_pairs_run(ofk_ctx *c, const ofk_params *p)
         float *err = c->err + (size_t)b0 * c->max_pts;
         int *counts = c->counts + b0;
         int nseg = 0, segcap = 0;
-        // Since round 4 the response kernel reads the previous frames as BGR and leaves their gray level behind (k_mineig_pair<.., BGR>):
-        // no conversion launch for them, and the chain's first kernel waits for nothing on the auxiliary stream.  Their pyramid can only
-        // follow that kernel; it runs beside the selection, which leaves most of the chip idle (third stream when there is one slice).
-        const bool bgr_eig = !have_gray && ofk_mineig_bgr_ok(w, p->block_size);
-        auto pyramids = [&](hipStream_t q, uint8_t *a, uint8_t *b2, int images) {      // levels 1.. of one or both frame sets from level 0
-            StageTimer t(c, OFK_STAGE_PYR, q);
-            for (int l = ofk_launch_pyr3(q, a, b2, c->pyr_stride, lv, nb, images) ? 4 : 1; l <= lv.n; ++l) {
-                if (b2) ofk_launch_pyr_down2(q, a + lv.off[l - 1], b2 + lv.off[l - 1], c->pyr_stride, lv.h[l - 1], lv.w[l - 1], a + lv.off[l], b2 + lv.off[l], c->pyr_stride, nb);
-                else ofk_launch_pyr_down(q, a + lv.off[l - 1], c->pyr_stride, lv.h[l - 1], lv.w[l - 1], a + lv.off[l], c->pyr_stride, nb);
-            }
-        };
-        if (!have_gray && !bgr_eig) {
+        if (!have_gray) {
             StageTimer t(c, OFK_STAGE_GRAY, sa);
             ofk_launch_gray(sa, bgr0, c->bgr_stride, pyr0, c->pyr_stride, nb, h, w);
         }
-        if (overlap && !bgr_eig) OFK_HIP(c, hipEventRecord(c->ev_g0[k], sa));
+        if (overlap) OFK_HIP(c, hipEventRecord(c->ev_g0[k], sa));
         if (!have_gray) {
             StageTimer t(c, OFK_STAGE_GRAY, sa);
             ofk_launch_gray(sa, bgr1, c->bgr_stride, pyr1, c->pyr_stride, nb, h, w);
         }
-        if (bgr_eig) pyramids(sa, pyr1, nullptr, nb);
-        else pyramids(sa, pyr0, pyr1, 2 * nb);
+        {
+            StageTimer t(c, OFK_STAGE_PYR, sa);
+            for (int l = ofk_launch_pyr3(sa, pyr0, pyr1, c->pyr_stride, lv, nb, 2 * nb) ? 4 : 1; l <= lv.n; ++l)
+                ofk_launch_pyr_down2(sa, pyr0 + lv.off[l - 1], pyr1 + lv.off[l - 1], c->pyr_stride, lv.h[l - 1], lv.w[l - 1], pyr0 + lv.off[l],
+                                     pyr1 + lv.off[l], c->pyr_stride, nb);
+        }
         if (overlap) {
             OFK_HIP(c, hipEventRecord(c->ev_aux[k], sa));
-            if (!bgr_eig) OFK_HIP(c, hipStreamWaitEvent(st, c->ev_g0[k], 0));   // the response kernel needs the previous frame's gray level
+            OFK_HIP(c, hipStreamWaitEvent(st, c->ev_g0[k], 0));              // the response kernel needs the previous frame's gray level
         }
         if (fork && k > 0) OFK_HIP(c, hipStreamWaitEvent(st, c->ev_stagger[k - 1], 0));
         {
             StageTimer t(c, OFK_STAGE_EIG, st);                  // response + 3x3 NMS + candidate keys, no map in HBM
             ofk_launch_zero_detect_state(st, maxbits, cand_count, c->sel_hist + (size_t)b0 * 1024, nb);   // one launch, histogram of the selection included
-            const int rc = bgr_eig ? ofk_launch_mineig_cand_bgr(st, bgr0, c->bgr_stride, pyr0, c->pyr_stride, h, w, p->block_size, maxbits, p->quality, cand_seg,
-                                                                c->seg_keys, seg_count, OFK_SEG_MAX, c->dev_flags, nb, &nseg, &segcap)
-                                   : ofk_launch_mineig_cand(st, pyr0, c->pyr_stride, h, w, p->block_size, maxbits, nullptr, 0, p->quality, cand, c->cand_cap,
-                                                            cand_count, cand_seg, c->seg_keys, seg_count, OFK_SEG_MAX, c->dev_flags, nb, &nseg, &segcap);
-            if (rc) return ofk_fail(c, OFK_E_INVALID, "corner response: block_size %d does not fit (LDS tile / key segments)", p->block_size);
-        }
-        hipStream_t sp = st;                                     // where the previous frames' pyramid is built
-        if (bgr_eig) {
-            if (overlap && S == 1 && c->aux2[0]) {
-                sp = c->aux2[0];
-                OFK_HIP(c, hipEventRecord(c->ev_resp[k], st));
-                OFK_HIP(c, hipStreamWaitEvent(sp, c->ev_resp[k], 0));
-            }
-            pyramids(sp, pyr0, nullptr, nb);
-            if (sp != st) OFK_HIP(c, hipEventRecord(c->ev_pp[k], sp));
+            if (ofk_launch_mineig_cand(st, pyr0, c->pyr_stride, h, w, p->block_size, maxbits, nullptr, 0, p->quality, cand, c->cand_cap,
+                                       cand_count, cand_seg, c->seg_keys, seg_count, OFK_SEG_MAX, c->dev_flags, nb, &nseg, &segcap))
+                return ofk_fail(c, OFK_E_INVALID, "corner response: block_size %d does not fit (LDS tile / key segments)", p->block_size);
         }
         if (fork) OFK_HIP(c, hipEventRecord(c->ev_stagger[k], st));
         {
@@ -1035,7 +1006,6 @@ extern "C" int ofk_pairs_run(ofk_ctx *c, const ofk_params *p)
                               c->sel_keys + (size_t)b0 * OFK_CHUNK, true);
         }
         if (overlap) OFK_HIP(c, hipStreamWaitEvent(st, c->ev_aux[k], 0));    // LK needs both pyramids
-        if (sp != st) OFK_HIP(c, hipStreamWaitEvent(st, c->ev_pp[k], 0));
         {
             StageTimer t(c, OFK_STAGE_LK, st);
             ofk_launch_lk(st, pyr0, pyr1, c->pyr_stride, lv, pts_prev, counts, c->max_pts, p->win, p->max_count, p->eps, p->min_eig_thr,

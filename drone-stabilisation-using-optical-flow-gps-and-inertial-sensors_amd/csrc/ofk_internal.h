@@ -28,8 +28,6 @@ struct ofk_ctx {
     hipEvent_t ev_fork;
     hipStream_t aux[OFK_MAX_STREAMS]; int overlap;        // per-slice auxiliary stream: next-frame gray + pyramids beside the response kernel
     hipEvent_t ev_g0[OFK_MAX_STREAMS], ev_aux[OFK_MAX_STREAMS];
-    hipStream_t aux2[OFK_MAX_STREAMS];                    // [0] only: the previous frames' pyramid behind the BGR-reading response kernel, beside the selection
-    hipEvent_t ev_resp[OFK_MAX_STREAMS], ev_pp[OFK_MAX_STREAMS];   // response kernel done (gray level 0 of the previous frames exists) / their pyramid done
     uint8_t *pyr_alt[2]; int pyr_set;                     // second pyramid set: the auxiliary stream runs one call ahead
     int pyr_last;                                         // the set the latest ofk_pairs_run built its pyramids in (ofk_resident_pyramid)
     hipEvent_t ev_lkdone[2][OFK_MAX_STREAMS];             // LK of the call that last read a set has finished
@@ -90,7 +88,7 @@ struct ofk_ctx {
 };
 
 // Launch-geometry knobs of ofk_set_tuning (ofk.h): process-wide, 0 = the built-in choice.  Results never depend on them.
-struct ofk_tuning { int eig_rows, no_pair, no_pyr3, pyr3_chunks, pyr_rows, jpeg_chunk, gray_px, no_bgr_eig; };
+struct ofk_tuning { int eig_rows, no_pair, no_pyr3, pyr3_chunks, pyr_rows, jpeg_chunk, gray_px; };
 extern ofk_tuning g_ofk_tuning;
 
 // --- helpers (host)
@@ -137,10 +135,6 @@ int  ofk_launch_mineig_cand(hipStream_t s, const uint8_t *gray, size_t gray_stri
                             unsigned long long *cand, int cand_cap, int *cand_count, unsigned long long *seg,
                             size_t seg_keys_per_image, int *seg_count, int seg_count_cap, int *flags, int batch, int *nseg_out,
                             int *segcap_out);
-bool ofk_mineig_bgr_ok(int w, int block);   // the BGR-reading response kernel takes this geometry (else: convert first, ofk_launch_mineig_cand)
-int  ofk_launch_mineig_cand_bgr(hipStream_t s, const uint8_t *bgr, size_t bgr_stride, uint8_t *gray_out, size_t gray_stride, int h, int w,
-                                int block, unsigned int *maxbits, double quality, unsigned long long *seg, size_t seg_keys_per_image,
-                                int *seg_count, int seg_count_cap, int *flags, int batch, int *nseg_out, int *segcap_out);
 void ofk_stream_geometry(int h, int w, int block, int batch, int *rows, int *nseg, int *seg_cap);
 void ofk_launch_select(hipStream_t s, unsigned long long *cand, int cand_cap, int *cand_count, const unsigned long long *seg,
                        int seg_cap, const int *seg_count, int nseg, const unsigned int *maxbits, double quality, int h, int w,

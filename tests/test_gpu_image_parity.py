@@ -322,7 +322,7 @@ def test_tuning_knobs_do_not_change_results(gpu_ctx, pkg, ofk):
     assert len(base_pts) > 40
     try:
         for knob, values in (("no_pair", (1,)), ("eig_rows", (8, 33, 100)), ("no_pyr3", (1,)), ("pyr3_chunks", (1, 3)), ("pyr_rows", (4, 9)),
-                             ("gray_px", (16, 32, 64)), ("no_bgr_eig", (1,))):
+                             ("gray_px", (16, 32, 64))):
             for v in values:
                 ofk.set_tuning(knob, v)
                 assert np.array_equal(gpu_ctx.good_features(g, 120, 0.02, 6, 7), base_pts), (knob, v)
@@ -333,6 +333,6 @@ def test_tuning_knobs_do_not_change_results(gpu_ctx, pkg, ofk):
                     assert np.array_equal(out[key], base_out[key]), (knob, v, key)
             ofk.set_tuning(knob, 0)
     finally:
-        for knob in ("no_pair", "eig_rows", "no_pyr3", "pyr3_chunks", "pyr_rows", "jpeg_chunk", "gray_px", "no_bgr_eig"):
+        for knob in ("no_pair", "eig_rows", "no_pyr3", "pyr3_chunks", "pyr_rows", "jpeg_chunk", "gray_px"):
             ofk.set_tuning(knob, 0)
     pipe.close()
