@@ -34,13 +34,8 @@
 #define JCH_MIN 64              // batches (a single 1080p frame: 7000 threads of 64 bytes), where latency counts, not throughput
 #define JB0 4                   // a symbol belongs to chunk i if the byte cursor after the refill is in [i*JCH + JB0, (i+1)*JCH + JB0)
                                 // (the guess of chunk i starts with the cursor at i*JCH + 4 after its first refill)
-#ifndef J_NOFLUSH
-#define J_NOFLUSH 0
-#endif
 #define JTPB 256                // decoder threads per workgroup (chunks of ONE image: the tables live in LDS)
-#ifndef JTPW
 #define JTPW 256                // ... of the coefficient-writing pass (its LDS rows bound the occupancy)
-#endif
 #define JMAX_ITERS 64           // flag slots; more iterations than this are read back one by one
 
 struct jpeg_tab {               // per image
@@ -325,9 +320,7 @@ __global__ __launch_bounds__(1024) void k_jpeg_scan(const jpeg_tab *__restrict__
 // The few coefficients behind position JROW_K (the high-frequency half: a few per cent at camera qualities) go straight to the
 // zeroed coefficient buffer.  A block that straddles a chunk boundary is shared with the neighbouring thread: its parts are
 // scattered element-wise onto the zeroed background instead.
-#ifndef JROW_K
 #define JROW_K 32
-#endif
 #define JBLK_PITCH (JROW_K + 2)                                   // int16 per LDS row: an odd number of dwords spreads the lanes over the banks
 struct jemit_store {
     int16_t *row;                                                 // this thread's LDS row (zigzag order, zero between blocks)
@@ -351,9 +344,6 @@ struct jemit_store {
     __device__ void drain()
     {
         if (!pend_dst) return;
-#if J_NOFLUSH == 2
-        if (pend[0].x != 0x12345678u) { pend_dst = nullptr; return; }
-#endif
 #pragma unroll
         for (int q = 0; q < JROW_K / 8; ++q) pend_dst[q] = pend[q];
         pend_dst = nullptr;
@@ -363,18 +353,14 @@ struct jemit_store {
         const int n = n0 + done;
         cur = done + 1;
         if (n >= nblk) return;
-#if J_NOFLUSH == 1                                               // timing experiments only (wrong pixels)
-        return;
-#endif
         if (done == 0 && head_partial) { scatter(n); return; }
         drain();
         uint32_t *src = (uint32_t *)row;
         pend_dst = (uint4 *)(out + (size_t)n * 64);
 #pragma unroll
-        for (int q = 0; q < JROW_K / 8; ++q) { pend[q] = make_uint4(src[4 * q], src[4 * q + 1], src[4 * q + 2], src[4 * q + 3]);
-#if J_NOFLUSH != 3
+        for (int q = 0; q < JROW_K / 8; ++q) {
+            pend[q] = make_uint4(src[4 * q], src[4 * q + 1], src[4 * q + 2], src[4 * q + 3]);
             src[4 * q] = src[4 * q + 1] = src[4 * q + 2] = src[4 * q + 3] = 0;
-#endif
         }
     }
 };
@@ -1008,6 +994,10 @@ static int jdecode_staged(ofk_ctx *c, int slot, uint8_t *dst, uint8_t *dst2, int
     const jpeg_geom g = J.g;
     const int batch = J.batch, nch_max = J.nch_max;
     if (dst && (size_t)g.w * g.h > dst_capacity_px) return ofk_fail(c, OFK_E_INVALID, "ofk_jpeg: %dx%d frames exceed the destination", g.w, g.h);
+    // a caller-supplied destination is one of the context's resident buffers: max_batch images each (checked BEFORE any kernel is queued -
+    // the colour pass would write past them)
+    if (dst && ((split < batch ? split : batch) > c->max_batch || (dst2 && split < batch && batch - split > c->max_batch)))
+        return ofk_fail(c, OFK_E_INVALID, "ofk_jpeg: %d staged streams exceed the context's %d images per frame set", batch, c->max_batch);
     // device scratch
     const size_t B = (size_t)batch;
     size_t off = 0;
@@ -1100,7 +1090,8 @@ int ofk_jpeg_decode_staged_pairs(ofk_ctx *c, int slot, uint8_t *dst_prev, uint8_
     jstages *js = (jstages *)c->jstage;
     if (!js || slot < 0 || slot > 1 || !js->slot[slot].valid) return ofk_fail(c, OFK_E_INVALID, "ofk_pairs_upload_staged: slot %d holds no staged streams (ofk_jpeg_stage)", slot);
     const int count = js->slot[slot].batch;
-    if (count & 1) return ofk_fail(c, OFK_E_INVALID, "ofk_pairs_upload_staged: %d staged streams are not pairs (previous frames first, then the next frames)", count);
+    if (count & 1) { js->slot[slot].valid = 0; return ofk_fail(c, OFK_E_INVALID, "ofk_pairs_upload_staged: %d staged streams are not pairs (previous frames first, then the next frames)", count); }
+    if (count / 2 > c->max_batch) { js->slot[slot].valid = 0; return ofk_fail(c, OFK_E_INVALID, "ofk_pairs_upload_staged: %d pairs exceed the context (%d)", count / 2, c->max_batch); }
     if (batch_out) *batch_out = count / 2;
     return jdecode_staged(c, slot, dst_prev, dst_next, count / 2, dst_stride, dst_capacity_px, h_out, w_out, nullptr, nullptr, wait_before_writing != nullptr,
                           wait_before_writing, nwait, as_gray);

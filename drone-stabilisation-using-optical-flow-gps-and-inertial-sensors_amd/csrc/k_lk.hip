@@ -687,11 +687,7 @@ __device__ __forceinline__ void lkq_store_row(unsigned *o, unsigned *dump, int l
 
 // 120 VGPRs (amdgpu_num_vgpr counts register PAIRS of the unified file: 60): four waves per SIMD leave 32 registers, i.e. room for one
 // 32-register gray wave beside them - the compiler's own allocation after the pixel-pair packing is 124, which takes that room away
-#ifdef OFK_LK_NOCAP
-#define OFK_LKQ_ATTR
-#else
 #define OFK_LKQ_ATTR __attribute__((amdgpu_num_vgpr(60)))
-#endif
 __global__ __launch_bounds__(64) OFK_LKQ_ATTR void k_lk15q(const uint8_t *__restrict__ prev, const uint8_t *__restrict__ next, size_t pyr_stride,
                                               ofk_levels lv, const float *__restrict__ prev_pts, const int *__restrict__ counts,
                                               int pts_stride, int max_count, double eps2, float eps2_lo, float eps2_hi,
