@@ -87,22 +87,16 @@ extern "C" int ofk_comm_init(ofk_ctx *c, const uint8_t *ids, int n_ids, int rank
     // creation order (see ofk_set_streams)
     rc = ofk_prepare_streams(c);
     if (rc != OFK_OK) { ofk_comm_destroy(c); return rc; }
-    for (int k = 0; k < n_ids; ++k) {
+    {   // communicator 0: the one every rank needs (gathers with one slice, all-reduces, barriers)
         ncclUniqueId id;
-        memcpy(id.internal, ids + (size_t)k * NCCL_UNIQUE_ID_BYTES, NCCL_UNIQUE_ID_BYTES);
-        ncclResult_t r = m->comm_init_rank(&m->comm[k], world, id, rank);
+        memcpy(id.internal, ids, NCCL_UNIQUE_ID_BYTES);
+        ncclResult_t r = m->comm_init_rank(&m->comm[0], world, id, rank);
         if (r != ncclSuccess) {
-            if (k == 0) {
-                ofk_fail(c, OFK_E_HIP, "ncclCommInitRank(communicator 0, rank %d of %d): %s", rank, world, m->error_string(r));
-                ofk_comm_destroy(c);
-                return OFK_E_HIP;
-            }
-            // a per-slice communicator is an optimisation: without it the step's records travel in ONE gather behind the last slice
-            fprintf(stderr, "libofk: rank %d: ncclCommInitRank of communicator %d failed (%s); gathering on %d communicator(s)\n", rank, k, m->error_string(r), k);
-            m->comm[k] = nullptr;
-            break;
+            ofk_fail(c, OFK_E_HIP, "ncclCommInitRank(communicator 0, rank %d of %d): %s", rank, world, m->error_string(r));
+            ofk_comm_destroy(c);
+            return OFK_E_HIP;
         }
-        m->ncomm = k + 1;
+        m->ncomm = 1;
     }
     m->rank = rank; m->world = world; m->cap_batch = c->max_batch;
     const size_t sb = (size_t)c->max_batch * 8 * sizeof(float);
@@ -115,15 +109,40 @@ extern "C" int ofk_comm_init(ofk_ctx *c, const uint8_t *ids, int n_ids, int rank
     ok = ok && hipMalloc((void **)&m->red, 64 * sizeof(double)) == hipSuccess && hipHostMalloc(&m->hred, 64 * sizeof(double)) == hipSuccess &&
          hipHostMalloc((void **)&m->hrecv, m->hrecv_bytes) == hipSuccess;
     if (!ok) { ofk_comm_destroy(c); return ofk_fail(c, OFK_E_HIP, "ofk_comm_init: device buffers"); }
-    // every rank must cut its gathers the same way: agree on the smallest communicator count any rank ended up with
+    // Per-slice communicators (n_ids > 1).  ncclCommInitRank is collective: a rank that gave up on communicator k while its peers were
+    // inside that call would leave them waiting for ever, so the COUNT is agreed first - the smallest n_ids any rank passed, one
+    // all-reduce over communicator 0 - then every rank creates exactly that many, and a failure from here on is fatal (error return,
+    // everything destroyed; the launcher ends the job), never a silent per-rank fallback.
     if (n_ids > 1) {
-        double have = (double)m->ncomm;
-        rc = ofk_comm_allreduce_f64(c, &have, 1, 2);
+        double want = (double)n_ids;
+        rc = ofk_comm_allreduce_f64(c, &want, 1, 2);
         if (rc != OFK_OK) { ofk_comm_destroy(c); return rc; }
-        const int agreed = (int)have < 1 ? 1 : (int)have;
-        for (int k = agreed; k < m->ncomm; ++k) { m->comm_destroy(m->comm[k]); m->comm[k] = nullptr; }
-        if (agreed < m->ncomm) m->ncomm = agreed;
+        const int agreed = (int)want < 1 ? 1 : (int)want;
+        for (int k = 1; k < agreed; ++k) {
+            rc = ofk_comm_add(c, ids + (size_t)k * NCCL_UNIQUE_ID_BYTES);
+            if (rc != OFK_OK) { ofk_comm_destroy(c); return rc; }
+        }
     }
+    return OFK_OK;
+}
+
+// One more communicator (a slice of its own to gather on).  Collective: every rank of the world calls it the same number of times with
+// the same ids (sharding.Comm agrees on the count over communicator 0 first); an error here cannot be recovered from locally.
+extern "C" int ofk_comm_add(ofk_ctx *c, const uint8_t *id_bytes)
+{
+    if (!c || !c->comm || !id_bytes) return ofk_fail(c, OFK_E_INVALID, "ofk_comm_add: no communicator 0 yet (ofk_comm_init) or NULL id");
+    ofk_comm *m = c->comm;
+    if (m->ncomm >= OFK_MAX_STREAMS) return ofk_fail(c, OFK_E_INVALID, "ofk_comm_add: at most %d communicators", OFK_MAX_STREAMS);
+    OFK_HIP(c, hipSetDevice(c->device));
+    ncclUniqueId id;
+    memcpy(id.internal, id_bytes, NCCL_UNIQUE_ID_BYTES);
+    ncclResult_t r = m->comm_init_rank(&m->comm[m->ncomm], m->world, id, m->rank);
+    if (r != ncclSuccess) {
+        m->comm[m->ncomm] = nullptr;
+        return ofk_fail(c, OFK_E_HIP, "ncclCommInitRank(communicator %d, rank %d of %d): %s - the ranks had agreed on this communicator, so this is fatal "
+                        "for the job (run with one communicator: --comms 1)", m->ncomm, m->rank, m->world, m->error_string(r));
+    }
+    ++m->ncomm;
     return OFK_OK;
 }
 

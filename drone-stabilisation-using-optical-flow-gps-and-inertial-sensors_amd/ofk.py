@@ -32,7 +32,7 @@ SYMBOLS = (
     "ofk_set_streams", "ofk_set_overlap", "ofk_set_tuning", "ofk_get_tuning", "ofk_mark", "ofk_mark_wait", "ofk_profile_enable", "ofk_profile_read", "ofk_resident_pyramid",
     "ofk_imu_reset", "ofk_imu_push", "ofk_imu_state", "ofk_filter_configure", "ofk_filter_state", "ofk_stream_step_fused",
     "ofk_stream_step_fused_jpeg", "ofk_stream_last_points", "ofk_pairs_filter_step",
-    "ofk_comm_unique_id", "ofk_comm_init", "ofk_comm_destroy", "ofk_comm_rank", "ofk_comm_world", "ofk_comm_gather_records",
+    "ofk_comm_unique_id", "ofk_comm_init", "ofk_comm_add", "ofk_comm_destroy", "ofk_comm_rank", "ofk_comm_world", "ofk_comm_gather_records",
     "ofk_comm_fetch_records", "ofk_comm_allreduce_f64", "ofk_comm_count", "ofk_comm_pending", "ofk_comm_reorder_records",
 )
 
@@ -142,7 +142,7 @@ def load_library():
         L.ofk_profile_enable.argtypes = [vp, i]
         L.ofk_profile_read.argtypes = [vp, vp, vp]
         L.ofk_resident_pyramid.argtypes = [vp, i, i, vp, C.c_size_t]
-        L.ofk_comm_unique_id.argtypes = [vp, i]; L.ofk_comm_init.argtypes = [vp, vp, i, i, i]; L.ofk_comm_destroy.argtypes = [vp]
+        L.ofk_comm_unique_id.argtypes = [vp, i]; L.ofk_comm_init.argtypes = [vp, vp, i, i, i]; L.ofk_comm_add.argtypes = [vp, vp]; L.ofk_comm_destroy.argtypes = [vp]
         L.ofk_comm_rank.argtypes = [vp]; L.ofk_comm_world.argtypes = [vp]
         L.ofk_comm_gather_records.argtypes = [vp, i, i]; L.ofk_comm_fetch_records.argtypes = [vp, i, i, vp]
         L.ofk_comm_allreduce_f64.argtypes = [vp, vp, i, i]
@@ -741,6 +741,14 @@ class Context:
         with self._lock:
             self._ck(self._L.ofk_comm_init(self._h, _p(uid), uid.size // 128, int(rank), int(world)))
         self.comm_rank, self.comm_world = int(rank), int(world)
+
+    def comm_add(self, unique_id):
+        """One more communicator (128-byte id).  Collective: every rank calls it, in the same order; an error is fatal for the job."""
+        uid = np.frombuffer(bytes(unique_id), np.uint8).copy()
+        if uid.size != 128:
+            raise ValueError("one 128-byte RCCL unique id")
+        with self._lock:
+            self._ck(self._L.ofk_comm_add(self._h, _p(uid)))
 
     def comm_destroy(self):
         with self._lock:

@@ -78,9 +78,35 @@ def rendezvous_path(environ=None, directory=None, generation=None):
     return os.path.join(d, f"ofk_rccl_uid_{key}_g{g}")
 
 
+_TOKEN = b"OFKTOKEN"
+
+
+def _token(pid=None):
+    """Launch token rank 0 appends to the published ids: its pid and that process's start time.  A reader accepts a file only while
+    that very process is alive - whatever a crashed earlier run with the same MASTER_ADDR:PORT left behind fails the check even when the
+    launcher (an interactive shell, a slurm step daemon, pytest) is older than the leftover and the modification-time rule cannot tell."""
+    pid = os.getpid() if pid is None else pid
+    t = _proc_start_time(pid)
+    return _TOKEN + int(pid).to_bytes(8, "little") + int(round((t or 0.0) * 100)).to_bytes(8, "little")
+
+
+def _token_alive(tok):
+    """True / False for a token whose writer is / is not the live process it names; None when /proc cannot tell."""
+    if len(tok) != 24 or tok[:8] != _TOKEN:
+        return False
+    pid, t100 = int.from_bytes(tok[8:16], "little"), int.from_bytes(tok[16:24], "little")
+    if not os.path.isdir("/proc/self"):
+        return None
+    t = _proc_start_time(pid)
+    if t is None:
+        return False
+    return abs(int(round(t * 100)) - t100) <= 1
+
+
 def exchange_unique_id(make_id, rank, world, path=None, timeout=120.0, nbytes=128, not_before=None):
-    """Rank 0 calls make_id() -> bytes and publishes them (stale file removed, write, atomic rename); the other ranks poll the
-    file and ignore one that is older than the launch (`not_before`, default launch_epoch()).  Returns the id on every rank.
+    """Rank 0 calls make_id() -> bytes and publishes them followed by its launch token (stale file removed, write, atomic rename); the
+    other ranks poll the file, ignore one that is older than the launch (`not_before`, default launch_epoch()) or whose token does not
+    name a live process, and return the ids.  nbytes = None accepts any positive multiple of 128 bytes (rank 0 decides how many ids).
     Rank 0 removes the file once every rank has acknowledged (one small file per rank).  Every call of a process uses the next
     generation's file name unless `path` is given."""
     global _exchange_generation
@@ -96,11 +122,11 @@ def exchange_unique_id(make_id, rank, world, path=None, timeout=120.0, nbytes=12
             except OSError:
                 pass
         uid = bytes(make_id())
-        if len(uid) != nbytes:
-            raise ValueError(f"unique id has {len(uid)} bytes, expected {nbytes}")
+        if (nbytes is not None and len(uid) != nbytes) or not uid or len(uid) % 128:
+            raise ValueError(f"unique id has {len(uid)} bytes, expected {nbytes or 'a multiple of 128'}")
         tmp = f"{path}.tmp{os.getpid()}"
         with open(tmp, "wb") as f:
-            f.write(uid)
+            f.write(uid + _token())
         os.replace(tmp, path)
         deadline = time.monotonic() + timeout
         pending = set(range(1, world))
@@ -131,16 +157,18 @@ def exchange_unique_id(make_id, rank, world, path=None, timeout=120.0, nbytes=12
                 stale_seen = True                               # a crashed earlier run's file: rank 0 of this launch replaces it
             else:
                 with open(path, "rb") as f:
-                    uid = f.read()
-                if len(uid) == nbytes:
+                    blob = f.read()
+                uid, tok = blob[:-24], blob[-24:]
+                if uid and len(uid) % 128 == 0 and (nbytes is None or len(uid) == nbytes) and _token_alive(tok) is not False:
                     with open(f"{path}.ack{rank}", "wb") as f:
                         f.write(b"1")
                     return uid
+                stale_seen = True                               # well-formed or not: not published by a live rank 0 of this launch
         except OSError:
             pass
         time.sleep(0.005)
     raise TimeoutError(f"rank {rank} of {world}: no unique id at {path} after {timeout} s" +
-                       (" (only a stale file from before this launch was there)" if stale_seen else "") +
+                       (" (only a stale file - older than this launch, or written by a process that no longer exists - was there)" if stale_seen else "") +
                        f"; rank 0 publishes it there - MASTER_ADDR/MASTER_PORT here: {os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}")
 
 
@@ -162,9 +190,20 @@ class Comm:
         self.ctx, self.rank, self.world = ctx, int(rank), int(world)
         # one communicator per free-running slice (ofk_set_streams): each slice then gathers its own records on its own stream
         # (make_id: a stand-in for ncclGetUniqueId where no RCCL exists - the CPU tests drive this class against a fake context)
-        uid = exchange_unique_id(make_id or (lambda: ofk.comm_unique_id(n_comms)), self.rank, self.world, path=path, nbytes=128 * int(n_comms))
-        ctx.comm_init(uid, self.rank, self.world)
-        self.n_comms = ctx.comm_count()                          # what the ranks agreed on (a failed per-slice communicator is dropped everywhere)
+        uid = exchange_unique_id(make_id or (lambda: ofk.comm_unique_id(n_comms)), self.rank, self.world, path=path, nbytes=None)
+        have = len(uid) // 128                                   # ids rank 0 drew: the same number on every rank
+        ctx.comm_init(uid[:128], self.rank, self.world)          # communicator 0: every rank needs it, a failure here raises
+        # ncclCommInitRank is collective, so the number of per-slice communicators is decided BEFORE any of them is created: the
+        # smallest count any rank wants (its n_comms, at most the ids there are), one all-reduce over communicator 0.  Every rank
+        # then creates exactly that many; an error behind the agreement raises (fatal for the job: the peers are inside the call).
+        agreed = 1
+        if have > 1:
+            agreed = max(1, int(ctx.comm_allreduce([float(min(int(n_comms), have))], "min")[0]))
+        for k in range(1, agreed):
+            ctx.comm_add(uid[128 * k:128 * (k + 1)])
+        self.n_comms = ctx.comm_count()
+        if self.n_comms != agreed:
+            raise RuntimeError(f"rank {self.rank}: holds {self.n_comms} communicators, the ranks agreed on {agreed}")
 
     def pending(self, slot=0):
         """Bitmask of the slices whose gather of `slot` is still travelling (non-blocking; for watchdogs)."""

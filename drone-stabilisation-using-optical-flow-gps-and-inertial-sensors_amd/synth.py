@@ -88,6 +88,21 @@ def render_pair(h, w, seed, v=(0.003, -0.002, 0.001), omega=(0.002, -0.001, 0.00
                 omega=np.asarray(omega, np.float64), d=float(d), n=np.asarray(n, np.float64))
 
 
+def warp_frame(bgr, H):
+    """A BGR uint8 frame seen through the pixel homography H (prev -> next), bilinear, edge pixels replicated: the `next` frame of a
+    pair whose `prev` is a given picture (a real camera frame instead of make_texture)."""
+    h, w = bgr.shape[:2]
+    Hi = np.linalg.inv(H)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    den = Hi[2, 0] * xx + Hi[2, 1] * yy + Hi[2, 2]
+    sx = (Hi[0, 0] * xx + Hi[0, 1] * yy + Hi[0, 2]) / den
+    sy = (Hi[1, 0] * xx + Hi[1, 1] * yy + Hi[1, 2]) / den
+    out = np.empty_like(bgr)
+    for ch in range(bgr.shape[2]):
+        out[..., ch] = np.clip(np.rint(_bilinear(bgr[..., ch].astype(np.float32), sx, sy)), 0, 255).astype(np.uint8)
+    return out
+
+
 def render_sequence(h, w, seed, n_frames, v=(0.003, -0.002, 0.001), omega=(0.002, -0.001, 0.003), d=1.0, n=(0, 0, 1),
                     scaling=None, margin=96):
     """`n_frames` BGR frames of one stream under constant per-frame motion: frame k shows the texture through H^k.

@@ -360,9 +360,14 @@ int ofk_jpeg_decode_bgr8(ofk_ctx *ctx, const uint8_t *const *jpeg, const size_t 
  * GPU) owns its own pairs and the only exchange is an all-gather of the per-pair velocity records.  librccl.so is bound at run
  * time (dlopen) by the first ofk_comm_* call; a single-GPU program never needs it.
  *   ofk_comm_unique_id     rank 0: n_ids x ncclGetUniqueId -> n_ids x 128 bytes the caller hands to every rank (file, socket ...)
- *   ofk_comm_init          n_ids x ncclCommInitRank on the context's device (one communicator per free-running slice of
- *                          ofk_set_streams, so that every slice gathers its own records on its own stream; one is enough for
- *                          correctness); allocates the gather buffers
+ *   ofk_comm_init          ncclCommInitRank of communicator 0 on the context's device + the gather buffers.  With n_ids > 1 (one
+ *                          communicator per free-running slice of ofk_set_streams, so that every slice gathers its own records on its
+ *                          own stream; one is enough for correctness) the ranks first agree on the smallest n_ids any of them passed
+ *                          (an all-reduce over communicator 0) and then create exactly that many.  ncclCommInitRank is collective, so
+ *                          a failure behind that agreement is an error return on the rank that sees it - fatal for the job, never a
+ *                          per-rank fallback that would leave the peers waiting inside the call
+ *   ofk_comm_add           one more communicator from a 128-byte id; collective (every rank, same order); what ofk_comm_init does
+ *                          n_ids - 1 times, exported for callers that negotiate the count themselves (sharding.Comm)
  *   ofk_comm_gather_records  k_records_f32 of the latest ofk_pairs_run + ncclAllGather of [batch][8] f32 {vx,vy,vz,residual,
  *                          n_used,s_min,rank,corners} into the context's receive buffer `slot` (0/1), queued behind the step on
  *                          the library's own stream: no host wait, step k+1 can be queued at once
@@ -371,14 +376,14 @@ int ofk_jpeg_decode_bgr8(ofk_ctx *ctx, const uint8_t *const *jpeg, const size_t 
  *                          timing, and the Monte-Carlo sweep's per-step (sum v, sum v^2, count) statistics */
 int ofk_comm_unique_id(uint8_t *ids, int n_ids);
 int ofk_comm_init(ofk_ctx *ctx, const uint8_t *ids, int n_ids, int rank, int world);
+int ofk_comm_add(ofk_ctx *ctx, const uint8_t *id);
 int ofk_comm_destroy(ofk_ctx *ctx);
 int ofk_comm_rank(const ofk_ctx *ctx);
 int ofk_comm_world(const ofk_ctx *ctx);
 int ofk_comm_gather_records(ofk_ctx *ctx, int batch, int slot);
 int ofk_comm_fetch_records(ofk_ctx *ctx, int slot, int batch, float *host_out);
 int ofk_comm_allreduce_f64(ofk_ctx *ctx, double *inout, int n, int op);
-/* Communicators the ranks agreed on at ofk_comm_init (a per-slice communicator whose ncclCommInitRank fails on any rank is
- * dropped everywhere, down to one: the step's records then travel in one gather behind the last slice). */
+/* Communicators this rank holds = what the ranks agreed on (1: the step's records travel in one gather behind the last slice). */
 int ofk_comm_count(const ofk_ctx *ctx);
 /* Non-blocking watchdog query: bit k set = the gather of slice k of `slot` has not completed (0 = done / nothing queued). */
 int ofk_comm_pending(ofk_ctx *ctx, int slot);

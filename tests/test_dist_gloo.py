@@ -103,7 +103,7 @@ BOOT = textwrap.dedent("""
 """) % ROOT
 
 
-def _run_world(script_text, tmp_path, extra_env):
+def _run_world(script_text, tmp_path, extra_env, expect_rc=0):
     script = tmp_path / "worker.py"
     script.write_text(script_text)
     with socket.socket() as s:
@@ -114,7 +114,8 @@ def _run_world(script_text, tmp_path, extra_env):
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=240)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
-        assert p.returncode == 0 and f"rank {r} ok" in o, o
+        assert p.returncode == expect_rc and (expect_rc != 0 or f"rank {r} ok" in o), o
+    return outs
 
 
 def test_world2_gloo_gather_and_shard(tmp_path):
@@ -132,11 +133,42 @@ def test_world2_bootstrap_with_fake_collective(tmp_path):
     assert not stale.exists() and not (tmp_path / "rdv.ack1").exists()      # rank 0 cleaned the rendezvous files up
 
 
+def test_world2_bootstrap_ignores_a_fresh_file_of_a_dead_publisher(tmp_path, pkg):
+    """The long-lived-parent case: the launcher (a shell, a slurm step daemon, pytest) is OLDER than the file a crashed earlier run
+    left under the same MASTER_ADDR:PORT, so the modification-time rule accepts it.  The launch token does not: the file names a
+    rank-0 process that no longer exists, readers skip it and rank 0 of this launch replaces it."""
+    from of_amd import sharding
+    dead = subprocess.Popen([sys.executable, "-c", "import time; time.sleep(30)"])
+    tok = sharding._token(dead.pid)
+    assert sharding._token_alive(tok) is True
+    dead.kill(); dead.wait()
+    assert sharding._token_alive(tok) is False and sharding._token_alive(b"x" * 24) is False
+    stale = tmp_path / "rdv"
+    stale.write_bytes(bytes([7]) * 128 + tok)                   # well-formed, brand new, published by nobody alive
+    _run_world(BOOT, tmp_path, {"OFK_TEST_RDV": str(stale)})
+    assert not stale.exists()
+
+
 COMM = open(os.path.join(ROOT, "tests", "comm_sequence_worker.py")).read()
 
 
 def test_world2_comm_sequence_with_fake_context(tmp_path):
     _run_world(COMM, tmp_path, {"OFK_TEST_RDV": str(tmp_path / "rdv"), "OFK_TEST_ROOT": ROOT})
+
+
+def test_world2_communicator_count_is_agreed_before_any_is_created(tmp_path):
+    """Rank 1 can afford one communicator, rank 0 asks for two: the count is settled by an all-reduce over communicator 0 BEFORE a
+    second ncclCommInitRank is attempted anywhere, so both ranks end on one communicator, nobody waits inside a collective call the
+    other never enters, and the gathers (one slice) deliver every rank's records."""
+    _run_world(COMM, tmp_path, {"OFK_TEST_RDV": str(tmp_path / "rdv"), "OFK_TEST_ROOT": ROOT, "OFK_TEST_SCENARIO": "afford1"})
+
+
+def test_world2_failed_communicator_behind_the_agreement_is_fatal_on_both_ranks(tmp_path):
+    """A rank-local failure of the second ncclCommInitRank AFTER the ranks agreed on two: the failing rank raises and exits non-zero,
+    its peer is released from the collective call by the time-out with an error - no rank carries on with a different communicator
+    count, none hangs."""
+    outs = _run_world(COMM, tmp_path, {"OFK_TEST_RDV": str(tmp_path / "rdv"), "OFK_TEST_ROOT": ROOT, "OFK_TEST_SCENARIO": "addfail"}, expect_rc=7)
+    assert "simulated local failure" in outs[1] and "peers never entered" in outs[0]
 
 
 def test_reorder_records_matches_numpy_for_uneven_cuts():

@@ -208,6 +208,38 @@ def test_double_buffered_ingest_matches_the_one_shot_path(pkg, ofk, streams_per_
 
 
 @pytest.mark.gpu
+def test_staged_ingest_refuses_more_pairs_than_the_context_holds(pkg, ofk):
+    """ofk_jpeg_stage accepts any count; ofk_pairs_upload_staged must refuse 2 * (max_batch + 1) streams - and an odd count - BEFORE a
+    decoder kernel is queued: the colour pass would write past the resident frame sets.  The resident pairs of an earlier upload
+    stay untouched (records of a re-run are the same bits) and the slot is spent."""
+    from of_amd import synth
+    from of_amd.pipeline import FlowPipeline, PipelineConfig
+    h, w, B = 240, 320, 2
+    pairs = [synth.render_pair(h, w, 170 + b) for b in range(B + 1)]
+    sp = [_encode(p["prev"], 90, 2) for p in pairs]; sn = [_encode(p["next"], 90, 2) for p in pairs]
+    sensors = ofk.make_sensors(B, scaling=pairs[0]["scaling"], cx=pairs[0]["cx"], cy=pairs[0]["cy"])
+    cfg = PipelineConfig(max_corners=60, quality=0.03, min_distance=7, max_level=2)
+    for streams in (1, 2):                                                       # gray-direct path and the BGR path
+        pipe = FlowPipeline(w, h, B, cfg, streams=streams)
+        pipe.upload_jpeg(sp[:B], sn[:B], sensors)
+        ref = pipe.run()
+        ref_pyr = pipe.ctx.resident_pyramid(0, B - 1, h, w, 2)
+        for bad in (sp + sn, sp[:B] + sn[:B - 1]):                               # B + 1 pairs; an odd count
+            st = pipe.ctx.jpeg_stage(1, bad)
+            with pytest.raises(ofk.OfkError) as e:
+                pipe.ctx.pairs_upload_staged(1, st)
+            assert e.value.code == ofk.E_INVALID
+            with pytest.raises(ofk.OfkError):                                    # the slot is spent
+                pipe.ctx.pairs_upload_staged(1, st)
+        pipe.upload_jpeg(sp[:B], sn[:B], sensors)
+        out = pipe.run()
+        for k in ("counts", "prev_pts", "next_pts", "status", "records"):
+            assert np.array_equal(out[k], ref[k]), k
+        assert all(np.array_equal(a, b) for a, b in zip(pipe.ctx.resident_pyramid(0, B - 1, h, w, 2), ref_pyr))
+        pipe.close()
+
+
+@pytest.mark.gpu
 def test_gray_direct_ingest_state_machine(pkg, ofk):
     """The compressed ingest writes the gray frames straight into one pyramid set and no BGR frame (ofk_pairs_upload_staged on the
     default schedule): a second run without a new upload, a run after the schedule changed to two slices, odd frame sizes (the byte
