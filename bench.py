@@ -7,7 +7,7 @@
 
 Default (--config c1) = BASELINE.json configs[1], the configuration the metric is quoted on: 1920x1080 frame pairs, 500 Shi-Tomasi
 corners, 3-level LK pyramid.  --config c2 = configs[2] (1024 independent 640x480 pairs per step + the per-pair 6-state filter update
-queued behind every step), --config c4 = configs[4]'s pair workload (3840x2160, 2000 corners, 5-level pyramid, 128 pairs per step);
+queued behind every step), --config c4 = configs[4]'s pair workload (3840x2160, 2000 corners, 5-level pyramid, 256 pairs per step);
 same JSON contract, `config.workload` names the BASELINE entry, roofline and traffic come from that configuration's own PMC passes
 (profiles/<tag>c2_*, <tag>c4_*).
 
@@ -96,7 +96,7 @@ CONFIGS = {
                workload="1920x1080 frame pairs, 500 Shi-Tomasi corners, 3-level LK pyramid (BASELINE configs[1])"),
     "c2": dict(h=480, w=640, corners=500, levels=3, batch=1024, streams=2, ekf=True, cpu_sample=128, tag="c2",
                workload="batch of 1024 independent 640x480 frame pairs + per-pair 6-state EKF update (BASELINE configs[2])"),
-    "c4": dict(h=2160, w=3840, corners=2000, levels=5, batch=128, streams=1, ekf=False, cpu_sample=8, tag="c4",
+    "c4": dict(h=2160, w=3840, corners=2000, levels=5, batch=256, streams=1, ekf=False, cpu_sample=8, tag="c4",
                workload="3840x2160 frame pairs, 2000 corners, 5-level pyramid: the pair workload of BASELINE configs[4] "
                         "(its Monte-Carlo sweep: simulation.sweep, tests/test_gpu_estimation_parity.py)"),
 }
@@ -246,6 +246,20 @@ def ingest_inclusive(pipe, prev, nxt, sensors, B, reps=2):
                                               "while ofk_pairs_upload_staged decodes batch k; both frames of a pair in one decoder batch"}
     except Exception as e:
         out["jpeg_decode_on_device"] = {"error": str(e)[:200]}
+    # the decoder's own kernels (committed counter passes: tools/experiments/pmc_jpeg.sh -> profiles/<tag>_jpeg_decoder.json): per
+    # 512 frames of 1080p, every kernel alone on the chip, the dominant one against the VALU issue peak
+    dec, tag = _profile("jpeg_decoder")
+    if dec:
+        try:
+            ks = {k: v for k, v in dec["kernels"].items() if k.startswith("k_jpeg")}
+            dom = max(ks, key=lambda k: ks[k]["ms_per_512_frames"])
+            out["decoder"] = {"source": f"profiles/{tag}_jpeg_decoder.json", "ms_per_512_frames": dec["decoder_ms_per_512_frames"],
+                              "kernels_ms_per_512_frames": {k: v["ms_per_512_frames"] for k, v in ks.items()},
+                              "dominant": {"kernel": dom, "launches_per_decode": ks[dom]["launches_per_decode"], "ms_per_512_frames": ks[dom]["ms_per_512_frames"],
+                                           "bound": "valu", "achieved": ks[dom]["valu_ginstr_per_s"], "peak": VALU_PEAK_GINSTR, "unit": "G wave-instr/s",
+                                           "frac": ks[dom]["valu_frac_of_1228.8"], "wait_share_of_wave_cycles": ks[dom]["wait_share_of_wave_cycles"]}}
+        except Exception as e:
+            out["decoder"] = {"error": str(e)[:200]}
     return out
 
 
@@ -283,7 +297,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c1", choices=sorted(CONFIGS) + ["1", "2", "4"], help="BASELINE.json configuration: c1 = configs[1] (default, the "
                     "metric's own: 1080p / 500 corners / 3 levels), c2 = configs[2] (1024 x 640x480 + per-pair EKF), c4 = configs[4]'s 4K pair workload")
-    ap.add_argument("--batch", type=int, default=0, help="frame pairs per GPU per step (default: 512 at 1080p = 14 GB of the 288 GB; 1024 for c2; 128 for c4)")
+    ap.add_argument("--batch", type=int, default=0, help="frame pairs per GPU per step (default: 512 at 1080p = 14 GB of the 288 GB; 1024 for c2; 256 for c4)")
     ap.add_argument("--streams", type=int, default=0, help="free-running slices of the batch (HIP streams) per GPU (default: 1; 2 for c2)")
     ap.add_argument("--no-overlap", action="store_true", help="run every stage of a step serially on one stream")
     ap.add_argument("--no-isolated", action="store_true", help="skip the serial pass behind the timed region (profiling: the kernel "

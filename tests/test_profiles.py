@@ -11,7 +11,7 @@ import os
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = "r03"
+TAG = "r04"
 
 
 def load(name):
@@ -31,6 +31,38 @@ def test_traffic_summary_is_self_consistent():
     floor = {"gray": 2 * 4 * P, "pyr": 2 * (P + P // 4 + P // 16 + P // 64), "eig": P, "lk": 500 * 4 * (17 * 17 + 22 * 22) // 2}
     for s, per_pair in floor.items():
         assert t["stages"][s]["hbm_bytes_per_step"] >= 0.8 * per_pair * B, s
+
+
+@pytest.mark.parametrize("cfg,P,corners,levels", [("c2", 640 * 480, 500, 3), ("c4", 3840 * 2160, 2000, 5)])
+def test_traffic_summaries_of_the_other_configurations(cfg, P, corners, levels):
+    """bench.py --config c2 / c4 take roofline.traffic from their own PMC passes (profiles/<tag>c2_*, <tag>c4_*): the same checks."""
+    p = os.path.join(ROOT, "profiles", f"{TAG}{cfg}_traffic_pmc.json")
+    if not os.path.exists(p):
+        pytest.skip(f"{p} not committed yet")
+    t = json.load(open(p))
+    B = t["batch"]
+    assert abs(t["stages"]["gray"]["hbm_bytes_per_step"] / (2 * 4 * P * B) - 1) < 0.01
+    pyr = 2 * sum(P // 4 ** l for l in range(levels + 1))
+    for s, per_pair in {"gray": 2 * 4 * P, "pyr": pyr, "eig": P}.items():
+        assert t["stages"][s]["hbm_bytes_per_step"] >= 0.8 * per_pair * B, s
+    v = json.load(open(os.path.join(ROOT, "profiles", f"{TAG}{cfg}_valu_pmc.json")))
+    assert v["batch"] == B and v["stages"]["lk"]["SQ_INSTS_VALU_per_launch"] > 1000 * corners * B / 4      # > 1 k wave-instructions per point
+
+
+def test_committed_bench_lines_follow_the_contract():
+    """The bench lines kept under profiles/ (configs[1], [2], [4]) carry the contract's keys, a roofline and - at N = 1 - a CPU baseline."""
+    for name, tag in (("r04_bench_b512", ""), ("r04c2_bench", "c2"), ("r04c4_bench", "c4")):
+        p = os.path.join(ROOT, "profiles", name + ".json")
+        if not os.path.exists(p):
+            pytest.skip(f"{p} not committed yet")
+        d = json.load(open(p))
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+            assert k in d, (name, k)
+        assert d["vs_baseline"] is None and d["scaling"] == "weak" and "workload" in d["config"] and "BASELINE configs" in d["config"]["workload"]
+        assert abs(d["value"] - d["n_gpus"] * d["config"]["pairs_per_gpu_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
+        assert d["roofline"]["avg_ms"] <= d["ms_per_step"]
+        ns = d["north_star_kernel"]
+        assert ns["frac_fused_minimum"] <= ns["frac"] and (ns["frac_traffic"] is None or ns["frac_fused_minimum"] <= ns["frac_traffic"] * 1.05)
 
 
 def test_fetch_factor_is_calibrated():

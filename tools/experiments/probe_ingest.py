@@ -33,8 +33,11 @@ def main():
     pipe.upload_jpeg(sp, sn, sensors); pipe.run_async(); pipe.sync()
     t_stage = []
 
+    log = []
+
     def stage(slot):
-        t0 = time.perf_counter(); r = pipe.ctx.jpeg_stage(slot, sp + sn); t_stage.append(time.perf_counter() - t0); return r
+        t0 = time.perf_counter(); r = pipe.ctx.jpeg_stage(slot, sp + sn); t_stage.append(time.perf_counter() - t0)
+        log.append(("stage", slot, t0, time.perf_counter())); return r
     t_wait, t_dec, t_run = [], [], []
     with ThreadPoolExecutor(1) as ex:
         fut = ex.submit(stage, 0)
@@ -43,9 +46,13 @@ def main():
             t0 = time.perf_counter(); st = fut.result(); t_wait.append(time.perf_counter() - t0)
             fut = ex.submit(stage, (k + 1) & 1) if k + 1 < args.reps else None
             t0 = time.perf_counter(); pipe.ctx.pairs_upload_staged(k & 1, st); t_dec.append(time.perf_counter() - t0)
+            log.append(("decode", k & 1, t0, time.perf_counter()))
             t0 = time.perf_counter(); pipe.run_async(); t_run.append(time.perf_counter() - t0)
         pipe.sync()
         t_all = time.perf_counter() - t_all
+    base = min(e[2] for e in log)
+    for name, slot, a, b in sorted(log, key=lambda e: e[2]):
+        print(f"  {name:7s} slot {slot}  {1e3 * (a - base):8.2f} -> {1e3 * (b - base):8.2f} ms")
     ms = lambda v: round(1e3 * float(np.mean(v[1:])), 2)
     print({"batch": B, "stage_ms(helper)": ms(t_stage), "wait_for_stage_ms": ms(t_wait), "decode_ms": ms(t_dec), "queue_run_ms": ms(t_run),
            "loop_ms_per_batch": round(1e3 * t_all / args.reps, 2), "pairs_per_s": round(B * args.reps / t_all, 1)})

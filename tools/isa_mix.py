@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Instruction mix of the VALU-bound kernels' hot loops and the issue-cycle floor that mix implies (runs without a GPU).
 
-  python tools/isa_mix.py [--rates profiles/r03_valu_rates.txt] [--valu profiles/r03_valu_pmc.json] > profiles/r03_isa_mix.json
+  python tools/isa_mix.py [--rates profiles/r04_valu_rates.txt] [--valu profiles/r04_valu_pmc.json] > profiles/r04_isa_mix.json
 
 1. hipcc -S (device only, the product's flags) of k_corners.hip and k_lk.hip.
-2. k_mineig_pair<7,false>: the main loop holds 7 unrolled rows twice (border version, interior version; 2 v_sqrt_f32 per row).
+2. k_mineig_pair<7,false>: the main loop holds 7 unrolled rows twice (border version, interior version; 2 v_rsq_f32 per row since round 4).
    The INTERIOR version (the one almost every row of a 1080p frame runs) is the half of the loop body with fewer instructions;
    its instructions are counted per mnemonic.  k_lk15q: the whole kernel body (level set-up + Newton loop).
 3. Every VALU mnemonic is priced with its measured issue cost (tools/valu_rates.hip on the GPU box: ns per wave-instruction
@@ -126,10 +126,10 @@ def mix(instrs, rates):
 
 
 def pair_interior_rows(body):
-    """The interior 7-row version of k_mineig_pair's loop: split the loop body at the label in front of the 15th v_sqrt_f32."""
-    sq = [i for i, l in enumerate(body) if "v_sqrt_f32" in l]
+    """The interior 7-row version of k_mineig_pair's loop: split the loop body at the label in front of the 15th v_rsq_f32 (the square root of lambda_min: v_sqrt_f32 until round 3)."""
+    sq = [i for i, l in enumerate(body) if "v_rsq_f32" in l]
     if len(sq) != 28:
-        raise SystemExit(f"expected 28 v_sqrt_f32 in k_mineig_pair<7,false> (2 versions x 7 rows x 2 columns), found {len(sq)}")
+        raise SystemExit(f"expected 28 v_rsq_f32 in k_mineig_pair<7,false> (2 versions x 7 rows x 2 columns), found {len(sq)}")
     label = lambda i: max(j for j in range(i) if body[j].startswith(".LBB"))
     start_a, start_b = label(sq[0]), label(sq[14])
     end_b = next(j for j in range(sq[27], len(body)) if body[j].startswith(".LBB") and "s_cbranch" not in body[j] and j > sq[27] + 40)
@@ -139,8 +139,8 @@ def pair_interior_rows(body):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--rates", default=os.path.join(ROOT, "profiles", "r03_valu_rates.txt"))
-    ap.add_argument("--valu", default=os.path.join(ROOT, "profiles", "r03_valu_pmc.json"))
+    ap.add_argument("--rates", default=os.path.join(ROOT, "profiles", "r04_valu_rates.txt"))
+    ap.add_argument("--valu", default=os.path.join(ROOT, "profiles", "r04_valu_pmc.json"))
     args = ap.parse_args()
     rates = load_rates(args.rates)
     try:
