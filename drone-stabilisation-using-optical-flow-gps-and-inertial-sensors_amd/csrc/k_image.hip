@@ -323,6 +323,11 @@ __global__ __launch_bounds__(256) void k_pyr_down_stream(const uint8_t *__restri
 #define P3_EVEN(t1, t0) __builtin_amdgcn_perm((t1), (t0), 0x05040100u)                            // (t0.lo16, t1.lo16)
 #define P3_ODD(t1, t0) __builtin_amdgcn_perm((t1), (t0), 0x07060302u)                             // (t0.hi16, t1.hi16)
 #define P3_BYTES(v1, v0) __builtin_amdgcn_perm((v1), (v0), 0x07050301u)                           // (v >> 8) of the four u16 halves
+#define P3_ODDB(d) __builtin_amdgcn_perm(0u, (d), 0x0c030c01u)                                    // (d >> 8) & 0x00ff00ff in one instruction
+// value of lane-1; lane 0 of the wave, which has no lane-1, keeps `old` (bound_ctrl off).  In the strip that starts at the image's left
+// edge lane 0 IS the lane whose columns -2, -1 mirror 2, 1, so the mirrored pair goes in as `old` and no select is needed; in the other
+// strips lane 0 is a halo lane whose values never reach a stored column.
+#define P3_SHR_OLD(old, x) ((unsigned)__builtin_amdgcn_update_dpp((int)(old), (int)(x), 0x138, 0xF, 0xF, false))
 
 __device__ __forceinline__ unsigned p3_vert(unsigned a, unsigned b, unsigned c, unsigned d, unsigned e)
 {
@@ -332,10 +337,11 @@ __device__ __forceinline__ unsigned p3_vert(unsigned a, unsigned b, unsigned c, 
 // 16 bytes of a level-0 row -> the four pairs of horizontal sums centred on bytes (0,2) (4,6) (8,10) (12,14)
 __device__ __forceinline__ void p3_h16(uint4 d, bool first, bool last, unsigned *h)
 {
-    const unsigned E0 = d.x & P3_M, O0 = (d.x >> 8) & P3_M, E1 = d.y & P3_M, O1 = (d.y >> 8) & P3_M;
-    const unsigned E2 = d.z & P3_M, O2 = (d.z >> 8) & P3_M, E3 = d.w & P3_M, O3 = (d.w >> 8) & P3_M;
-    unsigned pE = P3_SHR(E3), pO = P3_SHR(O3), nE = P3_SHL(E0);
-    if (first) { pE = E0; pO = O0 << 16; }                      // columns -2,-1 mirror 2,1
+    const unsigned E0 = d.x & P3_M, O0 = P3_ODDB(d.x), E1 = d.y & P3_M, O1 = P3_ODDB(d.y);
+    const unsigned E2 = d.z & P3_M, O2 = P3_ODDB(d.z), E3 = d.w & P3_M, O3 = P3_ODDB(d.w);
+    const unsigned pE = P3_SHR_OLD(E0, E3), pO = P3_SHR_OLD(O0 << 16, O3);      // columns -2,-1 mirror 2,1 (lane 0 of the first strip)
+    unsigned nE = P3_SHL(E0);
+    (void)first;
     if (last) nE = E3 >> 16;                                    // column w mirrors w-2
     const unsigned l20 = P3_AB(E0, pE), l21 = P3_AB(E1, E0), l22 = P3_AB(E2, E1), l23 = P3_AB(E3, E2), l24 = P3_AB(nE, E3);
     const unsigned l10 = P3_AB(O0, pO), l11 = P3_AB(O1, O0), l12 = P3_AB(O2, O1), l13 = P3_AB(O3, O2);
@@ -348,8 +354,9 @@ __device__ __forceinline__ void p3_h16(uint4 d, bool first, bool last, unsigned 
 // 8 values of a level-1 row as even/odd pairs (E0 = (o0,o2), O0 = (o1,o3), E1 = (o4,o6), O1 = (o5,o7)) -> two pairs of sums
 __device__ __forceinline__ void p3_h8(unsigned E0, unsigned O0, unsigned E1, unsigned O1, bool first, bool last, unsigned &g0, unsigned &g1)
 {
-    unsigned pE = P3_SHR(E1), pO = P3_SHR(O1), nE = P3_SHL(E0);
-    if (first) { pE = E0; pO = O0 << 16; }
+    const unsigned pE = P3_SHR_OLD(E0, E1), pO = P3_SHR_OLD(O0 << 16, O1);
+    unsigned nE = P3_SHL(E0);
+    (void)first;
     if (last) nE = E1 >> 16;
     const unsigned l20 = P3_AB(E0, pE), l21 = P3_AB(E1, E0), l22 = P3_AB(nE, E1), l10 = P3_AB(O0, pO), l11 = P3_AB(O1, O0);
     g0 = 6u * E0 + 4u * (l10 + O0) + l20 + l21;
@@ -359,8 +366,9 @@ __device__ __forceinline__ void p3_h8(unsigned E0, unsigned O0, unsigned E1, uns
 // 4 values of a level-2 row (E = (t0,t2), O = (t1,t3)) -> one pair of sums
 __device__ __forceinline__ unsigned p3_h4(unsigned E, unsigned O, bool first, bool last)
 {
-    unsigned pE = P3_SHR(E), pO = P3_SHR(O), nE = P3_SHL(E);
-    if (first) { pE = E; pO = O << 16; }
+    const unsigned pE = P3_SHR_OLD(E, E), pO = P3_SHR_OLD(O << 16, O);
+    unsigned nE = P3_SHL(E);
+    (void)first;
     if (last) nE = E >> 16;
     return 6u * E + 4u * (P3_AB(O, pO) + O) + P3_AB(E, pE) + P3_AB(nE, E);
 }
@@ -425,7 +433,7 @@ __global__ __launch_bounds__(64) void k_pyr3_stream(p3_args A)
             if (st && own && tt < n1)
                 *reinterpret_cast<uint2 *>(slab + A.off1 + (size_t)tt * w1 + (c0 >> 1)) = make_uint2(P3_BYTES(v[1], v[0]), P3_BYTES(v[3], v[2]));
             // level 1 -> horizontally filtered row of level 1
-            const unsigned t0 = (v[0] >> 8) & P3_M, t1 = (v[1] >> 8) & P3_M, t2 = (v[2] >> 8) & P3_M, t3 = (v[3] >> 8) & P3_M;
+            const unsigned t0 = P3_ODDB(v[0]), t1 = P3_ODDB(v[1]), t2 = P3_ODDB(v[2]), t3 = P3_ODDB(v[3]);
             unsigned g0, g1;
             p3_h8(P3_EVEN(t1, t0), P3_ODD(t1, t0), P3_EVEN(t3, t2), P3_ODD(t3, t2), first, last, g0, g1);
 #pragma unroll
@@ -438,7 +446,7 @@ __global__ __launch_bounds__(64) void k_pyr3_stream(p3_args A)
                 const int qrow = (tt - 2) >> 1;
                 if (st && own && tt >= 2 && qrow < n2)
                     *reinterpret_cast<unsigned *>(slab + A.off2 + (size_t)qrow * w2 + (c0 >> 2)) = P3_BYTES(w1v, w0);
-                const unsigned s0 = (w0 >> 8) & P3_M, s1 = (w1v >> 8) & P3_M;
+                const unsigned s0 = P3_ODDB(w0), s1 = P3_ODDB(w1v);
                 const unsigned k2 = p3_h4(P3_EVEN(s1, s0), P3_ODD(s1, s0), first, last);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) r2[j] = r2[j + 1];

@@ -18,7 +18,7 @@ def test_comm_world1_gather_is_stream_ordered_and_carries_the_records(pkg, ofk, 
     pipe = FlowPipeline(320, 240, B, cfg, streams=2)
     pipe.upload(prev, nxt, sensors)
     comm = sharding.Comm(pipe.ctx, 0, 1, path=str(tmp_path / "rdv"), n_comms=2)
-    assert comm.world == 1 and comm.rank == 0
+    assert comm.world == 1 and comm.rank == 0 and comm.n_comms == 2   # communicator 0 + one ofk_comm_add behind the agreement
     for k in range(4):                                           # queue steps and gathers back to back, no host wait in between
         pipe.run_async()
         comm.gather_async(B, k % 2)
@@ -36,6 +36,10 @@ def test_comm_world1_gather_is_stream_ordered_and_carries_the_records(pkg, ofk, 
     with pytest.raises(ofk.OfkError):
         pipe.ctx.comm_init(b"\0" * 128, 0, 1)                   # one communicator set per context
     comm.close()
+    # the C entry point with several ids does the same internally: communicator 0, agreement over it, then exactly that many
+    pipe.ctx.comm_init(ofk.comm_unique_id(3), 0, 1)
+    assert pipe.ctx.comm_count() == 3
+    pipe.ctx.comm_destroy()
     pipe.close()
 
 

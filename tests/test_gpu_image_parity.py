@@ -305,6 +305,31 @@ def test_good_features_plateau_rows_fill_the_key_buffer(gpu_ctx, bs):
     assert inner.shape[0] >= 5 and np.ptp(inner) == 0 and inner[0, 0] > 0.2 * eig.max()    # one plateau, among the strongest responses
 
 
+def test_good_features_on_nearly_flat_images_with_isolated_dots(gpu_ctx):
+    """The response kernels take lambda_min's square root from v_rsq_f32 + one Newton step and clamp its argument away from zero
+    (k_corners.hip sqrt_rn_normal).  The argument IS zero wherever Sxx == Syy and Sxy == 0 - flat regions, but also every window that
+    holds one isolated dot (its Sobel pattern is symmetric: sum dx^2 == sum dy^2, sum dx dy == 0), where a + c is as small as it gets
+    (amplitude 1: 24 kd ~ 2e-7).  There (a + c) - root must still round to a + c, the plateaus of equal responses around each dot must
+    come out as the oracle's, and on an image of nothing but such dots they ARE the maxima the quality level is taken from."""
+    h, w = 216, 464
+    rng = np.random.default_rng(11)
+    for amp, base in ((1, 0), (1, 254), (2, 17), (3, 128), (255, 0)):
+        img = np.full((h, w), base, np.uint8)
+        ys = rng.integers(12, h - 12, 40); xs = rng.integers(12, w - 12, 40)
+        img[ys, xs] = np.clip(base + amp, 0, 255) if base + amp <= 255 else base - amp
+        for bs in (3, 5, 7, 12):
+            assert np.array_equal(gpu_ctx.mineig(img, bs).view(np.uint32), io.mineig(img, bs).view(np.uint32)), (amp, base, bs)
+            for mc, q, md in ((400, 0.001, 0.0), (60, 0.5, 5.0), (400, 0.999, 1.0)):
+                corners_equal(gpu_ctx, img, mc, q, md, bs)
+    # dots beside real texture: the threshold comes from the texture, the dots' plateaus fall below it or not as in the oracle
+    img = np.zeros((h, w), np.uint8)
+    img[:, : w // 2] = rng.integers(0, 256, (h, w // 2))
+    img[rng.integers(12, h - 12, 30), rng.integers(w // 2 + 12, w - 12, 30)] = 1
+    for bs in (3, 7, 12):
+        for q in (1e-6, 1e-3):
+            corners_equal(gpu_ctx, img, 1000, q, 0.0, bs)
+
+
 def test_tuning_knobs_do_not_change_results(gpu_ctx, pkg, ofk):
     """ofk_set_tuning (include/ofk.h) moves strip lengths and picks between kernels that compute the same thing: corners, pyramid
     levels and decoded-and-tracked records are bit-identical under every knob (what the header promises)."""
