@@ -833,6 +833,8 @@ struct jstage {
     jpeg_geom g;
     int batch, nch_max, valid;
     hipEvent_t copied;                      // H2D of this slot complete
+    char err[256];                          // last staging error of THIS slot: ofk_jpeg_stage may run on a helper thread while the owner
+                                            // thread writes the context's message (ofk_jpeg_stage_error reads this one)
 };
 struct jstages {
     jstage slot[2]; hipStream_t copy;
@@ -859,26 +861,8 @@ static int jhmap(ofk_ctx *c, jstages *js, size_t ints)
     return OFK_OK;
 }
 
-static jstages *jstages_of(ofk_ctx *c)
+static void jstages_free(jstages *js)
 {
-    if (!c->jstage) {
-        jstages *js = (jstages *)calloc(1, sizeof(jstages));
-        if (!js) return nullptr;
-        if (hipStreamCreateWithFlags(&js->copy, hipStreamNonBlocking) != hipSuccess) { free(js); return nullptr; }
-        if (hipStreamCreateWithFlags(&js->dec, hipStreamNonBlocking) != hipSuccess) { hipStreamDestroy(js->copy); free(js); return nullptr; }
-        for (int k = 0; k < 2; ++k)
-            if (hipEventCreateWithFlags(&js->slot[k].copied, hipEventDisableTiming) != hipSuccess) { free(js); return nullptr; }
-        if (hipStreamCreateWithFlags(&js->zero, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&js->zero_go, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&js->zeroed, hipEventDisableTiming) != hipSuccess) { free(js); return nullptr; }
-        c->jstage = js;
-    }
-    return (jstages *)c->jstage;
-}
-
-void ofk_jpeg_release(ofk_ctx *c)
-{
-    jstages *js = (jstages *)c->jstage;
-    if (!js) return;
     for (int k = 0; k < 2; ++k) {
         if (js->slot[k].host) hipHostFree(js->slot[k].host);
         if (js->slot[k].dev) hipFree(js->slot[k].dev);
@@ -891,6 +875,29 @@ void ofk_jpeg_release(ofk_ctx *c)
     if (js->zeroed) hipEventDestroy(js->zeroed);
     if (js->hmap) hipHostFree(js->hmap);
     free(js);
+}
+
+static jstages *jstages_of(ofk_ctx *c)
+{
+    if (!c->jstage) {
+        jstages *js = (jstages *)calloc(1, sizeof(jstages));
+        if (!js) return nullptr;
+        bool ok = hipStreamCreateWithFlags(&js->copy, hipStreamNonBlocking) == hipSuccess &&
+                  hipStreamCreateWithFlags(&js->dec, hipStreamNonBlocking) == hipSuccess &&
+                  hipStreamCreateWithFlags(&js->zero, hipStreamNonBlocking) == hipSuccess &&
+                  hipEventCreateWithFlags(&js->zero_go, hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&js->zeroed, hipEventDisableTiming) == hipSuccess;
+        for (int k = 0; k < 2 && ok; ++k) ok = hipEventCreateWithFlags(&js->slot[k].copied, hipEventDisableTiming) == hipSuccess;
+        if (!ok) { (void)hipGetLastError(); jstages_free(js); return nullptr; }      // whatever was created so far is released
+        c->jstage = js;
+    }
+    return (jstages *)c->jstage;
+}
+
+void ofk_jpeg_release(ofk_ctx *c)
+{
+    if (!c->jstage) return;
+    jstages_free((jstages *)c->jstage);
     c->jstage = nullptr;
 }
 
@@ -903,20 +910,23 @@ static int jstage_fill(ofk_ctx *c, int slot, const uint8_t *const *jpeg, const s
     if (!js) return ofk_fail(c, OFK_E_HIP, "ofk_jpeg: staging set-up failed");
     jstage &J = js->slot[slot];
     J.valid = 0;
+    J.err[0] = 0;
+    // errors go to the SLOT's message (this function may run beside the owner thread, which owns the context's message)
+    auto fail = [&](int code, const char *fmt, auto... args) { snprintf(J.err, sizeof(J.err), fmt, args...); return code; };
     jhost *jh = (jhost *)malloc(sizeof(jhost) * (size_t)batch);
-    if (!jh) return ofk_fail(c, OFK_E_INVALID, "ofk_jpeg: out of host memory");
+    if (!jh) return fail(OFK_E_INVALID, "ofk_jpeg: out of host memory");
     size_t ent_total = 0;
     int nch_max = 1;
     for (int b = 0; b < batch; ++b) {
         const char *err = jparse(jpeg[b], nbytes[b], &jh[b]);
-        if (err) { const int rc = ofk_fail(c, OFK_E_INVALID, "ofk_jpeg: stream %d: %s", b, err); free(jh); return rc; }
+        if (err) { const int rc = fail(OFK_E_INVALID, "ofk_jpeg: stream %d: %s", b, err); free(jh); return rc; }
         if (b && (jh[b].w != jh[0].w || jh[b].h != jh[0].h || jh[b].ncomp != jh[0].ncomp || jh[b].hs[0] != jh[0].hs[0] || jh[b].vs[0] != jh[0].vs[0])) {
-            const int rc = ofk_fail(c, OFK_E_INVALID, "ofk_jpeg: stream %d differs in size or sampling from stream 0 (one geometry per batch)", b);
+            const int rc = fail(OFK_E_INVALID, "ofk_jpeg: stream %d differs in size or sampling from stream 0 (one geometry per batch)", b);
             free(jh); return rc;
         }
         ent_total += JPAD(jh[b].ent_len);
     }
-    if (ent_total >= (1ull << 32)) { free(jh); return ofk_fail(c, OFK_E_INVALID, "ofk_jpeg: more than 4 GiB of entropy data in one batch"); }
+    if (ent_total >= (1ull << 32)) { free(jh); return fail(OFK_E_INVALID, "ofk_jpeg: more than 4 GiB of entropy data in one batch"); }
     jpeg_geom g = jgeom(jh[0]);
     g.jch = JCH;
     while (g.jch > JCH_MIN && ent_total / (size_t)g.jch < 131072) g.jch >>= 1;   // keep >= 128 k decoder threads if the data allows
@@ -931,12 +941,12 @@ static int jstage_fill(ofk_ctx *c, int slot, const uint8_t *const *jpeg, const s
     if (J.copied) (void)hipEventSynchronize(J.copied);           // the slot's previous transfer has left the pinned buffer
     if (J.host_bytes < stage) {
         if (J.host) { hipHostFree(J.host); J.host = nullptr; J.host_bytes = 0; }
-        if (hipHostMalloc(&J.host, jup(stage, 1 << 20), hipHostMallocDefault) != hipSuccess) { free(jh); return ofk_fail(c, OFK_E_HIP, "ofk_jpeg: pinned staging allocation failed"); }
+        if (hipHostMalloc(&J.host, jup(stage, 1 << 20), hipHostMallocDefault) != hipSuccess) { free(jh); return fail(OFK_E_HIP, "ofk_jpeg: pinned staging allocation failed"); }
         J.host_bytes = jup(stage, 1 << 20);
     }
     if (J.dev_bytes < stage) {
         if (J.dev) { hipFree(J.dev); J.dev = nullptr; J.dev_bytes = 0; }
-        if (hipMalloc(&J.dev, jup(stage, 1 << 20)) != hipSuccess) { free(jh); return ofk_fail(c, OFK_E_HIP, "ofk_jpeg: device staging allocation failed"); }
+        if (hipMalloc(&J.dev, jup(stage, 1 << 20)) != hipSuccess) { free(jh); return fail(OFK_E_HIP, "ofk_jpeg: device staging allocation failed"); }
         J.dev_bytes = jup(stage, 1 << 20);
     }
     jpeg_tab *ht = (jpeg_tab *)J.host;
@@ -944,7 +954,7 @@ static int jstage_fill(ofk_ctx *c, int slot, const uint8_t *const *jpeg, const s
     // tables and entropy segments into the staging buffer: a plain copy of ~0.4 MB per 1080p frame, spread over a few host threads
     // (one thread moves ~10 GB/s, which would make this copy the slowest stage of the ingest)
     size_t *eoff = (size_t *)malloc(sizeof(size_t) * (size_t)batch);
-    if (!eoff) { free(jh); return ofk_fail(c, OFK_E_INVALID, "ofk_jpeg: out of host memory"); }
+    if (!eoff) { free(jh); return fail(OFK_E_INVALID, "ofk_jpeg: out of host memory"); }
     size_t eo = 0;
     for (int b = 0; b < batch; ++b) { eoff[b] = eo; eo += JPAD(jh[b].ent_len); }
     auto stage_range = [&](int b0, int step) {
@@ -975,8 +985,10 @@ static int jstage_fill(ofk_ctx *c, int slot, const uint8_t *const *jpeg, const s
     }
     free(eoff);
     free(jh);
-    OFK_HIP(c, hipMemcpyAsync(J.dev, J.host, stage, hipMemcpyHostToDevice, js->copy));
-    OFK_HIP(c, hipEventRecord(J.copied, js->copy));
+    if (hipMemcpyAsync(J.dev, J.host, stage, hipMemcpyHostToDevice, js->copy) != hipSuccess || hipEventRecord(J.copied, js->copy) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(OFK_E_HIP, "ofk_jpeg: staging copy to the device failed");
+    }
     J.stage_bytes = stage; J.tab_bytes = tab_bytes; J.g = g; J.batch = batch; J.nch_max = nch_max; J.valid = 1;
     return OFK_OK;
 }
@@ -1078,11 +1090,18 @@ int ofk_jpeg_decode_device(ofk_ctx *c, const uint8_t *const *jpeg, const size_t 
                            size_t dst_capacity_px, int *h_out, int *w_out, uint8_t **out, size_t *out_stride)
 {
     int rc = jstage_fill(c, 0, jpeg, nbytes, batch);
-    if (rc != OFK_OK) return rc;
+    if (rc != OFK_OK) return c->jstage && ((jstages *)c->jstage)->slot[0].err[0] ? ofk_fail(c, rc, "%s", ((jstages *)c->jstage)->slot[0].err) : rc;   // owner thread: its message
     return jdecode_staged(c, 0, dst, nullptr, batch, dst_stride, dst_capacity_px, h_out, w_out, out, out_stride);
 }
 
 int ofk_jpeg_stage_streams(ofk_ctx *c, int slot, const uint8_t *const *jpeg, const size_t *nbytes, int count) { return jstage_fill(c, slot, jpeg, nbytes, count); }
+
+// the slot's own message ("" when its last staging succeeded)
+const char *ofk_jpeg_slot_error(const ofk_ctx *c, int slot)
+{
+    const jstages *js = c ? (const jstages *)c->jstage : nullptr;
+    return (js && slot >= 0 && slot <= 1) ? js->slot[slot].err : "";
+}
 
 int ofk_jpeg_decode_staged_pairs(ofk_ctx *c, int slot, uint8_t *dst_prev, uint8_t *dst_next, size_t dst_stride, size_t dst_capacity_px, int *batch_out,
                                  int *h_out, int *w_out, const hipEvent_t *wait_before_writing, int nwait, int as_gray)

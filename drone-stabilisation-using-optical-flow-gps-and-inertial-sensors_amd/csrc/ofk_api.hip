@@ -832,7 +832,7 @@ extern "C" int ofk_pairs_upload_jpeg(ofk_ctx *c, const uint8_t *const *prev_jpeg
     for (int b = 0; b < batch; ++b) { all[b] = prev_jpeg[b]; len[b] = prev_bytes[b]; all[batch + b] = next_jpeg[b]; len[batch + b] = next_bytes[b]; }
     int rc = ofk_jpeg_stage(c, 0, all, len, 2 * batch);
     free(all); free(len);
-    if (rc != OFK_OK) return rc;
+    if (rc != OFK_OK) return ofk_fail(c, rc, "%s", ofk_jpeg_slot_error(c, 0));      // synchronous caller = the owner thread: its message
     return ofk_pairs_upload_staged(c, 0);
 }
 
@@ -840,9 +840,13 @@ extern "C" int ofk_pairs_upload_jpeg(ofk_ctx *c, const uint8_t *const *prev_jpeg
 extern "C" int ofk_jpeg_stage(ofk_ctx *c, int slot, const uint8_t *const *jpeg, const size_t *nbytes, int count)
 {
     if (!c) return OFK_E_INVALID;
-    if (hipSetDevice(c->device) != hipSuccess) return ofk_fail(c, OFK_E_HIP, "hipSetDevice failed");
+    if (hipSetDevice(c->device) != hipSuccess) return OFK_E_HIP;
     return ofk_jpeg_stage_streams(c, slot, jpeg, nbytes, count);
 }
+
+// Message of the slot's last ofk_jpeg_stage ("" after a success).  ofk_jpeg_stage does not touch ofk_last_error: it may run on a helper
+// thread while the owner thread is inside another entry point.
+extern "C" const char *ofk_jpeg_stage_error(const ofk_ctx *c, int slot) { return ofk_jpeg_slot_error(c, slot); }
 
 // Phase 2: the 2 B streams staged in `slot` (B previous frames, then B next frames) decoded into the resident frame-pair buffers.
 extern "C" int ofk_pairs_upload_staged(ofk_ctx *c, int slot)

@@ -106,6 +106,7 @@ int ofk_export_records_stream(ofk_ctx *c, float *device_dst, int batch, hipStrea
                                    // before touching the context's stream / shared buffers
 void ofk_jpeg_release(ofk_ctx *c);
 int ofk_jpeg_stage_streams(ofk_ctx *c, int slot, const uint8_t *const *jpeg, const size_t *nbytes, int count);
+const char *ofk_jpeg_slot_error(const ofk_ctx *c, int slot);       // the slot's own message: staging may run beside the owner thread
 int ofk_jpeg_decode_staged_pairs(ofk_ctx *c, int slot, uint8_t *dst_prev, uint8_t *dst_next, size_t dst_stride, size_t dst_capacity_px, int *batch_out,
                                  int *h_out, int *w_out, const hipEvent_t *wait_before_writing, int nwait, int as_gray);
                                  // wait_before_writing != NULL: decode on the ingest stream, beside whatever runs on the context's, behind those events;

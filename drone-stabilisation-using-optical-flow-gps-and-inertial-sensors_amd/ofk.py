@@ -26,7 +26,7 @@ SYMBOLS = (
     "ofk_version", "ofk_last_error", "ofk_device_count", "ofk_create", "ofk_destroy", "ofk_sync", "ofk_device_sync",
     "ofk_gray_bgr8", "ofk_pyr_down_u8", "ofk_pyramid_u8", "ofk_scharr_s16", "ofk_mineig_response", "ofk_select_corners",
     "ofk_good_features", "ofk_lk_pyr", "ofk_flow_model", "ofk_feasibility", "ofk_velocity_solve", "ofk_imu_propagate",
-    "ofk_post_solve", "ofk_kf_predict_update", "ofk_of_simulation", "ofk_feas_simulation", "ofk_hist_overlap", "ofk_associate_sensors", "ofk_feature_eval", "ofk_d_split", "ofk_pairs_upload", "ofk_pairs_upload_jpeg", "ofk_jpeg_stage", "ofk_pairs_upload_staged", "ofk_jpeg_info", "ofk_jpeg_decode_bgr8", "ofk_pairs_set_sensors",
+    "ofk_post_solve", "ofk_kf_predict_update", "ofk_of_simulation", "ofk_feas_simulation", "ofk_hist_overlap", "ofk_associate_sensors", "ofk_feature_eval", "ofk_d_split", "ofk_pairs_upload", "ofk_pairs_upload_jpeg", "ofk_jpeg_stage", "ofk_jpeg_stage_error", "ofk_pairs_upload_staged", "ofk_jpeg_info", "ofk_jpeg_decode_bgr8", "ofk_pairs_set_sensors",
     "ofk_pairs_run", "ofk_pairs_download", "ofk_pairs_export_records_f32", "ofk_stream_begin", "ofk_stream_step",
     "ofk_stream_begin_jpeg", "ofk_stream_step_jpeg",
     "ofk_set_streams", "ofk_set_overlap", "ofk_set_tuning", "ofk_get_tuning", "ofk_mark", "ofk_mark_wait", "ofk_profile_enable", "ofk_profile_read", "ofk_resident_pyramid",
@@ -119,6 +119,7 @@ def load_library():
         L.ofk_pairs_upload.argtypes = [vp, vp, vp, i, i, i]
         L.ofk_pairs_upload_jpeg.argtypes = [vp, vp, vp, vp, vp, i]
         L.ofk_jpeg_stage.argtypes = [vp, i, vp, vp, i]; L.ofk_pairs_upload_staged.argtypes = [vp, i]
+        L.ofk_jpeg_stage_error.restype = C.c_char_p; L.ofk_jpeg_stage_error.argtypes = [vp, i]
         L.ofk_jpeg_info.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
         L.ofk_jpeg_decode_bgr8.argtypes = [vp, vp, vp, i, vp]
         L.ofk_pairs_set_sensors.argtypes = [vp, vp, i]
@@ -555,8 +556,8 @@ class Context:
         h, w, _ = jpeg_info(streams[0])
         keep, ptrs, sizes = self._jpeg_args(streams)
         rc = self._L.ofk_jpeg_stage(self._h, int(slot), ptrs, sizes, len(keep))
-        if rc != OK:
-            raise OfkError(rc, self._L.ofk_last_error(self._h).decode())
+        if rc != OK:                                             # the slot's own message: the owner thread may be writing the context's
+            raise OfkError(rc, self._L.ofk_jpeg_stage_error(self._h, int(slot)).decode())
         return len(keep), h, w
 
     def pairs_upload_staged(self, slot, staged):

@@ -245,6 +245,9 @@ int ofk_pairs_upload_jpeg(ofk_ctx *ctx, const uint8_t *const *prev_jpeg, const s
  * Loop: stage(0, batch 0); for k: { stage(k+1 & 1, batch k+1) on the helper thread; upload_staged(k & 1); ofk_pairs_run; }.
  * pipeline.FlowPipeline.run_jpeg_batches does exactly that; bench.py reports its rate as ingest_inclusive.jpeg_double_buffered. */
 int ofk_jpeg_stage(ofk_ctx *ctx, int slot, const uint8_t *const *jpeg, const size_t *nbytes, int count);
+/* Message of the slot's last ofk_jpeg_stage ("" after a success).  ofk_jpeg_stage never writes ofk_last_error: it may run on a helper
+ * thread while the owner thread is inside another entry point, and the context holds ONE message. */
+const char *ofk_jpeg_stage_error(const ofk_ctx *ctx, int slot);
 int ofk_pairs_upload_staged(ofk_ctx *ctx, int slot);
 int ofk_pairs_set_sensors(ofk_ctx *ctx, const double *sensors, int batch);
 /* Runs gray -> pyramids -> corners -> LK -> centre/scale -> (feasibility) -> solve -> post-solve for every resident

@@ -240,6 +240,26 @@ def test_staged_ingest_refuses_more_pairs_than_the_context_holds(pkg, ofk):
 
 
 @pytest.mark.gpu
+def test_staging_errors_have_their_own_message(pkg, ofk, gold):
+    """ofk_jpeg_stage may run on a helper thread beside the owner: its errors go to the SLOT's message (ofk_jpeg_stage_error), the
+    context's message (ofk_last_error) stays the owner's."""
+    from of_amd.pipeline import FlowPipeline, PipelineConfig
+    good = gold["jpg_c420_ros"].tobytes()
+    pipe = FlowPipeline(640, 480, 2, PipelineConfig(max_corners=20))
+    with pytest.raises(ofk.OfkError) as e:
+        pipe.ctx.pairs_run(pipe._params)                         # the owner's error: nothing resident
+    owner_msg = pipe.ctx._L.ofk_last_error(pipe.ctx._h)
+    assert b"no resident frame pairs" in owner_msg
+    with pytest.raises(ofk.OfkError) as e:
+        pipe.ctx.jpeg_stage(1, [good, gold["jpg_c420_odd"].tobytes(), good, good])           # stream 1 has another geometry
+    assert "stream 1" in str(e.value)
+    assert pipe.ctx._L.ofk_last_error(pipe.ctx._h) == owner_msg  # untouched by the staging failure
+    st = pipe.ctx.jpeg_stage(1, [good] * 4)                      # a success clears the slot's message
+    assert pipe.ctx._L.ofk_jpeg_stage_error(pipe.ctx._h, 1) == b""
+    pipe.close()
+
+
+@pytest.mark.gpu
 def test_gray_direct_ingest_state_machine(pkg, ofk):
     """The compressed ingest writes the gray frames straight into one pyramid set and no BGR frame (ofk_pairs_upload_staged on the
     default schedule): a second run without a new upload, a run after the schedule changed to two slices, odd frame sizes (the byte
