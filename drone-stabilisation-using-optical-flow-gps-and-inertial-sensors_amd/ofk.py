@@ -149,7 +149,7 @@ def load_library():
         L.ofk_comm_allreduce_f64.argtypes = [vp, vp, i, i]
         L.ofk_comm_count.argtypes = [vp]; L.ofk_comm_pending.argtypes = [vp, i]; L.ofk_comm_reorder_records.argtypes = [vp, i, i, i, vp]
         for s in SYMBOLS:
-            if s != "ofk_last_error":
+            if s not in ("ofk_last_error", "ofk_jpeg_stage_error"):      # the two that return a message, not a status
                 getattr(L, s).restype = i
         _lib = L
         return L
