@@ -912,7 +912,7 @@ static int jstage_fill(ofk_ctx *c, int slot, const uint8_t *const *jpeg, const s
     J.valid = 0;
     J.err[0] = 0;
     // errors go to the SLOT's message (this function may run beside the owner thread, which owns the context's message)
-    auto fail = [&](int code, const char *fmt, auto... args) { snprintf(J.err, sizeof(J.err), fmt, args...); return code; };
+#define fail(code, ...) (snprintf(J.err, sizeof(J.err), __VA_ARGS__), (code))
     jhost *jh = (jhost *)malloc(sizeof(jhost) * (size_t)batch);
     if (!jh) return fail(OFK_E_INVALID, "ofk_jpeg: out of host memory");
     size_t ent_total = 0;
@@ -992,6 +992,8 @@ static int jstage_fill(ofk_ctx *c, int slot, const uint8_t *const *jpeg, const s
     J.stage_bytes = stage; J.tab_bytes = tab_bytes; J.g = g; J.batch = batch; J.nch_max = nch_max; J.valid = 1;
     return OFK_OK;
 }
+
+#undef fail
 
 // Phase 2: the staged streams [0, split) go to dst ([.][dst_stride] BGR8), the streams [split, batch) to dst2 (split >= batch: all
 // to dst); with dst == NULL into the context's scratch (*out / *out_stride tell where).  Synchronous on the context's stream.
