@@ -95,11 +95,13 @@ def _token_alive(tok):
     if len(tok) != 24 or tok[:8] != _TOKEN:
         return False
     pid, t100 = int.from_bytes(tok[8:16], "little"), int.from_bytes(tok[16:24], "little")
-    if not os.path.isdir("/proc/self"):
-        return None
     t = _proc_start_time(pid)
     if t is None:
-        return False
+        # not visible.  Sibling ranks of one launcher share its PID namespace: if this process can see its own launcher, a live rank 0
+        # would be visible too, so the publisher is gone; otherwise (no /proc, or every rank in a namespace of its own) /proc cannot tell
+        # and the modification-time rule decides alone
+        ppid = os.getppid()
+        return False if (ppid > 1 and _proc_start_time(ppid) is not None) else None
     return abs(int(round(t * 100)) - t100) <= 1
 
 
