@@ -34,6 +34,8 @@ struct ofk_comm {
     float *send[2], *recv[2];           // [B][8] and [world][B][8] f32, two slots so step k+1 may export while step k travels
     int cap_batch;
     hipEvent_t done[2][OFK_MAX_STREAMS];            // gather of slot s (slice k) complete
+    hipStream_t xs; hipEvent_t ev_ready;            // one slice: export + all-gather run on a stream of their OWN behind the step's solve, so
+                                                    // that the next step's first kernel does not queue behind a collective (xs = exchange stream)
     int slot_slices[2], slot_batch[2];              // how the slot's latest gather was cut
     float *hrecv; size_t hrecv_bytes;               // pinned host staging for ofk_comm_fetch_records
     double *red; void *hred;            // all-reduce scratch (device / pinned host), 64 doubles
@@ -87,6 +89,11 @@ extern "C" int ofk_comm_init(ofk_ctx *c, const uint8_t *ids, int n_ids, int rank
     // creation order (see ofk_set_streams)
     rc = ofk_prepare_streams(c);
     if (rc != OFK_OK) { ofk_comm_destroy(c); return rc; }
+    if (hipStreamCreateWithFlags(&m->xs, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&m->ev_ready, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        ofk_comm_destroy(c);
+        return ofk_fail(c, OFK_E_HIP, "ofk_comm_init: exchange stream");
+    }
     {   // communicator 0: the one every rank needs (gathers with one slice, all-reduces, barriers)
         ncclUniqueId id;
         memcpy(id.internal, ids, NCCL_UNIQUE_ID_BYTES);
@@ -158,6 +165,8 @@ extern "C" int ofk_comm_destroy(ofk_ctx *c)
         if (m->recv[s]) hipFree(m->recv[s]);
         for (int k = 0; k < OFK_MAX_STREAMS; ++k) if (m->done[s][k]) hipEventDestroy(m->done[s][k]);
     }
+    if (m->xs) hipStreamDestroy(m->xs);
+    if (m->ev_ready) hipEventDestroy(m->ev_ready);
     if (m->red) hipFree(m->red);
     if (m->hred) hipHostFree(m->hred);
     if (m->hrecv) hipHostFree(m->hrecv);
@@ -196,15 +205,29 @@ extern "C" int ofk_comm_gather_records(ofk_ctx *c, int batch, int slot)
         if (e != hipSuccess) return ofk_fail(c, OFK_E_HIP, "k_records_f32: %s", hipGetErrorString(e));
         return OFK_OK;
     }
-    hipStream_t s;
+    if (!c->slices_open) {
+        // One slice: the exchange leaves the context's stream.  Behind whatever that stream holds now (the step's solve) the exchange
+        // stream exports the records and gathers them; the context's stream goes straight on to the next step, whose solve only waits
+        // for the EXPORT kernel (ev_x), never for the collective - no rank's response kernel queues behind another rank's progress.
+        OFK_HIP(c, hipEventRecord(m->ev_ready, c->stream));
+        OFK_HIP(c, hipStreamWaitEvent(m->xs, m->ev_ready, 0));
+        ofk_launch_records_f32(m->xs, c->records, m->send[slot], batch);
+        OFK_HIP(c, hipEventRecord(c->ev_x, m->xs));
+        c->x_pending = 1;
+        OFK_NCCL(c, m, m->all_gather(m->send[slot], m->recv[slot], (size_t)batch * 8, ncclFloat32, m->comm[0], m->xs));
+        OFK_HIP(c, hipEventRecord(m->done[slot][0], m->xs));
+        m->slot_slices[slot] = 1; m->slot_batch[slot] = batch;
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return ofk_fail(c, OFK_E_HIP, "k_records_f32: %s", hipGetErrorString(e));
+        return OFK_OK;
+    }
+    hipStream_t s;                                               // slices open, one communicator: behind the last slice, after the others' end events
     int rc = ofk_export_records_stream(c, m->send[slot], batch, &s);
     if (rc != OFK_OK) return rc;
     OFK_NCCL(c, m, m->all_gather(m->send[slot], m->recv[slot], (size_t)batch * 8, ncclFloat32, m->comm[0], s));
     OFK_HIP(c, hipEventRecord(m->done[slot][0], s));
-    if (c->slices_open) {                                        // the next solves wait for the gather as they did for the export
-        OFK_HIP(c, hipEventRecord(c->ev_x, s));
-        c->x_pending = 1;
-    }
+    OFK_HIP(c, hipEventRecord(c->ev_x, s));                      // the next solves wait for the gather as they did for the export
+    c->x_pending = 1;
     m->slot_slices[slot] = 1; m->slot_batch[slot] = batch;
     return OFK_OK;
 }
@@ -266,6 +289,9 @@ extern "C" int ofk_comm_allreduce_f64(ofk_ctx *c, double *inout, int n, int op)
     OFK_HIP(c, hipSetDevice(c->device));
     int rc = ofk_join_slices(c);
     if (rc != OFK_OK) return rc;
+    // never two collectives of one communicator in flight: the gathers of both slots (exchange stream / slice streams) first
+    for (int s = 0; s < 2; ++s)
+        for (int k = 0; k < m->slot_slices[s]; ++k) OFK_HIP(c, hipStreamWaitEvent(c->stream, m->done[s][k], 0));
     memcpy(m->hred, inout, (size_t)n * 8);
     OFK_HIP(c, hipMemcpyAsync(m->red, m->hred, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
     OFK_NCCL(c, m, m->all_reduce(m->red, m->red, (size_t)n, ncclFloat64, op == 0 ? ncclSum : (op == 1 ? ncclMax : ncclMin), m->comm[0], c->stream));

@@ -372,8 +372,10 @@ int ofk_jpeg_decode_bgr8(ofk_ctx *ctx, const uint8_t *const *jpeg, const size_t 
  *   ofk_comm_add           one more communicator from a 128-byte id; collective (every rank, same order); what ofk_comm_init does
  *                          n_ids - 1 times, exported for callers that negotiate the count themselves (sharding.Comm)
  *   ofk_comm_gather_records  k_records_f32 of the latest ofk_pairs_run + ncclAllGather of [batch][8] f32 {vx,vy,vz,residual,
- *                          n_used,s_min,rank,corners} into the context's receive buffer `slot` (0/1), queued behind the step on
- *                          the library's own stream: no host wait, step k+1 can be queued at once
+ *                          n_used,s_min,rank,corners} into the context's receive buffer `slot` (0/1), stream-ordered behind the step
+ *                          on the library's own EXCHANGE stream (one slice; with free-running slices: on the slices' streams): no
+ *                          host wait, and step k+1's kernels do not queue behind the collective - its solve only waits for the
+ *                          export kernel that reads the records
  *   ofk_comm_fetch_records waits for the gather of `slot`, copies [world][batch][8] f32 (rank-major) to host_out
  *   ofk_comm_allreduce_f64 in-place all-reduce of n <= 64 doubles (op 0 sum, 1 max, 2 min), synchronous: barriers, max-over-ranks
  *                          timing, and the Monte-Carlo sweep's per-step (sum v, sum v^2, count) statistics */
