@@ -51,6 +51,7 @@ The JSON line also carries
                  device every step (bounded: a few steps each, outside the timed region) with the decoder's own kernel times.
   cpu_baseline : the CPU oracle (oracle/, single thread, kind "port") timed on this host over a bounded sample of the
                  same frame pairs (rank 0, N=1 only).
+  monte_carlo_sweep (--config c4 only): configs[4]'s Monte-Carlo sweep at 2000 points x 4096 trials per step, device noise and host noise.
 """
 import argparse
 import json
@@ -260,6 +261,27 @@ def ingest_inclusive(pipe, prev, nxt, sensors, B, reps=2):
                                            "frac": ks[dom]["valu_frac_of_1228.8"], "wait_share_of_wave_cycles": ks[dom]["wait_share_of_wave_cycles"]}}
         except Exception as e:
             out["decoder"] = {"error": str(e)[:200]}
+    return out
+
+
+def monte_carlo_sweep(points=2000, trials=4096, steps=10):
+    """The other half of BASELINE configs[4]: the reference's effect_of_flow_errors sweep (simulation.py:183-202) at 2000 points and
+    4096 trials per sigma step - of_simulation for all trials of a step in ONE launch, the normals drawn on the device by the
+    counter-based generator (ofk_of_simulation_rng), against the same sweep with numpy's generator and a 262 MB noise tensor uploaded
+    per step.  Bounded: `steps` sigma steps each way; never part of `value`."""
+    import of_amd.simulation as sim
+    out = {"workload": f"effect_of_flow_errors sweep, {points} points x {trials} trials per sigma step, f64", "unit": "trials/s"}
+    try:
+        pts = np.random.default_rng(1).uniform(-1.2, 1.2, (points, 2))
+        sargs = (pts, [1.0, 1, 1], [1.0, 1, 1], 1.0, [0.0, 0, 1], [0.02, 0, 0.205])
+        for name, kw, n in (("device_noise", dict(device_seed=7), steps), ("host_noise", dict(generator=np.random.default_rng(3)), max(2, steps // 4))):
+            sim.sweep("flow_errors", *sargs, k=100, trials=trials, steps=[5], **kw)
+            t0 = time.perf_counter()
+            res = sim.sweep("flow_errors", *sargs, k=100, trials=trials, steps=list(range(10, 10 + n)), **kw)
+            dt = (time.perf_counter() - t0) / n
+            out[name] = {"value": round(trials / dt, 1), "ms_per_sigma_step": round(dt * 1e3, 3), "v_mean_of_first_step": [round(float(x), 5) for x in res[:3]]}
+    except Exception as e:
+        out["error"] = str(e)[:200]
     return out
 
 
@@ -538,6 +560,8 @@ def main():
                                     "multi_thread": {"value": round(cps_mt, 3), "cores": nthr, "sample": f"{msample} pairs, one pair per thread"}}
         if world == 1 and not args.no_ingest:
             line["ingest_inclusive"] = ingest_inclusive(pipe, prev, nxt, sensors, B)
+        if world == 1 and cname == "c4":
+            line["monte_carlo_sweep"] = monte_carlo_sweep()
         print(json.dumps(line), flush=True)
     if comm is not None:
         comm.barrier()

@@ -844,15 +844,61 @@ void ofk_launch_stream_fuse(hipStream_t s, const float *prev_pts, const float *n
 
 // ------------------------------------------------------------------------------------------------ Monte-Carlo error simulation
 // One block per trial (simulation.py:36-66).  truth: v[0..2] omega[3..5] height[6] normal[7..9] t[10..12].
+// Counter-based noise for the Monte-Carlo sweeps ("Philox/counter-based noise so CPU and GPU draw identical values").
+// Element e of trial t of sweep step s under seed (k0, k1) = output (e & 1) of the Box-Muller transform of Philox4x32-10(counter =
+// (e >> 1, t, s, 0), key = (k0, k1)): u1 = ((x0 >> 5) 2^26 + (x1 >> 6) + 0.5) 2^-53, u2 likewise from x2, x3 (never 0 or 1),
+// r = sqrt(-2 ln u1), normals r cos(2 pi u2), r sin(2 pi u2).  Nothing is stored: a trial's 10 + 4 n normals are regenerated where they
+// are used, any rank can produce any trial (the counter holds the GLOBAL trial index), and oracle/estimation_oracle.py restates the
+// same function in numpy (Random123's known answers pin the integer part; the f64 transform agrees to the last ulps of libm).
+__device__ __forceinline__ void ofk_philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned out[4])
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+struct ofk_noise { unsigned k0, k1, step, trial; };
+__device__ __forceinline__ double ofk_noise_normal(const ofk_noise &g, unsigned e)
+{
+    unsigned x[4];
+    ofk_philox4x32_10(e >> 1, g.trial, g.step, 0u, g.k0, g.k1, x);
+    const double u1 = ((double)(x[0] >> 5) * 67108864.0 + (double)(x[1] >> 6) + 0.5) * 0x1p-53;
+    const double u2 = ((double)(x[2] >> 5) * 67108864.0 + (double)(x[3] >> 6) + 0.5) * 0x1p-53;
+    const double r = sqrt(-2.0 * log(u1)), th = 6.283185307179586476925 * u2;
+    return (e & 1u) ? r * sin(th) : r * cos(th);
+}
+__global__ void k_noise_normals(ofk_noise g, int count, double *__restrict__ out)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < count) out[e] = ofk_noise_normal(g, (unsigned)e);
+}
+void ofk_launch_noise_normals(hipStream_t s, unsigned k0, unsigned k1, unsigned step, unsigned trial, int count, double *out)
+{
+    ofk_noise g = {k0, k1, step, trial};
+    hipLaunchKernelGGL(k_noise_normals, dim3((count + 255) / 256), dim3(256), 0, s, g, count, out);
+}
+
+// RNG = false: the caller supplies the normals (z, the reference's np.random.normal draws in their order); RNG = true: they come from
+// ofk_noise_normal under (seed, step) with the global trial index trial0 + blockIdx.x - the 4096-wide batches of BASELINE configs[4]
+// then need no 262 MB noise tensor per step from the host.
+template <bool RNG>
 __global__ __launch_bounds__(256) void k_of_simulation(const double *__restrict__ truth, const double *__restrict__ sig,
                                                        const double *__restrict__ pos, const double *__restrict__ true_flow,
                                                        int n, const double *__restrict__ z, double *__restrict__ v_obs,
-                                                       double *__restrict__ bound)
+                                                       double *__restrict__ bound, ofk_noise rng)
 {
     __shared__ double s_red[4];
     __shared__ double s_v[8];
     const int trial = blockIdx.x, tid = threadIdx.x;
-    const double *zi = z + (size_t)trial * (10 + 4 * (size_t)n);
+    rng.trial += (unsigned)trial;
+    // element e of this trial's row of 10 + 4 n normals
+    auto Z = [&](size_t e) -> double { return RNG ? ofk_noise_normal(rng, (unsigned)e) : z[(size_t)trial * (10 + 4 * (size_t)n) + e]; };
+    const double zi[7] = {Z(0), Z(1), Z(2), Z(3), Z(4), Z(5), Z(6)};
+    const size_t zf = 7, zp = 7 + 2 * (size_t)n;               // first flow / position normal of the row
     const double lv[3] = {truth[0], truth[1], truth[2]}, av[3] = {truth[3], truth[4], truth[5]}, hgt = truth[6];
     const double nv[3] = {truth[7], truth[8], truth[9]}, tr[3] = {truth[10], truth[11], truth[12]};
     const double ang[3] = {av[0] + sig[0] * zi[0], av[1] + sig[0] * zi[1], av[2] + sig[0] * zi[2]};
@@ -860,11 +906,10 @@ __global__ __launch_bounds__(256) void k_of_simulation(const double *__restrict_
     const double h_err = hgt + sig[2] * zi[6];
     const double nn = sqrt(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
     const double ne[3] = {nv[0] / nn, nv[1] / nn, nv[2] / nn};      // normal noise is discarded (simulation.py:46)
-    const double *zf = zi + 7, *zp = zi + 7 + 2 * (size_t)n;
     Acc a; acc_zero(a);
     for (int i = tid; i < n; i += 256) {
-        const double x = pos[2 * i] + sig[4] * zp[2 * i], y = pos[2 * i + 1] + sig[4] * zp[2 * i + 1];
-        const double ux = true_flow[2 * i] + sig[3] * zf[2 * i], uy = true_flow[2 * i + 1] + sig[3] * zf[2 * i + 1];
+        const double x = pos[2 * i] + sig[4] * Z(zp + 2 * i), y = pos[2 * i + 1] + sig[4] * Z(zp + 2 * i + 1);
+        const double ux = true_flow[2 * i] + sig[3] * Z(zf + 2 * i), uy = true_flow[2 * i + 1] + sig[3] * Z(zf + 2 * i + 1);
         double q0, q1, q2, sA, sB;
         point_terms(OFK_SOLVE_SIM, x, y, ux, uy, ne, ang, h_err, 1.0, q0, q1, q2, sA, sB);
         acc_point(a, x, y, q0, q1, q2, sA, sB);
@@ -880,8 +925,8 @@ __global__ __launch_bounds__(256) void k_of_simulation(const double *__restrict_
     double part2 = 0.0;
     for (int i = tid; i < n; i += 256) {
         const double xp0 = pos[2 * i], xp1 = pos[2 * i + 1];
-        const double dx0 = sig[4] * zp[2 * i], dx1 = sig[4] * zp[2 * i + 1];                 // dxp = (pos_err - pos, 0)
-        const double dd0 = sig[3] * zf[2 * i], dd1 = sig[3] * zf[2 * i + 1];                 // ddotx
+        const double dx0 = sig[4] * Z(zp + 2 * i), dx1 = sig[4] * Z(zp + 2 * i + 1);         // dxp = (pos_err - pos, 0)
+        const double dd0 = sig[3] * Z(zf + 2 * i), dd1 = sig[3] * Z(zf + 2 * i + 1);         // ddotx
         // reference computes dxp / ddotx as differences of the perturbed and true values; reproduce that rounding
         const double pe0 = xp0 + dx0, pe1 = xp1 + dx1, fe0 = true_flow[2 * i] + dd0, fe1 = true_flow[2 * i + 1] + dd1;
         const double e0 = pe0 - xp0, e1 = pe1 - xp1, f0 = fe0 - true_flow[2 * i], f1 = fe1 - true_flow[2 * i + 1];
@@ -915,7 +960,15 @@ void ofk_launch_of_simulation(hipStream_t s, const double *truth, const double *
                               const double *true_flow, int n, const double *z, int trials, double *v_obs,
                               double *bound)
 {
-    hipLaunchKernelGGL(k_of_simulation, dim3(trials), dim3(256), 0, s, truth, sig, pos, true_flow, n, z, v_obs, bound);
+    hipLaunchKernelGGL(k_of_simulation<false>, dim3(trials), dim3(256), 0, s, truth, sig, pos, true_flow, n, z, v_obs, bound, ofk_noise{0u, 0u, 0u, 0u});
+}
+
+// the same with the normals generated on the device: trials trial0 .. trial0 + trials - 1 of sweep step `step` under `seed`
+void ofk_launch_of_simulation_rng(hipStream_t s, const double *truth, const double *sig, const double *pos, const double *true_flow, int n,
+                                  unsigned long long seed, unsigned step, unsigned trial0, int trials, double *v_obs, double *bound)
+{
+    hipLaunchKernelGGL(k_of_simulation<true>, dim3(trials), dim3(256), 0, s, truth, sig, pos, true_flow, n, (const double *)nullptr, v_obs, bound,
+                       ofk_noise{(unsigned)seed, (unsigned)(seed >> 32), step, trial0});
 }
 
 // ------------------------------------------------------------------------------------------------ multi-plane sorting statistics

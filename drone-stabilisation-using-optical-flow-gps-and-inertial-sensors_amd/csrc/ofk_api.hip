@@ -770,6 +770,37 @@ extern "C" int ofk_of_simulation(ofk_ctx *c, const double *truth, const double *
     return get(c, bound, db, (size_t)trials * 8);
 }
 
+// of_simulation with the normals drawn on the device (counter-based: k_estimate.hip ofk_noise_normal); nothing but 13 + 6 + 4 n doubles
+// goes up and 4 doubles per trial come back
+extern "C" int ofk_of_simulation_rng(ofk_ctx *c, const double *truth, const double *sig, const double *pos, const double *true_flow, int n,
+                                     unsigned long long seed, unsigned step, unsigned trial0, int trials, double *v_obs, double *bound)
+{
+    if (!c || !truth || !sig || !pos || !true_flow || !v_obs || !bound || n < 1 || trials < 1 || (unsigned long long)n * 4 + 10 > 0x7fffffffull)
+        return ofk_fail(c, OFK_E_INVALID, "ofk_of_simulation_rng: bad argument");
+    Bump bp;
+    TRY(est_begin(c, (size_t)n * 32 + (size_t)trials * 32 + 8 * 256, bp));
+    double *dt = bp.put(truth, 13 * 8), *ds = bp.put(sig, 6 * 8), *dp = bp.put(pos, (size_t)n * 16), *df = bp.put(true_flow, (size_t)n * 16),
+           *dv = bp.take((size_t)trials * 24), *db = bp.take((size_t)trials * 8);
+    if (bp.rc) return ofk_fail(c, OFK_E_HIP, "ofk_of_simulation_rng: upload failed");
+    ofk_launch_of_simulation_rng(c->stream, dt, ds, dp, df, n, seed, step, trial0, trials, dv, db);
+    TRY(check_launch(c, "k_of_simulation<rng>"));
+    TRY(get(c, v_obs, dv, (size_t)trials * 24));
+    return get(c, bound, db, (size_t)trials * 8);
+}
+
+// elements 0 .. count - 1 of the noise row of (seed, step, trial): the generator itself, for tests and for callers that want the draws
+extern "C" int ofk_noise_normals(ofk_ctx *c, unsigned long long seed, unsigned step, unsigned trial, int count, double *out)
+{
+    if (!c || !out || count < 1) return ofk_fail(c, OFK_E_INVALID, "ofk_noise_normals: bad argument");
+    Bump bp;
+    TRY(est_begin(c, (size_t)count * 8 + 256, bp));
+    double *d = bp.take((size_t)count * 8);
+    if (bp.rc) return ofk_fail(c, OFK_E_HIP, "ofk_noise_normals: scratch");
+    ofk_launch_noise_normals(c->stream, (unsigned)seed, (unsigned)(seed >> 32), step, trial, count, d);
+    TRY(check_launch(c, "k_noise_normals"));
+    return get(c, out, d, (size_t)count * 8);
+}
+
 extern "C" int ofk_feas_simulation(ofk_ctx *c, const double *truth, const double *sig, const double *pos, const double *true_flow,
                                    int n, const double *z, int trials, double *mean, double *per_trial, double *v_obs)
 {

@@ -181,6 +181,9 @@ void ofk_launch_kf(hipStream_t s, int ns, int nm, int nc, const double *F, const
 void ofk_launch_of_simulation(hipStream_t s, const double *truth, const double *sig, const double *pos,
                               const double *true_flow, int n, const double *z, int trials, double *v_obs,
                               double *bound);
+void ofk_launch_of_simulation_rng(hipStream_t s, const double *truth, const double *sig, const double *pos, const double *true_flow, int n,
+                                  unsigned long long seed, unsigned step, unsigned trial0, int trials, double *v_obs, double *bound);
+void ofk_launch_noise_normals(hipStream_t s, unsigned k0, unsigned k1, unsigned step, unsigned trial, int count, double *out);
 void ofk_launch_feas_simulation(hipStream_t s, const double *truth, const double *sig, const double *pos, const double *true_flow,
                                 int n, const double *z, int trials, double *per, double *mean, double *v_obs);
 void ofk_launch_hist_overlap(hipStream_t s, const double *d1, int n1, const double *d2, int n2, int bins, int *out);

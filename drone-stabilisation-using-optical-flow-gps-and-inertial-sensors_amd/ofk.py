@@ -26,7 +26,7 @@ SYMBOLS = (
     "ofk_version", "ofk_last_error", "ofk_device_count", "ofk_create", "ofk_destroy", "ofk_sync", "ofk_device_sync",
     "ofk_gray_bgr8", "ofk_pyr_down_u8", "ofk_pyramid_u8", "ofk_scharr_s16", "ofk_mineig_response", "ofk_select_corners",
     "ofk_good_features", "ofk_lk_pyr", "ofk_flow_model", "ofk_feasibility", "ofk_velocity_solve", "ofk_imu_propagate",
-    "ofk_post_solve", "ofk_kf_predict_update", "ofk_of_simulation", "ofk_feas_simulation", "ofk_hist_overlap", "ofk_associate_sensors", "ofk_feature_eval", "ofk_d_split", "ofk_pairs_upload", "ofk_pairs_upload_jpeg", "ofk_jpeg_stage", "ofk_jpeg_stage_error", "ofk_pairs_upload_staged", "ofk_jpeg_info", "ofk_jpeg_decode_bgr8", "ofk_pairs_set_sensors",
+    "ofk_post_solve", "ofk_kf_predict_update", "ofk_of_simulation", "ofk_of_simulation_rng", "ofk_noise_normals", "ofk_feas_simulation", "ofk_hist_overlap", "ofk_associate_sensors", "ofk_feature_eval", "ofk_d_split", "ofk_pairs_upload", "ofk_pairs_upload_jpeg", "ofk_jpeg_stage", "ofk_jpeg_stage_error", "ofk_pairs_upload_staged", "ofk_jpeg_info", "ofk_jpeg_decode_bgr8", "ofk_pairs_set_sensors",
     "ofk_pairs_run", "ofk_pairs_download", "ofk_pairs_export_records_f32", "ofk_stream_begin", "ofk_stream_step",
     "ofk_stream_begin_jpeg", "ofk_stream_step_jpeg",
     "ofk_set_streams", "ofk_set_overlap", "ofk_set_tuning", "ofk_get_tuning", "ofk_mark", "ofk_mark_wait", "ofk_profile_enable", "ofk_profile_read", "ofk_resident_pyramid",
@@ -114,6 +114,8 @@ def load_library():
         L.ofk_d_split.argtypes = [vp, vp, vp, i, i, d, vp, vp, vp]
         L.ofk_kf_predict_update.argtypes = [vp, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i]
         L.ofk_of_simulation.argtypes = [vp, vp, vp, vp, vp, i, vp, i, vp, vp]
+        L.ofk_of_simulation_rng.argtypes = [vp, vp, vp, vp, vp, i, C.c_ulonglong, C.c_uint, C.c_uint, i, vp, vp]
+        L.ofk_noise_normals.argtypes = [vp, C.c_ulonglong, C.c_uint, C.c_uint, i, vp]
         L.ofk_feas_simulation.argtypes = [vp, vp, vp, vp, vp, i, vp, i, vp, vp, vp]
         L.ofk_hist_overlap.argtypes = [vp, vp, i, vp, i, i, C.POINTER(i)]
         L.ofk_pairs_upload.argtypes = [vp, vp, vp, i, i, i]
@@ -493,6 +495,25 @@ class Context:
         with self._lock:
             self._ck(self._L.ofk_of_simulation(self._h, _p(truth), _p(sig), _p(pos), _p(true_flow), n, _p(z), trials, _p(v), _p(bound)))
         return v, bound
+
+    def of_simulation_rng(self, truth, sig, pos, true_flow, seed, step, trials, trial0=0):
+        """of_simulation with the normals drawn on the device (ofk_of_simulation_rng: Philox4x32-10 + Box-Muller keyed by (seed, step,
+        global trial index)).  Returns (v_obs [trials, 3], bound [trials])."""
+        truth = _arr(truth, np.float64, (13,)); sig = _arr(sig, np.float64, (6,))
+        pos = _arr(pos, np.float64); true_flow = _arr(true_flow, np.float64)
+        n = len(pos)
+        v = np.empty((int(trials), 3), np.float64); bound = np.empty(int(trials), np.float64)
+        with self._lock:
+            self._ck(self._L.ofk_of_simulation_rng(self._h, _p(truth), _p(sig), _p(pos), _p(true_flow), n, C.c_ulonglong(int(seed)), C.c_uint(int(step)),
+                                                   C.c_uint(int(trial0)), int(trials), _p(v), _p(bound)))
+        return v, bound
+
+    def noise_normals(self, seed, step, trial, count):
+        """Elements 0 .. count - 1 of the device generator's row for (seed, step, trial)."""
+        out = np.empty(int(count), np.float64)
+        with self._lock:
+            self._ck(self._L.ofk_noise_normals(self._h, C.c_ulonglong(int(seed)), C.c_uint(int(step)), C.c_uint(int(trial)), int(count), _p(out)))
+        return out
 
     def feas_simulation(self, truth, sig, pos, true_flow, z, per_trial=False):
         """simulation.py:70-104 for all trials in one launch.  Returns (mean [6, n] in the reference's return order, v_obs

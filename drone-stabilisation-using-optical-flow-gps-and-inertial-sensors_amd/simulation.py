@@ -153,7 +153,7 @@ def sweep_step(axis, i, k, data, height_above_gr, normal_vector, sigmas):
 
 
 def sweep(axis, data, linear_velocity, angular_velocity, height_above_gr, normal_vector, translation, sigmas=None, k=100, trials=None,
-          steps=None, generator=None, comm=None):
+          steps=None, generator=None, comm=None, device_seed=None):
     """One of the reference's eight Monte-Carlo sweeps (SWEEP_AXES; simulation.py:183-461): k steps, `trials` of_simulation
     iterations per step (default: the block's own `iterations`), all trials of a step in ONE launch of k_of_simulation.  Returns
     np.append(v_mean, v_std) laid out like the saved effect_*.npy files ([k,3] means then [k,3] standard deviations); with
@@ -162,7 +162,11 @@ def sweep(axis, data, linear_velocity, angular_velocity, height_above_gr, normal
     With `comm` (sharding.Comm) the trials of every step are sharded over the ranks: rank r solves the contiguous slice
     shard_range(trials, r, world) of the step's trials on its own GPU and the per-step statistics come from one all-reduce of
     (sum v, sum v^2, count) = 7 doubles - trials never travel.  Every rank draws the step's full noise
-    tensor from the same generator and keeps its slice, so the result does not depend on the number of ranks."""
+    tensor from the same generator and keeps its slice, so the result does not depend on the number of ranks.
+
+    device_seed (an int): the normals are drawn ON THE DEVICE by the counter-based generator of ofk_of_simulation_rng (Philox4x32-10 keyed
+    by (device_seed, step index, global trial index)) instead of numpy's - no noise tensor is built or uploaded (2000 points x 4096
+    trials = 262 MB per step at BASELINE configs[4]'s size), and a rank's shard is exactly the rows a single rank would draw."""
     global true_flow, iterations
     try:
         from . import sharding
@@ -177,11 +181,19 @@ def sweep(axis, data, linear_velocity, angular_velocity, height_above_gr, normal
     for row, i in enumerate(idx):
         d, h, n, sig = sweep_step(axis, i, k, data, height_above_gr, normal_vector, sigmas)
         true_flow = generate_test_data(d, linear_velocity, angular_velocity, h, n, translation)
-        z = draw_noise(len(d), trials, generator)[lo:hi]
-        if hi > lo:
+        if device_seed is not None:
+            if hi > lo:
+                truth = np.concatenate([np.asarray(linear_velocity, np.float64), np.asarray(angular_velocity, np.float64), [float(h)],
+                                        np.asarray(n, np.float64), np.asarray(translation, np.float64)])
+                v_obs, _ = ofk.default_context().of_simulation_rng(truth, np.asarray(sig, np.float64), d, true_flow, device_seed, i, hi - lo, trial0=lo)
+            else:
+                v_obs = np.zeros((0, 3))
+        elif hi > lo:
+            z = draw_noise(len(d), trials, generator)[lo:hi]
             iterations = hi - lo
             v_obs, _, _ = of_simulation(linear_velocity, angular_velocity, h, n, translation, d, *sig, z=z)
         else:
+            draw_noise(len(d), trials, generator)                # keep the generator in step with the other ranks
             v_obs = np.zeros((0, 3))
         if comm is None:
             v_mean[row] = v_obs.mean(axis=0); v_std[row] = v_obs.std(axis=0)

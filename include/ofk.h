@@ -175,6 +175,15 @@ int ofk_kf_predict_update(ofk_ctx *ctx, int ns, int nm, int nc, const double *F,
  * v_obs [trials][3], bound [trials] (analytic error bound, simulation.py:56-64). */
 int ofk_of_simulation(ofk_ctx *ctx, const double *truth, const double *sig, const double *pos, const double *true_flow,
                       int n, const double *z, int trials, double *v_obs, double *bound);
+/* The same with the normals drawn ON THE DEVICE by a counter-based generator, for the 4096-wide batches of the Monte-Carlo sweeps
+ * (simulation.py:183-461 at BASELINE configs[4]'s size: 2000 points x 4096 trials = 262 MB of host noise per step otherwise):
+ * element e of the row of trial t of sweep step `step` = output (e & 1) of the Box-Muller transform of
+ * Philox4x32-10(counter (e >> 1, t, step, 0), key (seed & 0xffffffff, seed >> 32)); uniforms ((x0 >> 5) 2^26 + (x1 >> 6) + 0.5) 2^-53.
+ * Trials trial0 .. trial0 + trials - 1 (GLOBAL indices: ranks that shard the trials produce the same rows as one rank would).
+ * ofk_noise_normals returns elements 0 .. count - 1 of one row - the generator itself (oracle: estimation_oracle.noise_normals). */
+int ofk_of_simulation_rng(ofk_ctx *ctx, const double *truth, const double *sig, const double *pos, const double *true_flow, int n,
+                          unsigned long long seed, unsigned step, unsigned trial0, int trials, double *v_obs, double *bound);
+int ofk_noise_normals(ofk_ctx *ctx, unsigned long long seed, unsigned step, unsigned trial, int count, double *out);
 
 /* feas_simulation(...) - simulation.py:70-104 (driven by the live experiment simulation.py:753-812: three ground planes, the
  * second one with randomly rotated flow), with the np.random.normal draws supplied by the caller:

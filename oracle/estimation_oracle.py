@@ -333,3 +333,41 @@ def feature_eval(pos, pos_err, oldpos, oldpos_err, vel, vel_err, focal_len, dumm
         dn = quad / np.amax(quad) if np.amax(quad) > 0 else np.zeros_like(quad)
         score = weight[0] * (1 - norm(h)) + weight[1] * norm(he) + weight[2] * (1 - dn) + weight[3] * norm(e)
     return h, he, immobile, score, np.argsort(score, kind="stable")
+
+
+# ------------------------------------------------------------------------------------------------ counter-based noise (Monte-Carlo sweeps)
+# The reference draws its noise with np.random.normal, unseeded (simulation.py:40-47); the golden vectors inject those draws.  For the
+# 4096-wide batches of BASELINE configs[4] the product can draw the normals on the device instead (csrc/k_estimate.hip ofk_noise_normal,
+# include/ofk.h ofk_of_simulation_rng); this is the same function in numpy.  The integer part is Philox4x32-10 (Salmon et al., "Parallel
+# random numbers: as easy as 1, 2, 3", SC'11 - Random123), pinned by that paper's known-answer vectors (tests/test_oracle_golden.py).
+_PH_M0, _PH_M1, _PH_W0, _PH_W1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0x9E3779B9), np.uint64(0xBB67AE85)
+_U32 = np.uint64(0xFFFFFFFF)
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Philox4x32-10 on arrays of 32-bit counter words (uint64 holders) -> four arrays of 32-bit outputs."""
+    c = [np.asarray(x, np.uint64) & _U32 for x in (c0, c1, c2, c3)]
+    k = [np.uint64(int(k0) & 0xFFFFFFFF), np.uint64(int(k1) & 0xFFFFFFFF)]
+    for _ in range(10):
+        p0 = _PH_M0 * c[0]; p1 = _PH_M1 * c[2]
+        c = [(p1 >> np.uint64(32)) ^ c[1] ^ k[0], p1 & _U32, (p0 >> np.uint64(32)) ^ c[3] ^ k[1], p0 & _U32]
+        k = [(k[0] + _PH_W0) & _U32, (k[1] + _PH_W1) & _U32]
+    return c
+
+
+def noise_normals(seed, step, trial, count):
+    """Elements 0 .. count - 1 of the noise row of (seed, step, trial): element e = output (e & 1) of the Box-Muller transform of
+    Philox4x32-10(counter (e >> 1, trial, step, 0), key (seed low, seed high))."""
+    j = np.arange((int(count) + 1) // 2, dtype=np.uint64)
+    x0, x1, x2, x3 = philox4x32_10(j, np.full_like(j, int(trial)), np.full_like(j, int(step)), np.zeros_like(j), int(seed) & 0xFFFFFFFF, int(seed) >> 32)
+    u1 = ((x0 >> np.uint64(5)).astype(np.float64) * 67108864.0 + (x1 >> np.uint64(6)).astype(np.float64) + 0.5) * 2.0 ** -53
+    u2 = ((x2 >> np.uint64(5)).astype(np.float64) * 67108864.0 + (x3 >> np.uint64(6)).astype(np.float64) + 0.5) * 2.0 ** -53
+    r = np.sqrt(-2.0 * np.log(u1)); th = 6.283185307179586476925 * u2
+    out = np.empty(2 * len(j), np.float64)
+    out[0::2] = r * np.cos(th); out[1::2] = r * np.sin(th)
+    return out[:int(count)]
+
+
+def noise_rows(seed, step, trial0, trials, n_points):
+    """[trials, 10 + 4 n] normals: what ofk_of_simulation_rng draws for trials trial0 .. trial0 + trials - 1 (of_simulation's z)."""
+    return np.stack([noise_normals(seed, step, trial0 + t, 10 + 4 * int(n_points)) for t in range(int(trials))])

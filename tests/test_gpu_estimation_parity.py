@@ -211,6 +211,62 @@ def test_sweep_layout_and_default_trials(pkg, gpu_ctx, sweeps_golden):
         sim.sweep_step("no_such_axis", 0, 100, sweeps_golden["points_raw"], 1.0, [0, 0, 1], None)
 
 
+# ---- the counter-based noise of the device (ofk_of_simulation_rng): generator, kernel and sweep against the oracle's restatement
+def test_device_noise_generator_matches_the_oracle(gpu_ctx):
+    """ofk_noise_normals = oracle noise_normals: Philox4x32-10 integers identical, the f64 Box-Muller transform to the last ulps of
+    libm's log / sin / cos (a normal near zero is a difference of magnitudes ~1: absolute tolerance 4e-16)."""
+    for seed, step, trial, count in ((0, 0, 0, 8), (1, 2, 3, 811), (0xFFFFFFFFFFFFFFFF, 99, 4095, 8010), (20261005, 7, 123456, 33)):
+        got = gpu_ctx.noise_normals(seed, step, trial, count)
+        ref = eo.noise_normals(seed, step, trial, count)
+        np.testing.assert_allclose(got, ref, rtol=2e-14, atol=4e-16)
+    z = gpu_ctx.noise_normals(5, 1, 2, 400000)
+    assert abs(z.mean()) < 5 / np.sqrt(z.size) and abs(z.std() - 1) < 5e-3 and abs((z ** 4).mean() - 3) < 0.05
+
+
+@pytest.mark.parametrize("n_pts,trials", [(200, 64), (2000, 24)])
+def test_of_simulation_with_device_noise_equals_injected_oracle_noise(gpu_ctx, golden, n_pts, trials):
+    """The kernel with RNG = true draws exactly the rows the oracle generates: v_obs and the analytic bound equal the injected-noise
+    kernel's (golden G6 pins that one to the reference) on those rows; a shard (trial0 > 0) equals the slice of the whole."""
+    g = golden
+    rng = np.random.default_rng(n_pts)
+    pts = g["g1_points"] if n_pts == 200 else rng.uniform(-1.2, 1.2, (n_pts, 2))
+    tf = eo.generate_test_data(pts, g["g1_v"], g["g1_omega"], 1.0, g["g1_n"], g["g1_t"])
+    truth = np.concatenate([g["g1_v"], g["g1_omega"], [1.0], g["g1_n"], g["g1_t"]])
+    sig = [0.00071, 0.005, 0.01, 0.02, 0.03, 0.00065]
+    seed, step = 0x1234ABCD5678, 17
+    v, b = gpu_ctx.of_simulation_rng(truth, sig, pts, tf, seed, step, trials)
+    z = eo.noise_rows(seed, step, 0, trials, n_pts)
+    v_ref, b_ref = gpu_ctx.of_simulation(truth, sig, pts, tf, z)
+    close(v, v_ref, rtol=1e-9); close(b, b_ref, rtol=1e-8)
+    v_sh, b_sh = gpu_ctx.of_simulation_rng(truth, sig, pts, tf, seed, step, trials // 2, trial0=trials // 4)
+    assert np.array_equal(v_sh, v[trials // 4:trials // 4 + trials // 2]) and np.array_equal(b_sh, b[trials // 4:trials // 4 + trials // 2])
+    v_other, _ = gpu_ctx.of_simulation_rng(truth, sig, pts, tf, seed, step + 1, trials)
+    assert not np.allclose(v_other, v)
+
+
+def test_sweep_with_device_noise_reproduces_a_saved_curve(pkg, gpu_ctx, sweeps_golden):
+    """simulation.sweep(device_seed=...) at the batch width of BASELINE configs[4] (4096 trials per step, nothing uploaded but the
+    points): statistics against the reference's saved flow-error curve under the same rule as the injected-noise sweep."""
+    import of_amd.simulation as sim
+    axis = "flow_errors"
+    override, n_ref, band, std_steps, mean_tol, comps = SWEEP_RULES[axis]
+    saved = sweeps_golden[sim.SWEEP_AXES[axis][0]]
+    mean_s, std_s = saved[:300].reshape(100, 3), saved[300:].reshape(100, 3)
+    steps, trials = (10, 50, 90), 4096
+    out = sim.sweep(axis, sweeps_golden["points_raw"], [1.0, 1, 1], [1.0, 1, 1], 1.0, [0.0, 0, 1], [0.02, 0, 0.205], sigmas=override,
+                    k=100, trials=trials, steps=steps, device_seed=424242)
+    mean_o, std_o = out[:9].reshape(3, 3), out[9:].reshape(3, 3)
+    for row, i in enumerate(steps):
+        for c in comps:
+            tol = 4 * std_s[i, c] / np.sqrt(n_ref) + 4 * std_o[row, c] / np.sqrt(trials) + mean_tol
+            assert abs(mean_o[row, c] - mean_s[i, c]) < tol, (i, c, mean_o[row], mean_s[i], tol)
+            if band is not None and i in std_steps:
+                assert band[0] < std_o[row, c] / std_s[i, c] < band[1], (i, c, std_o[row], std_s[i])
+    again = sim.sweep(axis, sweeps_golden["points_raw"], [1.0, 1, 1], [1.0, 1, 1], 1.0, [0.0, 0, 1], [0.02, 0, 0.205], sigmas=override,
+                      k=100, trials=trials, steps=steps, device_seed=424242)
+    assert np.array_equal(again, out)                            # a seed names a sweep
+
+
 # ---- feas_simulation + overlap (simulation.py:70-104, 124-136; the live experiment :753-774), golden from the reference's functions
 @pytest.fixture(scope="module")
 def feas_golden():

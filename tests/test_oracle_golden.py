@@ -189,3 +189,21 @@ def test_sweep_steps_follow_the_reference_blocks(pkg):
         vo, _, _ = eo.of_simulation(v, om, h, n, t, d, tf, sig, rng.standard_normal((T, 10 + 4 * len(d))), T)
         assert np.all(np.abs(vo.mean(0) - mean_s) < 4 * std_s / 10 + 4 * vo.std(0) / np.sqrt(T)), (axis, vo.mean(0), mean_s)
         assert np.all(np.abs(vo.std(0) / std_s - 1) < 0.4), (axis, vo.std(0), std_s)
+
+
+def test_philox_known_answers_and_noise_rows():
+    """The counter-based noise of the Monte-Carlo sweeps (oracle/estimation_oracle.py noise_normals = csrc/k_estimate.hip
+    ofk_noise_normal): Philox4x32-10 against the known-answer vectors of Random123 (Salmon et al., SC'11: kat_vectors, philox4x32 10),
+    the normals' moments, and the independence of rows from how many trials are generated (what sharding relies on)."""
+    kats = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+            ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+            ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kats:
+        got = eo.philox4x32_10([ctr[0]], [ctr[1]], [ctr[2]], [ctr[3]], key[0], key[1])
+        assert tuple(int(x[0]) for x in got) == want
+    z = eo.noise_normals(99, 3, 5, 200001)
+    assert z.shape == (200001,) and abs(z.mean()) < 5 / np.sqrt(z.size) and abs(z.std() - 1) < 0.01 and abs((z ** 4).mean() - 3) < 0.1
+    assert np.array_equal(eo.noise_normals(99, 3, 5, 7), z[:7])                       # a prefix is a prefix (odd counts too)
+    rows = eo.noise_rows(99, 3, 4, 3, 50)
+    assert rows.shape == (3, 210) and np.array_equal(rows[1], eo.noise_normals(99, 3, 5, 210))
+    assert not np.array_equal(eo.noise_normals(99, 4, 5, 16), z[:16]) and not np.array_equal(eo.noise_normals(98, 3, 5, 16), z[:16])
