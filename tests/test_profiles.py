@@ -82,3 +82,21 @@ def test_bench_refuses_impossible_traffic(monkeypatch, capsys):
     monkeypatch.setattr(bench, "pmc_traffic", lambda stage, pairs: 300)
     assert bench.checked_traffic("eig", 256, 625) is None and "refused" in capsys.readouterr().err
     assert bench.checked_traffic("eig", 256, 300) == 300
+
+
+def test_bench_algorithmic_bytes_follow_survey_8d():
+    """bench.py's per-stage byte counts are SURVEY.md 8(d)'s formulas: at 1080p / 3 levels / 500 points G_gray = 16.59 MB, G_pyr = 6.80 MB,
+    G_lk ~ 1.6 MB per pair; the fused minimum of the pyramid pass is 2 (P0 + .. + P3) = 5.51 MB; every configuration the bench runs has
+    a workload string that names its BASELINE entry."""
+    import importlib.util
+    from types import SimpleNamespace
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    ab = bench.algorithmic_bytes(SimpleNamespace(max_level=3, win=15), 500, 46000, 1080, 1920)
+    assert abs(ab["gray"] / 1e6 - 16.59) < 0.01 and abs(ab["pyr"] / 1e6 - 6.80) < 0.01 and abs(ab["pyr_fused_minimum"] / 1e6 - 5.51) < 0.01
+    assert 1.5e6 < ab["lk"] < 1.7e6 and ab["eig"] == 1080 * 1920 + 8 * 46000
+    for name, c in bench.CONFIGS.items():
+        assert f"BASELINE configs[{name[1]}]" in c["workload"] and c["batch"] >= 128 and c["streams"] in (1, 2)
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert "1920" in base["configs"][1] and "1024" in base["configs"][2] and "3840" in base["configs"][4]
