@@ -36,7 +36,8 @@ __global__ __launch_bounds__(256) void k_gray_bgr8(const uint8_t *__restrict__ b
         // 2*(3735 b + 19235 g + 9798 r) + 32768 = 256 * dot(px, HI) + dot(px, LO) + 32768 with byte-sized coefficients
         // (7470 = 29*256 + 46, 38470 = 150*256 + 70, 19596 = 76*256 + 140): two v_dot4_u32_u8 per pixel, and the gray value
         // (sum >> 16; the sum stays below 2^24) is byte 2 of the result — v_perm gathers four of them into the output dword.
-        // One v_alignbit brings the pixel's three bytes to the bottom of a dword (the fourth byte meets coefficient 0).
+        // One v_alignbit brings the pixel's three bytes to the bottom of a dword (the fourth byte meets coefficient 0); a pixel that
+        // sits in bytes 1..3 of one dword (every fourth) meets coefficients shifted by one byte instead.
         constexpr unsigned HI = 29u | (150u << 8) | (76u << 16), LO = 46u | (70u << 8) | (140u << 16);
         const uint4 *s4 = reinterpret_cast<const uint4 *>(src + (size_t)p0 * 3);
         const uint4 a = s4[0], c = s4[1], d = s4[2];
@@ -45,8 +46,13 @@ __global__ __launch_bounds__(256) void k_gray_bgr8(const uint8_t *__restrict__ b
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const int byte = 3 * k;
-            const unsigned px = (byte & 3) ? __builtin_amdgcn_alignbit(wv[(byte >> 2) + 1], wv[byte >> 2], (byte & 3) * 8) : wv[byte >> 2];
-            t[k] = (__builtin_amdgcn_udot4(px, HI, 0u, false) << 8) + __builtin_amdgcn_udot4(px, LO, 32768u, false);
+            if ((byte & 3) == 1) {                              // bytes 1..3 of one dword: the coefficients move, not the pixel
+                const unsigned px = wv[byte >> 2];
+                t[k] = (__builtin_amdgcn_udot4(px, HI << 8, 0u, false) << 8) + __builtin_amdgcn_udot4(px, LO << 8, 32768u, false);
+            } else {
+                const unsigned px = (byte & 3) ? __builtin_amdgcn_alignbit(wv[(byte >> 2) + 1], wv[byte >> 2], (byte & 3) * 8) : wv[byte >> 2];
+                t[k] = (__builtin_amdgcn_udot4(px, HI, 0u, false) << 8) + __builtin_amdgcn_udot4(px, LO, 32768u, false);
+            }
         }
         unsigned out[4];
 #pragma unroll
@@ -83,8 +89,13 @@ __global__ __launch_bounds__(64) void k_gray_bgr8_wide(const uint8_t *__restrict
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const int byte = 3 * k;
-            const unsigned px = (byte & 3) ? __builtin_amdgcn_alignbit(wv[(byte >> 2) + 1], wv[byte >> 2], (byte & 3) * 8) : wv[byte >> 2];
-            t[k] = (__builtin_amdgcn_udot4(px, HI, 0u, false) << 8) + __builtin_amdgcn_udot4(px, LO, 32768u, false);
+            if ((byte & 3) == 1) {                              // bytes 1..3 of one dword: the coefficients move, not the pixel
+                const unsigned px = wv[byte >> 2];
+                t[k] = (__builtin_amdgcn_udot4(px, HI << 8, 0u, false) << 8) + __builtin_amdgcn_udot4(px, LO << 8, 32768u, false);
+            } else {
+                const unsigned px = (byte & 3) ? __builtin_amdgcn_alignbit(wv[(byte >> 2) + 1], wv[byte >> 2], (byte & 3) * 8) : wv[byte >> 2];
+                t[k] = (__builtin_amdgcn_udot4(px, HI, 0u, false) << 8) + __builtin_amdgcn_udot4(px, LO, 32768u, false);
+            }
         }
         unsigned out[4];
 #pragma unroll
