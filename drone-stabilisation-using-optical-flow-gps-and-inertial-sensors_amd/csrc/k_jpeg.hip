@@ -27,25 +27,37 @@
 #include "ofk_internal.h"
 #include <string.h>
 #include <stdlib.h>
+#include <atomic>
 #include <thread>
 #include <vector>
 
 #define JCH 256                 // entropy bytes per decoder thread when there is enough data; halved down to JCH_MIN for small
 #define JCH_MIN 64              // batches (a single 1080p frame: 7000 threads of 64 bytes), where latency counts, not throughput
-#define JB0 4                   // a symbol belongs to chunk i if the byte cursor after the refill is in [i*JCH + JB0, (i+1)*JCH + JB0)
-                                // (the guess of chunk i starts with the cursor at i*JCH + 4 after its first refill)
+#define JCH_MAX 1024            // largest chunk ofk_set_tuning("jpeg_chunk") may ask for: the padding is sized for it
 #define JTPB 256                // decoder threads per workgroup (chunks of ONE image: the tables live in LDS)
 #define JTPW 256                // ... of the coefficient-writing pass (its LDS rows bound the occupancy)
 #define JMAX_ITERS 64           // flag slots; more iterations than this are read back one by one
+#define JNSUB 12                // second-level tables an image's Huffman tables may use (the standard tables of T.81 Annex K need 11)
+
+// Look-up tables of the entropy decoder.  First level: the next 9 bits of the stream; second level (codes of 10..16 bits): the 7
+// bits behind them.  The same tables in two encodings, one per kind of pass, so that a symbol step is one LDS read and two field
+// extractions (before: code length and symbol, then run / size / EOB / ZRL told apart by three branches):
+//   S (synchronisation passes):  (len + s) << 8 | dk        bits the symbol takes with its extra bits; advance of the zigzag index
+//   W (write pass):              (len - 1) << 11 | s << 7 | dk
+// dk = run + 1 for a coefficient, 16 for ZRL, 64 for EOB (any k + 64 ends the block), 1 for a DC symbol; a prefix that is no code
+// reads as a 16-bit EOB (DC: a 16-bit zero difference), which is what jdhuff.c makes of it.  0x8000 | n = second-level table n;
+// 0xFFFF = the image's tables need more than JNSUB second-level tables: canonical search (jslow) for this prefix.
+struct jfast { uint16_t lut[6][512]; uint16_t sub[JNSUB][128]; };    // slot = 2 * component + (AC ? 1 : 0)
 
 struct jpeg_tab {               // per image
-    uint16_t lut[6][512];       // slot = 2*component + (AC ? 1 : 0); 9-bit lookahead: (length << 8) | symbol, 0 = longer code
-    int32_t maxcode[6][18];     // largest code of length l (-1: none), [17] = INT_MAX
+    jfast S, W;
+    int32_t maxcode[6][18];     // largest code of length l (-1: none), [17] = INT_MAX        (canonical tables: the slow path)
     int32_t valoff[6][18];      // vals index of the first code of length l minus that code
     uint8_t vals[6][256];
     uint16_t q[3][64];          // natural order
-    uint32_t ent_off, ent_len;  // entropy segment inside the batch's entropy buffer
+    uint32_t ent_off, ent_len;  // entropy segment (destuffed by the host) inside the batch's entropy buffer
     int32_t nch, ri;            // chunks of this image; restart interval in MCUs (0 = none)
+    uint32_t rst_off, nrst;     // restart boundaries: nrst byte offsets into the destuffed segment, from rst[rst_off] on
 };
 
 struct jpeg_geom {
@@ -60,181 +72,196 @@ __constant__ uint8_t c_izz[64] = {0, 1, 5, 6, 14, 15, 27, 28, 2, 4, 7, 13, 16, 2
 static const uint8_t h_zz[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
                                  35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
-// ------------------------------------------------------------------------------------------------ device: entropy decoder
-// Reads go to global memory (L1/L2 hits: a workgroup's chunks are contiguous).  Staging the chunks in LDS was measured and bought
-// nothing: with 8 waves per SIMD the loop is bound by instruction issue (~250 instructions per symbol with the divergence between
-// lanes), not by the latency of the byte reads, and the 42 KB of LDS cost two thirds of the occupancy.
-// The host pads every entropy segment with zeros up to JPAD(len): the reader needs no bounds checks.
-#define JPAD(len) (((size_t)(len) + 2 * JCH + 19) / JCH * JCH)
-struct jrd { const uint8_t *d; uint32_t pos; uint64_t buf; int nb, fake; int k, blk;    // fake: virtual zero bits buffered while parked at RSTn
-             uint64_t w0, w1, w2; uint32_t wb; };   // read-ahead window: the 24 bytes at wb (8-aligned, wb <= pos); not part of the state
+// the entry of a symbol whose code has `len` bits (both encodings; the host builds the tables with it, the device its slow path)
+__host__ __device__ inline uint32_t jentry(bool write, bool ac, int len, int sym)
+{
+    const int s = sym & 15, run = sym >> 4;
+    const int dk = !ac ? 1 : s ? run + 1 : run == 15 ? 16 : 64;
+    return write ? (uint32_t)(((len - 1) << 11) | (s << 7) | dk) : (uint32_t)(((len + s) << 8) | dk);
+}
 
-struct jlds {
-    uint16_t lut[6][512];
-    int32_t maxcode[6][18];
-    int32_t valoff[6][18];
-    uint8_t vals[6][256];
+// ------------------------------------------------------------------------------------------------ device: entropy decoder
+// The host hands over DESTUFFED entropy segments (FF00 -> FF, RSTn markers taken out and listed), so the decoder's position is a
+// plain bit offset and its state at a symbol boundary (bit position, zigzag index, block in MCU) is canonical by construction.
+// The bits come out of four registers per thread: hi:lo = the 64 stream bits around the cursor (big-endian dwords w, w + 1; c =
+// bits of hi already used, so the next 32 bits are one 64-bit shift away - enough for the longest code, 16, plus the longest run of
+// extra bits, 15), n0 = dword w + 2 and n1 = dword w + 3, requested when the cursor moved into dword w - 1: a symbol step never waits
+// for memory it asked for itself (a byte load per symbol put a round trip into every step of the chain: 83 % of the wave cycles
+// waiting).  Staging the chunks in LDS was measured and bought nothing (42 KB per 128 threads: a third of the occupancy).
+// Every segment starts 256-aligned and is zero-padded up to JPAD(len): no bounds checks.
+#define JPAD(len) (((size_t)(len) + 2 * JCH_MAX + 19) / JCH * JCH)
+__device__ inline uint32_t jld(const uint8_t *d, uint32_t at) { return *reinterpret_cast<const uint32_t *>(d + at); }
+
+// Reader of the write pass: four registers (see above).
+struct jrd {
+    const uint8_t *d; uint32_t hi, lo, n0, n1, nx; int c, k, blk;     // nx: byte offset of dword w + 4
+    __device__ void seek(uint32_t bp)
+    {
+        const uint32_t at = (bp >> 5) * 4u;
+        c = (int)(bp & 31u);
+        hi = __builtin_bswap32(jld(d, at)); lo = __builtin_bswap32(jld(d, at + 4));
+        n0 = jld(d, at + 8); n1 = jld(d, at + 12); nx = at + 16;
+    }
+    __device__ uint32_t pos() const { return (nx - 16u) * 8u + (uint32_t)c; }
+    __device__ bool refill() { return true; }
+    __device__ uint32_t top() const { return (uint32_t)((((uint64_t)hi << 32 | lo) << c) >> 32); }
+    __device__ void advance(int tot)
+    {
+        c += tot;
+        if (c >= 32) { hi = lo; lo = __builtin_bswap32(n0); n0 = n1; n1 = jld(d, nx); nx += 4; c -= 32; }
+    }
 };
 
-__device__ inline void jload_tables(jlds &T, const jpeg_tab *t)
+// Reader of the synchronisation passes: a ring of JRING stream dwords per thread in LDS, refilled at wave-uniform times.
+// With the register reader a thread asks for its next dword when it needs room, and - loads and waits being counted per WAVE - every
+// slide of any lane waits for the youngest load of all 64: some lane slides in almost every step and each lane walks through memory of
+// its own, so a wave met an L2 or HBM round trip in nearly every symbol step (2300 clocks per step at 8 waves per SIMD; the pass took
+// as long with 35 instructions per symbol as with 90).  Here every JREFILL steps ALL lanes ask for the 16 bytes behind their ring and
+// take in, if there is room, what they asked for JREFILL steps ago: one wait per JREFILL steps, for a load that old.  A symbol step
+// reads its 64 bits with one ds_read2_b32 (dword 0 is kept a second time behind dword 15: no wrap) - LDS latency instead of memory
+// latency.  A lane that outruns its ring (a burst of > 2 bytes per step) skips steps until the next refill.
+#define JRING 16
+#define JREFILL 8
+struct jring {
+    const uint8_t *d; uint32_t *rg;                              // rg: this thread's JRING + 1 dwords
+    uint32_t bp, fill;                                           // bit position; the ring holds the stream up to this byte offset (16-aligned)
+    uint4 in;                                                    // the 16 bytes at `fill`, requested at the last refill
+    int k, blk;
+    __device__ void put(const uint4 v, uint32_t at)
+    {
+        const uint32_t s = (at >> 2) & (JRING - 1);
+        const uint32_t a = __builtin_bswap32(v.x);
+        rg[s] = a; rg[s + 1] = __builtin_bswap32(v.y); rg[s + 2] = __builtin_bswap32(v.z); rg[s + 3] = __builtin_bswap32(v.w);
+        if (s == 0) rg[JRING] = a;
+    }
+    __device__ void seek(uint32_t b)
+    {
+        bp = b;
+        const uint32_t f0 = (b >> 7) * 16u;
+        const uint4 v0 = *reinterpret_cast<const uint4 *>(d + f0), v1 = *reinterpret_cast<const uint4 *>(d + f0 + 16), v2 = *reinterpret_cast<const uint4 *>(d + f0 + 32);
+        put(v0, f0); put(v1, f0 + 16); put(v2, f0 + 32);
+        fill = f0 + 48;
+        in = *reinterpret_cast<const uint4 *>(d + fill);
+    }
+    __device__ uint32_t pos() const { return bp; }
+    // every JREFILL steps: true = the lane can decode JREFILL symbols (< 4 bytes each) without looking at its ring's fill level
+    __device__ bool refill()
+    {
+        const uint32_t wb = (bp >> 5) * 4u;
+        if (fill + 16u - wb <= 4u * JRING) { put(in, fill); fill += 16; }
+        in = *reinterpret_cast<const uint4 *>(d + fill);
+        return fill - wb >= 8u + 4u * JREFILL;
+    }
+    __device__ uint32_t top() const
+    {
+        const uint32_t *p = rg + ((bp >> 5) & (JRING - 1));
+        return (uint32_t)((((uint64_t)p[0] << 32 | p[1]) << (bp & 31u)) >> 32);
+    }
+    __device__ void advance(int tot) { bp += (uint32_t)tot; }
+};
+
+__device__ inline void jload_tables(jfast &T, const jfast *t)
 {
-    const uint32_t *src = (const uint32_t *)t;
-    uint32_t *dst = (uint32_t *)&T;
-    for (int i = threadIdx.x; i < (int)(sizeof(jlds) / 4); i += blockDim.x) dst[i] = src[i];
+    const uint4 *src = (const uint4 *)t;
+    uint4 *dst = (uint4 *)&T;
+    for (int i = threadIdx.x; i < (int)(sizeof(jfast) / 16); i += blockDim.x) dst[i] = src[i];
     __syncthreads();
 }
 
-// Read-ahead window.  A decoder's byte reads are serially dependent (the cursor moves by what the last symbol used), and a byte
-// load per symbol put a global-memory round trip into every step of the chain (SQ counters: 83 % of the wave cycles waiting).
-// The window holds the 16 bytes at wb in w0, w1 and has the following 8 in flight in w2: w2 is only read when the window slides,
-// ~10 symbols after it was requested, so the chain sees registers.  Entropy segments start 256-aligned and are zero-padded
-// (JPAD), so the aligned 8-byte reads stay inside the buffer.
-__device__ inline uint64_t jload8(const uint8_t *d, uint32_t at) { return *reinterpret_cast<const uint64_t *>(d + at); }
-__device__ inline void jwindow(jrd &r)
-{
-    r.wb = r.pos & ~7u;
-    r.w0 = jload8(r.d, r.wb); r.w1 = jload8(r.d, r.wb + 8); r.w2 = jload8(r.d, r.wb + 16);
-}
-__device__ inline void jslide(jrd &r) { while (r.pos - r.wb >= 8) { r.w0 = r.w1; r.w1 = r.w2; r.wb += 8; r.w2 = jload8(r.d, r.wb + 16); } }
-// Canonical refill: byte by byte until 32..39 bits are buffered - enough for the longest code (16) plus the longest run of extra
-// bits (15), so a symbol needs one refill.  The state after it depends on the bit position only.  Both paths work on a register
-// view of the stream at the cursor (x0 = bytes pos..pos+3, first one lowest).  Fast path: the 1..4 bytes that are due hold no FF
-// (and no restart marker is pending), so they go in as one byte-reversed shift.  Otherwise byte by byte with the marker rules, the
-// view shifted by what each step consumed (some lane of a wave is here in every fifth step; one window slide per refill instead of
-// one per byte - the passes take the same time as with the per-byte version, the code is a third of the size).
-__device__ inline void jrefill(jrd &r)
-{
-    if (r.nb > 31) return;
-    jslide(r);
-    const uint32_t o = r.pos - r.wb;                                 // 0..7
-    const uint32_t a0 = (uint32_t)r.w0, a1 = (uint32_t)(r.w0 >> 32), a2 = (uint32_t)r.w1, a3 = (uint32_t)(r.w1 >> 32);
-    const bool up = o >= 4;
-    const uint32_t b0 = up ? a1 : a0, b1 = up ? a2 : a1, sh = o & 3;
-    uint32_t x0 = __builtin_amdgcn_alignbyte(b1, b0, sh);
-    {
-        const int n = (39 - r.nb) >> 3;                              // bytes the byte-wise loop would take: 1..4
-        const uint32_t y = ~x0 | (n == 4 ? 0u : 0xFFFFFFFFu << (8 * n));             // a zero byte in y = an FF among the n bytes
-        if (!r.fake && ((y - 0x01010101u) & ~y & 0x80808080u) == 0) {
-            r.buf = (r.buf << (8 * n)) | (uint64_t)(__builtin_bswap32(x0) >> (32 - 8 * n));
-            r.nb += 8 * n; r.pos += n;
-            return;
-        }
-    }
-    // at most 4 bytes go in, each may be followed by a stuffed zero: 8 bytes of the view plus one to look at, pos + 8 <= wb + 15
-    const uint32_t b2 = up ? a3 : a2, b3 = up ? 0u : a3;
-    uint32_t x1 = __builtin_amdgcn_alignbyte(b2, b1, sh), x2 = __builtin_amdgcn_alignbyte(b3, b2, sh);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (r.nb <= 31) {
-            uint32_t b = 0;
-            if (r.fake) r.fake += 8;                              // parked in front of a restart marker: zero bits, like libjpeg
-            else {
-                uint32_t adv = 1;
-                b = x0 & 255u;
-                if (b == 0xFF) {
-                    const uint32_t nx = (x0 >> 8) & 255u;
-                    if (nx == 0) adv = 2;                         // stuffed zero (an FF in front of the zero padding counts as one too)
-                    else if ((nx & 0xF8u) == 0xD0u) { b = 0; r.fake = 8; adv = 0; }   // RSTn: stay in front of it until the interval's bits are used up
-                }
-                r.pos += adv;
-                x0 = __builtin_amdgcn_alignbyte(x1, x0, adv); x1 = __builtin_amdgcn_alignbyte(x2, x1, adv); x2 >>= 8 * adv;
-            }
-            r.buf = (r.buf << 8) | b;
-            r.nb += 8;
-        }
-    }
-}
-
-// the nb unread bits in front of byte cursor pos: nb - fake real ones (walking back over stuffed zeros), then the virtual zeros
-__device__ inline void jrebuild(jrd &r)
-{
-    uint64_t buf = 0;
-    int got = 0;
-    const int real = r.nb - r.fake;
-    uint32_t p = r.pos;
-    while (got < real && p > 0) {
-        --p;
-        uint32_t b = r.d[p];
-        if (b == 0 && p > 0 && r.d[p - 1] == 0xFF) { --p; b = 0xFF; }
-        buf |= (uint64_t)b << got;
-        got += 8;
-    }
-    r.buf = buf << r.fake;
-}
-
-__device__ inline uint32_t jpeek(const jrd &r, int n) { return (uint32_t)(r.buf >> (r.nb - n)) & ((1u << n) - 1u); }
 __device__ inline int jextend(int v, int s) { return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; }
 
-__device__ inline uint64_t jpack(const jrd &r) { return ((uint64_t)r.pos << 32) | ((uint64_t)(r.fake & 63) << 24) | ((uint64_t)r.nb << 16) | ((uint64_t)r.k << 8) | (uint64_t)r.blk; }
-__device__ inline void junpack(jrd &r, uint64_t s) { r.pos = (uint32_t)(s >> 32); r.fake = (int)((s >> 24) & 63); r.nb = (int)((s >> 16) & 63); r.k = (int)((s >> 8) & 63); r.blk = (int)(s & 15); }
+__device__ inline uint64_t jpack(uint32_t bp, int k, int blk) { return ((uint64_t)bp << 32) | ((uint64_t)k << 8) | (uint64_t)blk; }
 
-// Decodes symbols from a symbol boundary (reader refilled) until the byte cursor reaches `bnext` or `max_blocks` blocks are complete.
-// emit.coef(zigzag index, value) is called for every non-zero coefficient of the block in progress (DC as its difference),
+// A code longer than the look-ahead whose prefix got no second-level table: the first length whose largest code is not below the
+// prefix (jdhuff.c's loop), the seven comparisons side by side; canonical tables from global memory (rare: no LDS spent on them).
+__device__ inline uint32_t jslow(const jpeg_tab *t, int slot, uint32_t top, bool write)
+{
+    const int c16 = (int)(top >> 16);
+    unsigned below = 0;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) below |= (unsigned)((c16 >> (6 - j)) > t->maxcode[slot][10 + j]) << j;
+    const int l = 10 + __builtin_ctz(~below | 0x80u);
+    if (l > 16) return jentry(write, slot & 1, 16, 0);
+    return jentry(write, slot & 1, l, t->vals[slot][((c16 >> (16 - l)) + t->valoff[slot][l]) & 255]);
+}
+
+// Decodes symbols from the reader's position while they START in front of bit `bend` (and, WRITE, fewer than max_blocks blocks are
+// complete).  emit.coef(zigzag index, value) for every non-zero coefficient of the block in progress (DC as its difference),
 // emit.block(i) when the i-th block of this run is complete.
-template <class Emit>
-__device__ inline int jrun(const jlds &T, jrd &r, uint32_t bnext, const jpeg_geom &g, int max_blocks, Emit &emit)
+// RST (streams with restart intervals): rl = bits up to the next restart boundary.  A symbol that would run across it is the
+// interval's padding (1-bits: a proper prefix of every table's longest codes, never a code - T.81 Annex C), so the interval is
+// complete (jdhuff.c process_restart): on to the boundary, next MCU.  A decoder in step is at k = 0, blk = 0 there anyway; one that
+// is out of step is in step from there on.
+template <bool WRITE, bool RST, class Reader, class Emit>
+__device__ inline int jrun(const jfast &T, const jpeg_tab *t, const uint32_t *__restrict__ rst, Reader &r, uint32_t bend, const jpeg_geom &g, int max_blocks, Emit &emit)
 {
     int done = 0;
-    const int ny = g.comp_nb[0];
-    while (r.pos < bnext && done < max_blocks) {
-        const int comp = r.blk < ny ? 0 : r.blk - ny + 1;
-        const int slot = comp * 2 + (r.k ? 1 : 0);
-        int len, sym;
-        const uint32_t e = T.lut[slot][jpeek(r, 9)];
-        if (e) { len = e >> 8; sym = e & 255; }
-        else {
-            // a code longer than the lookahead: the first length whose largest code is not below the prefix (jdhuff.c's loop), found
-            // with the seven comparisons side by side - some lane of a wave is here in almost every step, and seven LDS reads one
-            // after the other were the longest link of the decoder's dependency chain
-            const int c16 = (int)jpeek(r, 16);
-            unsigned below = 0;
-#pragma unroll
-            for (int j = 0; j < 7; ++j) below |= (unsigned)((c16 >> (6 - j)) > T.maxcode[slot][10 + j]) << j;
-            const int l = 10 + __builtin_ctz(~below | 0x80u);
-            if (l > 16) { len = 16; sym = 0; }
-            else { len = l; sym = T.vals[slot][((c16 >> (16 - l)) + T.valoff[slot][l]) & 255]; }
+    const int ny = g.comp_nb[0], bpm = g.bpm;
+    const uint16_t *lut = &T.lut[0][0];
+    int sb = (r.blk < ny ? 0 : r.blk - ny + 1) * 2048;          // byte offset of the DC table of the block's component (AC: + 1024)
+    const uint32_t bp0 = r.pos();
+    int rem = (int)(bend - bp0);                                  // bits up to the end of the chunk
+    uint32_t ridx = 0, nrst = 0;
+    int rl = 0x7fffffff;
+    if (RST) {
+        nrst = t->nrst;
+        uint32_t lo = 0, hi = nrst;                               // first boundary behind bp0
+        while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if (rst[m] * 8u > bp0) hi = m; else lo = m + 1; }
+        ridx = lo;
+        if (ridx < nrst) rl = (int)(rst[ridx] * 8u - bp0);
+    }
+    // The loop is the WAVE's: every lane stays until the last one is done (a finished or stalled lane skips the body), so that the
+    // reader's refill points are the same for all lanes: JREFILL symbol steps, refill, ...
+    for (;;) {
+        if (!__any(rem > 0 && (!WRITE || done < max_blocks))) break;
+        const bool go = r.refill();
+#pragma unroll 1
+        for (int u = 0; u < JREFILL; ++u) {
+            if (!(go && rem > 0 && (!WRITE || done < max_blocks))) continue;
+            const uint32_t top = r.top();
+            uint32_t e = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(lut) + sb + (r.k ? 1024 : 0) + ((top >> 22) & 0x3FEu));
+            if (e & 0x8000u) {
+                if (e != 0xFFFFu) e = T.sub[e & 0x7FFFu][(top >> 16) & 127u];
+                else e = jslow(t, (sb >> 10) + (r.k ? 1 : 0), top, WRITE);
+            }
+            int tot, dk, len = 0, s = 0;
+            if (WRITE) { len = (int)(e >> 11) + 1; s = (int)(e >> 7) & 15; dk = (int)(e & 127u); tot = len + s; }
+            else { tot = (int)(e >> 8); dk = (int)(e & 255u); }
+            if (RST && tot > rl) {
+                const uint32_t lim = rst[ridx] * 8u;
+                r.seek(lim);
+                r.k = 0; r.blk = 0; sb = 0;
+                rem = (int)(bend - lim);
+                ++ridx;
+                rl = ridx < nrst ? (int)(rst[ridx] * 8u - lim) : 0x7fffffff;
+                continue;
+            }
+            if (WRITE && s) {
+                const int kk = r.k + dk - 1;
+                if (kk < 64) emit.coef(kk, jextend((int)((top << len) >> (32 - s)), s));
+            }
+            r.advance(tot); rem -= tot;
+            if (RST) rl -= tot;
+            r.k += dk;
+            if (r.k >= 64) {
+                r.k = 0; r.blk = r.blk + 1 == bpm ? 0 : r.blk + 1;
+                sb = (r.blk < ny ? 0 : r.blk - ny + 1) * 2048;
+                emit.block(done); ++done;
+            }
         }
-        if (r.fake && len > r.nb - r.fake) {
-            // Parked at a restart marker and the code would run into the virtual bits: what is left of the interval is its padding
-            // (1-bits, which are a proper prefix of every table's longest codes, never a code - T.81 Annex C), so the interval is
-            // complete (jdhuff.c process_restart): drop the padding, step over the marker, start the next MCU.  A decoder in
-            // step is at k = 0, blk = 0 here anyway; one that is out of step is in step from here on.
-            r.pos += 2; r.nb = 0; r.fake = 0; r.buf = 0; r.k = 0; r.blk = 0;
-            jrefill(r);
-            continue;
-        }
-        r.nb -= len;
-        const int run = r.k ? sym >> 4 : 0, s = sym & 15;
-        if (s) {
-            r.k += run;
-            const int v = jextend((int)jpeek(r, s), s);
-            r.nb -= s;
-            if (r.k < 64) emit.coef(r.k, v);
-            ++r.k;
-        } else if (r.k == 0) r.k = 1;                             // DC difference 0
-        else if (run == 15) r.k += 16;                            // ZRL
-        else r.k = 64;                                            // EOB
-        if (r.k >= 64) { r.k = 0; r.blk = r.blk + 1 == g.bpm ? 0 : r.blk + 1; emit.block(done); ++done; }
-        jrefill(r);
     }
     return done;
 }
 
-__device__ inline void jstart(jrd &r, uint32_t chunk, int jch)
-{   // chunk 0: the true start of the scan; otherwise the guess "a block starts at the first byte of the chunk"
-    r.pos = chunk * (uint32_t)jch; r.nb = 0; r.fake = 0; r.buf = 0; r.k = 0; r.blk = 0;
-    if (chunk && r.d[r.pos - 1] == 0xFF && (r.d[r.pos] == 0 || (r.d[r.pos] & 0xF8u) == 0xD0u)) ++r.pos;   // second byte of FF00 / RSTn
-    jwindow(r);
-    jrefill(r);
-}
-
 struct jemit_none { __device__ void coef(int, int) const {} __device__ void block(int) const {} };
 
-__global__ __launch_bounds__(JTPB) void k_jpeg_sync(const jpeg_tab *__restrict__ tabs, const uint8_t *__restrict__ ent, jpeg_geom g, int nch_max,
-                                                    unsigned long long *__restrict__ state, unsigned long long *__restrict__ used,
+template <bool RST>
+__global__ __launch_bounds__(JTPB) void k_jpeg_sync(const jpeg_tab *__restrict__ tabs, const uint8_t *__restrict__ ent, const uint32_t *__restrict__ rst,
+                                                    jpeg_geom g, int nch_max, unsigned long long *__restrict__ state, unsigned long long *__restrict__ used,
                                                     int *__restrict__ count, int iter, int *__restrict__ flags)
 {
-    __shared__ jlds T;
+    __shared__ jfast T;
+    __shared__ uint32_t ring[JTPB][JRING + 1];
     __shared__ unsigned long long elist[JTPB];
     __shared__ uint16_t clist[JTPB];
     __shared__ int wcount[JTPB / 64];
@@ -266,23 +293,20 @@ __global__ __launch_bounds__(JTPB) void k_jpeg_sync(const jpeg_tab *__restrict__
         work = (int)threadIdx.x < total;
         if (work) { i = blockIdx.x * JTPB + clist[threadIdx.x]; o = (size_t)b * nch_max + i; e = elist[threadIdx.x]; }
     }
-    jload_tables(T, t);
+    jload_tables(T, &t->S);
     if (!work) return;
-    jrd r;
-    r.d = ent + t->ent_off;
-    if (iter == 0) {
-        jstart(r, i, g.jch);
-        e = jpack(r);
-    } else {
-        junpack(r, e);
-        jrebuild(r);
-        jwindow(r);
-    }
+    jring r;
+    r.d = ent + t->ent_off; r.rg = ring[threadIdx.x];
+    const uint32_t cbits = (uint32_t)g.jch * 8u;
+    // chunk 0 starts at the true start of the scan; the guess of every other chunk: a block of the MCU's first component starts here
+    if (iter == 0) e = jpack((uint32_t)i * cbits, 0, 0);
+    r.k = (int)((e >> 8) & 63); r.blk = (int)(e & 15);
+    r.seek((uint32_t)(e >> 32));
     used[o] = e;
     jemit_none em;
-    const int n = jrun(T, r, (uint32_t)(i + 1) * (uint32_t)g.jch + JB0, g, 0x7fffffff, em);
+    const int n = jrun<false, RST>(T, t, rst + t->rst_off, r, (uint32_t)(i + 1) * cbits, g, 0x7fffffff, em);
     count[o] = n;
-    const unsigned long long x = jpack(r);
+    const unsigned long long x = jpack(r.pos(), r.k, r.blk);
     if (iter == 0) state[o] = x;
     else if (x != state[o]) { state[o] = x; flags[iter < JMAX_ITERS ? iter : JMAX_ITERS - 1] = 1; }
 }
@@ -365,33 +389,35 @@ struct jemit_store {
     }
 };
 
-__global__ __launch_bounds__(JTPW) void k_jpeg_write(const jpeg_tab *__restrict__ tabs, const uint8_t *__restrict__ ent, jpeg_geom g, int nch_max,
-                                                     const unsigned long long *__restrict__ state, const int *__restrict__ base,
+template <bool RST>
+__global__ __launch_bounds__(JTPW) void k_jpeg_write(const jpeg_tab *__restrict__ tabs, const uint8_t *__restrict__ ent, const uint32_t *__restrict__ rst,
+                                                     jpeg_geom g, int nch_max, const unsigned long long *__restrict__ state, const int *__restrict__ base,
                                                      int16_t *__restrict__ coef, int16_t *__restrict__ dcarr, int *__restrict__ endinfo)
 {
-    __shared__ jlds T;
+    __shared__ jfast T;
     __shared__ int16_t rows[JTPW][JBLK_PITCH];
     const int b = blockIdx.y;
     const jpeg_tab *t = tabs + b;
     if ((int)(blockIdx.x * JTPW) >= t->nch) return;
-    jload_tables(T, t);
+    jload_tables(T, &t->W);
     const int i = blockIdx.x * JTPW + threadIdx.x;
     if (i >= t->nch) return;
     const int n0 = base[(size_t)b * (nch_max + 1) + i];
     if (n0 >= g.nblk) return;
     jrd r;
     r.d = ent + t->ent_off;
-    if (i == 0) jstart(r, 0, g.jch);
-    else { junpack(r, state[(size_t)b * nch_max + i - 1]); jrebuild(r); jwindow(r); }
+    const unsigned long long e = i ? state[(size_t)b * nch_max + i - 1] : 0ull;
+    r.k = (int)((e >> 8) & 63); r.blk = (int)(e & 15);
+    r.seek((uint32_t)(e >> 32));
     for (int q = 0; q < JBLK_PITCH / 2; ++q) ((uint32_t *)rows[threadIdx.x])[q] = 0;
     jemit_store em;
     em.row = rows[threadIdx.x]; em.out = coef + (size_t)b * g.nblk * 64; em.n0 = n0; em.nblk = g.nblk; em.head_partial = r.k != 0;
     em.dc = dcarr + (size_t)b * g.nblk; em.cur = 0; em.pend_dst = nullptr;
-    const int n = jrun(T, r, (uint32_t)(i + 1) * (uint32_t)g.jch + JB0, g, g.nblk - n0, em);
+    const int n = jrun<true, RST>(T, t, rst + t->rst_off, r, (uint32_t)(i + 1) * (uint32_t)g.jch * 8u, g, g.nblk - n0, em);
     em.drain();
     if (r.k != 0 && n0 + n < g.nblk) em.scatter(n0 + n);          // the block still in progress continues in the next chunk
     if (n0 + n == g.nblk && n > 0) {                              // this thread finished the last block: where the scan ended
-        endinfo[b * 2] = (int)(r.pos - (uint32_t)(r.nb >> 3));
+        endinfo[b * 2] = (int)((r.pos() + 7u) >> 3);
         endinfo[b * 2 + 1] = 1;
     }
 }
@@ -765,27 +791,92 @@ static const char *jparse(const uint8_t *d, size_t n, jhost *j)
     }
     for (int c = 0; c < j->ncomp; ++c)
         if (!j->qok[j->tq[c]] || !j->hok[0][j->td[c]] || !j->hok[1][j->ta[c]]) return "a table the scan refers to is missing";
-    if (j->ent_len >= (1ull << 31)) return "entropy segment too long";
+    if (j->ent_len >= (1ull << 28)) return "entropy segment too long";      // bit positions are 32-bit
     return nullptr;
 }
 
-static void jbuild_slot(jpeg_tab *t, int slot, const uint8_t *bits, const uint8_t *vals)
-{   // T.81 Annex C code assignment; 9-bit lookahead like jdhuff.c's (there: 8 bits)
-    memset(t->lut[slot], 0, sizeof t->lut[slot]);
+// T.81 Annex C code assignment into the look-up tables of one slot (jfast: both encodings) and the canonical tables of the slow path
+static void jbuild_slot(jpeg_tab *t, int slot, const uint8_t *bits, const uint8_t *vals, int *nsub)
+{
+    const bool ac = slot & 1;
+    const uint16_t invS = (uint16_t)jentry(false, ac, 16, 0), invW = (uint16_t)jentry(true, ac, 16, 0);
+    for (int i = 0; i < 512; ++i) { t->S.lut[slot][i] = invS; t->W.lut[slot][i] = invW; }
     memcpy(t->vals[slot], vals, 256);
     int code = 0, p = 0;
     for (int l = 1; l <= 16; ++l) {
         t->valoff[slot][l] = p - code;
-        for (int k = 0; k < bits[l]; ++k, ++p, ++code)
+        for (int k = 0; k < bits[l]; ++k, ++p, ++code) {
+            const int sym = vals[p & 255];
+            const uint16_t eS = (uint16_t)jentry(false, ac, l, sym), eW = (uint16_t)jentry(true, ac, l, sym);
             if (l <= 9) {
                 const int lo = code << (9 - l);
-                for (int f = 0; f < (1 << (9 - l)) && lo + f < 512; ++f) t->lut[slot][lo + f] = (uint16_t)((l << 8) | vals[p & 255]);
+                for (int f = 0; f < (1 << (9 - l)) && lo + f < 512; ++f) { t->S.lut[slot][lo + f] = eS; t->W.lut[slot][lo + f] = eW; }
+                continue;
             }
+            const int pre = code >> (l - 9);
+            if (pre >= 512) continue;                            // an over-subscribed (invalid) table: no bit pattern reaches this code
+            uint16_t head = t->S.lut[slot][pre];
+            if (!(head & 0x8000u)) {                             // the first long code under this prefix: a second-level table, if one is left
+                head = 0xFFFFu;
+                if (*nsub < JNSUB) {
+                    head = (uint16_t)(0x8000u | (unsigned)*nsub);
+                    for (int f = 0; f < 128; ++f) { t->S.sub[*nsub][f] = invS; t->W.sub[*nsub][f] = invW; }
+                    ++*nsub;
+                }
+                t->S.lut[slot][pre] = t->W.lut[slot][pre] = head;
+            }
+            if (head != 0xFFFFu) {
+                const int n = head & 0x7FFF, lo = (code & ((1 << (l - 9)) - 1)) << (16 - l);
+                for (int f = 0; f < (1 << (16 - l)); ++f) { t->S.sub[n][lo + f] = eS; t->W.sub[n][lo + f] = eW; }
+            }
+        }
         t->maxcode[slot][l] = bits[l] ? code - 1 : -1;
         code <<= 1;
     }
     t->maxcode[slot][0] = -1; t->maxcode[slot][17] = 0x7fffffff;
     t->valoff[slot][0] = t->valoff[slot][17] = 0;
+}
+
+// all tables of one image; components that name the same Huffman table share its second-level tables
+static void jbuild_tables(jpeg_tab *t, const jhost &j)
+{
+    int nsub = 0;
+    for (int f = 0; f < JNSUB; ++f) { memset(t->S.sub[f], 0, sizeof t->S.sub[f]); memset(t->W.sub[f], 0, sizeof t->W.sub[f]); }
+    for (int cc = 0; cc < 3; ++cc) {
+        const int cs = cc < j.ncomp ? cc : 0;
+        for (int ac = 0; ac < 2; ++ac) {
+            const int slot = 2 * cc + ac, th = ac ? j.ta[cs] : j.td[cs];
+            int same = -1;
+            for (int pc = 0; pc < cc && same < 0; ++pc) { const int ps = pc < j.ncomp ? pc : 0; if ((ac ? j.ta[ps] : j.td[ps]) == th) same = 2 * pc + ac; }
+            if (same < 0) { jbuild_slot(t, slot, j.bits[ac][th], j.vals[ac][th], &nsub); continue; }
+            memcpy(t->S.lut[slot], t->S.lut[same], sizeof t->S.lut[slot]); memcpy(t->W.lut[slot], t->W.lut[same], sizeof t->W.lut[slot]);
+            memcpy(t->maxcode[slot], t->maxcode[same], sizeof t->maxcode[slot]); memcpy(t->valoff[slot], t->valoff[same], sizeof t->valoff[slot]);
+            memcpy(t->vals[slot], t->vals[same], 256);
+        }
+        memcpy(t->q[cc], j.q[j.tq[cs]], 128);
+    }
+}
+
+// Entropy segment -> staging buffer without its byte stuffing: FF00 -> FF; RSTn markers (streams with a restart interval) are taken
+// out and the offsets behind them listed; any other marker ends the data (libjpeg stops reading there too).  memchr + memcpy of the
+// runs between the FFs (one FF per ~256 bytes of entropy-coded data).  Returns the destuffed length; *nrst > maxr: too many markers.
+static size_t jdestuff(uint8_t *dst, const uint8_t *src, size_t n, bool restarts, uint32_t *rst, uint32_t maxr, uint32_t *nrst)
+{
+    size_t o = 0;
+    *nrst = 0;
+    while (n) {
+        const uint8_t *f = (const uint8_t *)memchr(src, 0xFF, n);
+        if (!f) { memcpy(dst + o, src, n); o += n; break; }
+        const size_t run = (size_t)(f - src);
+        memcpy(dst + o, src, run); o += run; src = f; n -= run;
+        if (n < 2) { dst[o++] = 0xFF; break; }                  // an FF in front of the zero padding counts as a stuffed one
+        const uint8_t nx = src[1];
+        if (nx == 0) dst[o++] = 0xFF;
+        else if (restarts && (nx & 0xF8u) == 0xD0u) { if (*nrst < maxr) rst[*nrst] = (uint32_t)o; ++*nrst; }
+        else break;
+        src += 2; n -= 2;
+    }
+    return o;
 }
 
 static jpeg_geom jgeom(const jhost &j)
@@ -829,9 +920,9 @@ static size_t jup(size_t v, size_t a) { return (v + a - 1) / a * a; }
 struct jstage {
     void *host; size_t host_bytes;          // pinned
     void *dev; size_t dev_bytes;            // device copy of the slot
-    size_t stage_bytes, tab_bytes;
+    size_t stage_bytes, tab_bytes, rst_bytes;
     jpeg_geom g;
-    int batch, nch_max, valid;
+    int batch, nch_max, valid, restarts;     // restarts: some stream has a restart interval (the RST instantiation of the decoder passes)
     hipEvent_t copied;                      // H2D of this slot complete
     char err[256];                          // last staging error of THIS slot: ofk_jpeg_stage may run on a helper thread while the owner
                                             // thread writes the context's message (ofk_jpeg_stage_error reads this one)
@@ -916,7 +1007,6 @@ static int jstage_fill(ofk_ctx *c, int slot, const uint8_t *const *jpeg, const s
     jhost *jh = (jhost *)malloc(sizeof(jhost) * (size_t)batch);
     if (!jh) return fail(OFK_E_INVALID, "ofk_jpeg: out of host memory");
     size_t ent_total = 0;
-    int nch_max = 1;
     for (int b = 0; b < batch; ++b) {
         const char *err = jparse(jpeg[b], nbytes[b], &jh[b]);
         if (err) { const int rc = fail(OFK_E_INVALID, "ofk_jpeg: stream %d: %s", b, err); free(jh); return rc; }
@@ -931,13 +1021,13 @@ static int jstage_fill(ofk_ctx *c, int slot, const uint8_t *const *jpeg, const s
     g.jch = JCH;
     while (g.jch > JCH_MIN && ent_total / (size_t)g.jch < 131072) g.jch >>= 1;   // keep >= 128 k decoder threads if the data allows
     if (g_ofk_tuning.jpeg_chunk) g.jch = g_ofk_tuning.jpeg_chunk;   // ofk_set_tuning("jpeg_chunk")
-    for (int b = 0; b < batch; ++b) {
-        const int nch = (int)((jh[b].ent_len + JB0) / (size_t)g.jch) + 1;
-        if (nch > nch_max) nch_max = nch;
-    }
-    // pinned staging: tables + entropy segments, one H2D copy
-    const size_t tab_bytes = jup(sizeof(jpeg_tab) * (size_t)batch, 256);
-    const size_t stage = tab_bytes + ent_total;
+    // restart boundaries: at most one in front of every interval but the first
+    uint32_t maxr = 0;
+    for (int b = 0; b < batch; ++b)
+        if (jh[b].ri > 0) { const uint32_t iv = (uint32_t)((g.mcux * g.mcuy + jh[b].ri - 1) / jh[b].ri); if (iv > maxr) maxr = iv; }
+    // pinned staging: tables, restart boundaries, entropy segments - one H2D copy
+    const size_t tab_bytes = jup(sizeof(jpeg_tab) * (size_t)batch, 256), rst_bytes = jup((size_t)maxr * 4 * (size_t)batch, 256);
+    const size_t stage = tab_bytes + rst_bytes + ent_total;
     if (J.copied) (void)hipEventSynchronize(J.copied);           // the slot's previous transfer has left the pinned buffer
     if (J.host_bytes < stage) {
         if (J.host) { hipHostFree(J.host); J.host = nullptr; J.host_bytes = 0; }
@@ -950,27 +1040,26 @@ static int jstage_fill(ofk_ctx *c, int slot, const uint8_t *const *jpeg, const s
         J.dev_bytes = jup(stage, 1 << 20);
     }
     jpeg_tab *ht = (jpeg_tab *)J.host;
-    uint8_t *hent = (uint8_t *)J.host + tab_bytes;
-    // tables and entropy segments into the staging buffer: a plain copy of ~0.4 MB per 1080p frame, spread over a few host threads
-    // (one thread moves ~10 GB/s, which would make this copy the slowest stage of the ingest)
+    uint32_t *hrst = (uint32_t *)((uint8_t *)J.host + tab_bytes);
+    uint8_t *hent = (uint8_t *)J.host + tab_bytes + rst_bytes;
+    // tables and entropy segments into the staging buffer: ~0.4 MB per 1080p frame, destuffed on the way (jdestuff), spread over a
+    // few host threads (one thread moves ~10 GB/s, which would make this copy the slowest stage of the ingest)
     size_t *eoff = (size_t *)malloc(sizeof(size_t) * (size_t)batch);
     if (!eoff) { free(jh); return fail(OFK_E_INVALID, "ofk_jpeg: out of host memory"); }
     size_t eo = 0;
     for (int b = 0; b < batch; ++b) { eoff[b] = eo; eo += JPAD(jh[b].ent_len); }
+    std::atomic<int> bad_rst(-1);
     auto stage_range = [&](int b0, int step) {
         for (int b = b0; b < batch; b += step) {
             const jhost &j = jh[b];
             jpeg_tab *t = ht + b;
-            for (int cc = 0; cc < 3; ++cc) {
-                const int cs = cc < j.ncomp ? cc : 0;
-                jbuild_slot(t, 2 * cc, j.bits[0][j.td[cs]], j.vals[0][j.td[cs]]);
-                jbuild_slot(t, 2 * cc + 1, j.bits[1][j.ta[cs]], j.vals[1][j.ta[cs]]);
-                memcpy(t->q[cc], j.q[j.tq[cs]], 128);
-            }
-            t->ent_off = (uint32_t)eoff[b]; t->ent_len = (uint32_t)j.ent_len;
-            t->nch = (int)((j.ent_len + JB0) / (size_t)g.jch) + 1; t->ri = j.ri;
-            memcpy(hent + eoff[b], j.ent, j.ent_len);
-            memset(hent + eoff[b] + j.ent_len, 0, JPAD(j.ent_len) - j.ent_len);
+            jbuild_tables(t, j);
+            t->rst_off = (uint32_t)((size_t)b * maxr);
+            const size_t len = jdestuff(hent + eoff[b], j.ent, j.ent_len, j.ri > 0, hrst + t->rst_off, maxr, &t->nrst);
+            if (t->nrst > maxr) { t->nrst = maxr; bad_rst = b; }
+            memset(hent + eoff[b] + len, 0, JPAD(j.ent_len) - len);
+            t->ent_off = (uint32_t)eoff[b]; t->ent_len = (uint32_t)len;
+            t->nch = (int)(len / (size_t)g.jch) + 1; t->ri = j.ri;
         }
     };
     unsigned nthr = std::thread::hardware_concurrency() / 2;
@@ -983,13 +1072,16 @@ static int jstage_fill(ofk_ctx *c, int slot, const uint8_t *const *jpeg, const s
         stage_range(0, (int)nthr);
         for (auto &th : pool) th.join();
     }
+    int nch_max = 1, any_rst = 0;
+    for (int b = 0; b < batch; ++b) { if (ht[b].nch > nch_max) nch_max = ht[b].nch; any_rst |= jh[b].ri > 0; }
+    if (bad_rst >= 0) { const int rc = fail(OFK_E_INVALID, "ofk_jpeg: stream %d: more restart markers than restart intervals (corrupt)", (int)bad_rst); free(eoff); free(jh); return rc; }
     free(eoff);
     free(jh);
     if (hipMemcpyAsync(J.dev, J.host, stage, hipMemcpyHostToDevice, js->copy) != hipSuccess || hipEventRecord(J.copied, js->copy) != hipSuccess) {
         (void)hipGetLastError();
         return fail(OFK_E_HIP, "ofk_jpeg: staging copy to the device failed");
     }
-    J.stage_bytes = stage; J.tab_bytes = tab_bytes; J.g = g; J.batch = batch; J.nch_max = nch_max; J.valid = 1;
+    J.stage_bytes = stage; J.tab_bytes = tab_bytes; J.rst_bytes = rst_bytes; J.g = g; J.batch = batch; J.nch_max = nch_max; J.restarts = any_rst; J.valid = 1;
     return OFK_OK;
 }
 
@@ -1029,7 +1121,10 @@ static int jdecode_staged(ofk_ctx *c, int slot, uint8_t *dst, uint8_t *dst2, int
     if (out) *out = dst;
     if (out_stride) *out_stride = dst_stride;
     const jpeg_tab *dt = (const jpeg_tab *)J.dev;
-    const uint8_t *dent = (const uint8_t *)J.dev + J.tab_bytes;
+    const uint32_t *drst = (const uint32_t *)((const uint8_t *)J.dev + J.tab_bytes);
+    const uint8_t *dent = (const uint8_t *)J.dev + J.tab_bytes + J.rst_bytes;
+    auto sync_pass = J.restarts ? k_jpeg_sync<true> : k_jpeg_sync<false>;
+    auto write_pass = J.restarts ? k_jpeg_write<true> : k_jpeg_write<false>;
     unsigned long long *state = (unsigned long long *)(S + o_state), *used = (unsigned long long *)(S + o_used);
     int *count = (int *)(S + o_count), *base = (int *)(S + o_base), *flags = (int *)(S + o_flags), *endinfo = flags + JMAX_ITERS;
     int16_t *coef = (int16_t *)(S + o_coef), *dcarr = coef + B * g.nblk * 64;     // coefficient blocks, then the dense DC array
@@ -1050,7 +1145,7 @@ static int jdecode_staged(ofk_ctx *c, int slot, uint8_t *dst, uint8_t *dst2, int
     TRY_J(jhmap(c, js, JMAX_ITERS + 2 * B));
     volatile int *hflags = js->hmap;
     int iter = 0;
-    hipLaunchKernelGGL(k_jpeg_sync, dgrid, dim3(JTPB), 0, st, dt, dent, g, nch_max, state, used, count, iter, flags);
+    hipLaunchKernelGGL(sync_pass, dgrid, dim3(JTPB), 0, st, dt, dent, drst, g, nch_max, state, used, count, iter, flags);
     bool converged = nch_max == 1;
     while (!converged) {
         const int first = iter + 1;
@@ -1060,7 +1155,7 @@ static int jdecode_staged(ofk_ctx *c, int slot, uint8_t *dst, uint8_t *dst2, int
         for (int k = 0; k < burst; ++k) {
             ++iter;
             if (iter >= JMAX_ITERS) OFK_HIP(c, hipMemsetAsync(flags + JMAX_ITERS - 1, 0, 4, st));
-            hipLaunchKernelGGL(k_jpeg_sync, dgrid, dim3(JTPB), 0, st, dt, dent, g, nch_max, state, used, count, iter, flags);
+            hipLaunchKernelGGL(sync_pass, dgrid, dim3(JTPB), 0, st, dt, dent, drst, g, nch_max, state, used, count, iter, flags);
         }
         hipLaunchKernelGGL(k_jpeg_ints_to_host, dim3(1), dim3(64), 0, st, flags, js->hmap_dev, JMAX_ITERS);
         OFK_HIP(c, hipStreamSynchronize(st));
@@ -1070,7 +1165,7 @@ static int jdecode_staged(ofk_ctx *c, int slot, uint8_t *dst, uint8_t *dst2, int
     }
     hipLaunchKernelGGL(k_jpeg_scan, dim3(batch), dim3(1024), 0, st, dt, nch_max, count, base);
     OFK_HIP(c, hipStreamWaitEvent(st, js->zeroed, 0));
-    hipLaunchKernelGGL(k_jpeg_write, dim3((nch_max + JTPW - 1) / JTPW, batch), dim3(JTPW), 0, st, dt, dent, g, nch_max, state, base, coef, dcarr, endinfo);
+    hipLaunchKernelGGL(write_pass, dim3((nch_max + JTPW - 1) / JTPW, batch), dim3(JTPW), 0, st, dt, dent, drst, g, nch_max, state, base, coef, dcarr, endinfo);
     hipLaunchKernelGGL(k_jpeg_dc, dim3(batch, g.ncomp), dim3(1024), 0, st, dt, g, dcarr);
     hipLaunchKernelGGL(k_jpeg_idct, dim3(g.mcuy, batch), dim3(256), 0, st, dt, g, coef, dcarr, planes, (unsigned)(((1u << 20) + g.bpm - 1) / g.bpm));
     hipLaunchKernelGGL(k_jpeg_color, dim3((g.w + 511) / 512, (g.h + 3) / 4, batch), dim3(64, 4), 0, st, g, planes, dst, dst2, split, dst_stride, as_gray);

@@ -63,7 +63,7 @@ static int *tuning_slot(const char *knob, int *lo, int *hi)
         {"no_pyr3", &g_ofk_tuning.no_pyr3, 0, 1},             // 1: pyramid level by level instead of the three-level pass
         {"pyr3_chunks", &g_ofk_tuning.pyr3_chunks, 1, 4096},  // row chunks per strip of k_pyr3_stream
         {"pyr_rows", &g_ofk_tuning.pyr_rows, 1, 4096},        // rows per strip of k_pyr_down_stream
-        {"jpeg_chunk", &g_ofk_tuning.jpeg_chunk, 64, 256},    // bytes of entropy data per decoder thread (64, 128, 256)
+        {"jpeg_chunk", &g_ofk_tuning.jpeg_chunk, 64, 1024},   // bytes of entropy data per decoder thread (a power of two)
         {"gray_px", &g_ofk_tuning.gray_px, 16, 64},           // experiment: one-wave workgroups of 16 / 32 / 64 pixels per thread in the BGR -> gray conversion
     };
     for (auto &t : tab)
@@ -76,7 +76,7 @@ extern "C" int ofk_set_tuning(const char *knob, int value)
     int lo, hi;
     int *slot = tuning_slot(knob, &lo, &hi);
     if (!slot) return ofk_fail(nullptr, OFK_E_INVALID, "ofk_set_tuning: unknown knob '%s'", knob ? knob : "(null)");
-    const bool jpeg_ok = slot != &g_ofk_tuning.jpeg_chunk || value == 64 || value == 128 || value == 256;
+    const bool jpeg_ok = slot != &g_ofk_tuning.jpeg_chunk || (value & (value - 1)) == 0;
     if (value != 0 && (value < lo || value > hi || !jpeg_ok)) return ofk_fail(nullptr, OFK_E_INVALID, "ofk_set_tuning: %s takes 0 (default) or %d..%d", knob, lo, hi);
     *slot = value;
     return OFK_OK;
