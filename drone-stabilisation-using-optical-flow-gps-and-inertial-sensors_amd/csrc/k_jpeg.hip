@@ -103,6 +103,7 @@ struct jrd {
         n0 = jld(d, at + 8); n1 = jld(d, at + 12); nx = at + 16;
     }
     __device__ uint32_t pos() const { return (nx - 16u) * 8u + (uint32_t)c; }
+    static constexpr bool uniform = false;
     __device__ bool refill() { return true; }
     __device__ uint32_t top() const { return (uint32_t)((((uint64_t)hi << 32 | lo) << c) >> 32); }
     __device__ void advance(int tot)
@@ -144,6 +145,7 @@ struct jring {
         in = *reinterpret_cast<const uint4 *>(d + fill);
     }
     __device__ uint32_t pos() const { return bp; }
+    static constexpr bool uniform = true;
     // every JREFILL steps: true = the lane can decode JREFILL symbols (< 4 bytes each) without looking at its ring's fill level
     __device__ bool refill()
     {
@@ -210,14 +212,17 @@ __device__ inline int jrun(const jfast &T, const jpeg_tab *t, const uint32_t *__
         ridx = lo;
         if (ridx < nrst) rl = (int)(rst[ridx] * 8u - bp0);
     }
-    // The loop is the WAVE's: every lane stays until the last one is done (a finished or stalled lane skips the body), so that the
-    // reader's refill points are the same for all lanes: JREFILL symbol steps, refill, ...
+    // Ring reader (Reader::uniform): the loop is the WAVE's - every lane stays until the last one is done (a finished or stalled
+    // lane skips the body), so that the refill points are the same for all lanes: JREFILL symbol steps, refill, ...
     for (;;) {
-        if (!__any(rem > 0 && (!WRITE || done < max_blocks))) break;
-        const bool go = r.refill();
+        bool go = true;
+        if (Reader::uniform) {
+            if (!__any(rem > 0 && (!WRITE || done < max_blocks))) break;
+            go = r.refill();
+        } else if (!(rem > 0 && (!WRITE || done < max_blocks))) break;
 #pragma unroll 1
-        for (int u = 0; u < JREFILL; ++u) {
-            if (!(go && rem > 0 && (!WRITE || done < max_blocks))) continue;
+        for (int u = 0; u < (Reader::uniform ? JREFILL : 1); ++u) {
+            if (Reader::uniform && !(go && rem > 0 && (!WRITE || done < max_blocks))) continue;
             const uint32_t top = r.top();
             uint32_t e = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(lut) + sb + (r.k ? 1024 : 0) + ((top >> 22) & 0x3FEu));
             if (e & 0x8000u) {
@@ -344,8 +349,10 @@ __global__ __launch_bounds__(1024) void k_jpeg_scan(const jpeg_tab *__restrict__
 // The few coefficients behind position JROW_K (the high-frequency half: a few per cent at camera qualities) go straight to the
 // zeroed coefficient buffer.  A block that straddles a chunk boundary is shared with the neighbouring thread: its parts are
 // scattered element-wise onto the zeroed background instead.
+#ifndef JROW_K
 #define JROW_K 32
-#define JBLK_PITCH (JROW_K + 2)                                   // int16 per LDS row: an odd number of dwords spreads the lanes over the banks
+#endif
+#define JBLK_PITCH (JROW_K + 8)                                   // int16 per LDS row: 16-byte aligned (the row moves as b128 reads / writes), 4 dwords of padding spread the lanes over the banks
 struct jemit_store {
     int16_t *row;                                                 // this thread's LDS row (zigzag order, zero between blocks)
     int16_t *out; int n0, nblk; bool head_partial;
@@ -364,12 +371,12 @@ struct jemit_store {
     // A complete block is read out of the row at once (the row is needed for the next block) but stored when the thread's NEXT
     // block is complete: the store then finds its data long arrived, where waiting for the LDS reads in place put their latency
     // into the dependency chain of almost every step (some lane of a wave completes a block in almost every step): 1.81 -> x ms
-    uint4 pend[JROW_K / 8]; uint4 *pend_dst;
+    uint32_t pend[JROW_K / 2]; uint4 *pend_dst;                   // (scalars: a uint4 member sends the whole struct to the stack)
     __device__ void drain()
     {
         if (!pend_dst) return;
 #pragma unroll
-        for (int q = 0; q < JROW_K / 8; ++q) pend_dst[q] = pend[q];
+        for (int q = 0; q < JROW_K / 8; ++q) pend_dst[q] = make_uint4(pend[4 * q], pend[4 * q + 1], pend[4 * q + 2], pend[4 * q + 3]);
         pend_dst = nullptr;
     }
     __device__ void block(int done)
@@ -379,12 +386,13 @@ struct jemit_store {
         if (n >= nblk) return;
         if (done == 0 && head_partial) { scatter(n); return; }
         drain();
-        uint32_t *src = (uint32_t *)row;
+        uint4 *src = reinterpret_cast<uint4 *>(row);
         pend_dst = (uint4 *)(out + (size_t)n * 64);
 #pragma unroll
         for (int q = 0; q < JROW_K / 8; ++q) {
-            pend[q] = make_uint4(src[4 * q], src[4 * q + 1], src[4 * q + 2], src[4 * q + 3]);
-            src[4 * q] = src[4 * q + 1] = src[4 * q + 2] = src[4 * q + 3] = 0;
+            const uint4 v = src[q];
+            pend[4 * q] = v.x; pend[4 * q + 1] = v.y; pend[4 * q + 2] = v.z; pend[4 * q + 3] = v.w;
+            src[q] = make_uint4(0, 0, 0, 0);
         }
     }
 };
@@ -395,7 +403,7 @@ __global__ __launch_bounds__(JTPW) void k_jpeg_write(const jpeg_tab *__restrict_
                                                      int16_t *__restrict__ coef, int16_t *__restrict__ dcarr, int *__restrict__ endinfo)
 {
     __shared__ jfast T;
-    __shared__ int16_t rows[JTPW][JBLK_PITCH];
+    __shared__ __attribute__((aligned(16))) int16_t rows[JTPW][JBLK_PITCH];
     const int b = blockIdx.y;
     const jpeg_tab *t = tabs + b;
     if ((int)(blockIdx.x * JTPW) >= t->nch) return;
@@ -420,6 +428,27 @@ __global__ __launch_bounds__(JTPW) void k_jpeg_write(const jpeg_tab *__restrict_
         endinfo[b * 2] = (int)((r.pos() + 7u) >> 3);
         endinfo[b * 2 + 1] = 1;
     }
+}
+
+// The write pass stores the first JROW_K zigzag positions of every block it completes as one 64-byte row and drops the few
+// coefficients behind them onto a zero background: what has to be zero beforehand is the UPPER half of every block (k_jpeg_zero_upper,
+// half the bytes of a plain fill, beside the synchronisation passes) and the lower half of the blocks that straddle a chunk boundary,
+// whose parts two threads scatter element-wise (k_jpeg_zero_heads, a few thousand rows per image, between the scan and the write pass).
+__global__ __launch_bounds__(256) void k_jpeg_zero_upper(uint4 *__restrict__ coef, size_t nblocks)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nblocks * 4; i += stride) coef[(i >> 2) * 8 + 4 + (i & 3)] = make_uint4(0, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(256) void k_jpeg_zero_heads(const jpeg_tab *__restrict__ tabs, jpeg_geom g, int nch_max, const unsigned long long *__restrict__ state,
+                                                         const int *__restrict__ base, int16_t *__restrict__ coef)
+{
+    const int b = blockIdx.y, i = blockIdx.x * 64 + (threadIdx.x >> 2);
+    if (i < 1 || i >= tabs[b].nch) return;
+    if (((state[(size_t)b * nch_max + i - 1] >> 8) & 63) == 0) return;        // a block starts with the chunk
+    const int n = base[(size_t)b * (nch_max + 1) + i];
+    if (n >= g.nblk) return;
+    reinterpret_cast<uint4 *>(coef + ((size_t)b * g.nblk + n) * 64)[threadIdx.x & 3] = make_uint4(0, 0, 0, 0);
 }
 
 // DC prediction: inclusive prefix sum of the DC differences of one component in decode order (one workgroup per image x component),
@@ -575,7 +604,7 @@ __global__ __launch_bounds__(256) void k_jpeg_idct(const jpeg_tab *__restrict__ 
 #pragma unroll
             for (int r = 0; r < 8; ++r) ws[lb][r * 9 + c] = (o[r] + (1 << 10)) >> 11;
         }
-        __syncthreads();
+        __syncthreads();                                           // (a wave-level fence would do - the eight lanes of a block are lanes of one wave - and measured 6 % slower)
         if (live) {
             int in[8], o[8];
 #pragma unroll
@@ -1134,11 +1163,12 @@ static int jdecode_staged(ofk_ctx *c, int slot, uint8_t *dst, uint8_t *dst2, int
     hipStream_t st = own_stream ? js->dec : c->stream;
     for (int k = 0; wait_ev && k < nwait; ++k) if (wait_ev[k]) OFK_HIP(c, hipStreamWaitEvent(st, wait_ev[k], 0));
     OFK_HIP(c, hipMemsetAsync(flags, 0, JMAX_ITERS * 4 + B * 8, st));
-    // 3.3 GB per 1024 frames of 1080p: on a stream of its own from here (the scratch is free: everything before is behind st) until the
+    // 1.65 GB per 1024 frames of 1080p (the upper halves of the coefficient blocks): on a stream of its own from here (the scratch is free: everything before is behind st) until the
     // write pass, which is the first to touch the coefficients - the fill runs beside the synchronisation passes, which leave HBM idle
     OFK_HIP(c, hipEventRecord(js->zero_go, st));
     OFK_HIP(c, hipStreamWaitEvent(js->zero, js->zero_go, 0));
-    OFK_HIP(c, hipMemsetAsync(coef, 0, B * g.nblk * 130, js->zero));
+    hipLaunchKernelGGL(k_jpeg_zero_upper, dim3(8192), dim3(256), 0, js->zero, (uint4 *)coef, B * g.nblk);
+    OFK_HIP(c, hipMemsetAsync(dcarr, 0, B * g.nblk * 2, js->zero));
     OFK_HIP(c, hipEventRecord(js->zeroed, js->zero));
     OFK_HIP(c, hipStreamWaitEvent(st, J.copied, 0));             // tables and entropy data are on the device from here on
     const dim3 dgrid((nch_max + JTPB - 1) / JTPB, batch);
@@ -1165,6 +1195,7 @@ static int jdecode_staged(ofk_ctx *c, int slot, uint8_t *dst, uint8_t *dst2, int
     }
     hipLaunchKernelGGL(k_jpeg_scan, dim3(batch), dim3(1024), 0, st, dt, nch_max, count, base);
     OFK_HIP(c, hipStreamWaitEvent(st, js->zeroed, 0));
+    hipLaunchKernelGGL(k_jpeg_zero_heads, dim3((nch_max + 63) / 64, batch), dim3(256), 0, st, dt, g, nch_max, state, base, coef);
     hipLaunchKernelGGL(write_pass, dim3((nch_max + JTPW - 1) / JTPW, batch), dim3(JTPW), 0, st, dt, dent, drst, g, nch_max, state, base, coef, dcarr, endinfo);
     hipLaunchKernelGGL(k_jpeg_dc, dim3(batch, g.ncomp), dim3(1024), 0, st, dt, g, dcarr);
     hipLaunchKernelGGL(k_jpeg_idct, dim3(g.mcuy, batch), dim3(256), 0, st, dt, g, coef, dcarr, planes, (unsigned)(((1u << 20) + g.bpm - 1) / g.bpm));

@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 for c in $CH; do
   rm -rf $O/jc_$c
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/jc_$c -- python3 $R/tools/bench_jpeg.py --batch $B --reps 3 --chunk $c > $O/jc_$c.log 2>&1 || { tail -5 $O/jc_$c.log; exit 1; }
-  echo "== chunk $c"; tail -1 $O/jc_$c.log | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print({k: d[k] for k in ('jpeg_upload_ms_per_call','decode_ms_per_call','jpeg_double_buffered_ms_per_call','matches_oracle')})"
+  echo "== chunk $c"; grep matches_oracle $O/jc_$c.log | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print({k: d[k] for k in ('jpeg_upload_ms_per_call','decode_ms_per_call','jpeg_double_buffered_ms_per_call','matches_oracle')})"
   python3 - <<PY
 import csv, glob
 f = glob.glob("$O/jc_$c/**/*kernel_stats.csv", recursive=True)[0]

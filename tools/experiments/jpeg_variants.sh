@@ -8,7 +8,7 @@ for lib in $R/build_variants/libofk_*.so; do
   cp $lib $PKG/libofk.so
   rm -rf $O/jv_$name
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/jv_$name -- python3 $R/tools/bench_jpeg.py --batch $B --reps 3 > $O/jv_$name.log 2>&1 || { tail -5 $O/jv_$name.log; exit 1; }
-  echo "== $name"; tail -1 $O/jv_$name.log | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print({k: d[k] for k in ('jpeg_upload_ms_per_call','decode_ms_per_call','jpeg_double_buffered_ms_per_call','matches_oracle')})"
+  echo "== $name"; grep matches_oracle $O/jv_$name.log | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print({k: d[k] for k in ('jpeg_upload_ms_per_call','decode_ms_per_call','jpeg_double_buffered_ms_per_call','matches_oracle')})"
   python3 - <<PY
 import csv, glob
 f = glob.glob("$O/jv_$name/**/*kernel_stats.csv", recursive=True)[0]
