@@ -1,29 +1,31 @@
 // k_jpeg.hip — baseline JPEG -> BGR8 on the device: the ingest in front of the hot path (the reference decodes
 // every sensor_msgs/CompressedImage with cv_bridge.compressed_imgmsg_to_cv2 = cv::imdecode = libjpeg,
 // velocity_measurment_node.py:112).  Output is bit-identical to libjpeg's default decompressor (ISLOW integer IDCT, "fancy"
-// triangle chroma upsampling, 16-bit fixed-point YCbCr->RGB).  The host only parses the marker segments and packs the tables;
-// entropy decoding, IDCT, upsampling and colour conversion run on the GPU.
+// triangle chroma upsampling, 16-bit fixed-point YCbCr->RGB).  The host parses the marker segments, packs the tables and takes the
+// byte stuffing out of the entropy segments while it copies them (jdestuff: memchr + memcpy); entropy decoding, IDCT, upsampling
+// and colour conversion run on the GPU.
 //
 // Huffman decoding is a serial bit-by-bit process per image.  It is parallelised by *self-synchronisation* (Klein & Wiseman 2003;
 // Weissenberger & Schmidt, "Massively parallel Huffman decoding on GPUs", ICPP 2018, and their 2021 JPEG follow-up): the entropy
-// segment is cut into chunks of JCH bytes, one decoder thread per chunk.  A decoder that starts at a wrong bit position / block
+// segment is cut into chunks of `jch` bytes, one decoder thread per chunk.  A decoder that starts at a wrong bit position / block
 // position produces garbage for a while but, because Huffman codes are prefix codes, falls into step with the true symbol sequence
 // after a few dozen symbols with overwhelming probability.
 //   1. k_jpeg_sync, iteration 0: every thread decodes its chunk from a guessed state (chunk start, block start) and publishes the
 //      state in which it crossed into the next chunk; iteration n > 0: every thread whose predecessor published a different state
 //      than the one it started from last time decodes its chunk again from that state.  Chunk 0 starts from the true state, so the
-//      truth advances at least one chunk per iteration; in practice all chunks agree after two iterations.  An iteration in which
-//      no thread changed its published state is a fixed point, and a fixed point that starts from the true state is the true
-//      decode (induction over the chunks) — the result never depends on the probabilistic argument, only the run time does.
+//      truth advances at least one chunk per iteration; in practice half of the chunks agree after two iterations and the rest
+//      after four to six.  An iteration in which no thread changed its published state is a fixed point, and a fixed point that
+//      starts from the true state is the true decode (induction over the chunks) — the result never depends on the probabilistic
+//      argument, only the run time does.
 //   2. k_jpeg_scan: exclusive prefix sum of the blocks completed per chunk = index of the block a chunk starts in.
-//   3. k_jpeg_write: every thread decodes its chunk once more from its (now true) entry state and stores the coefficients.
+//   3. k_jpeg_write: every thread decodes its chunk once more from its (now true) entry state and stores the coefficients
+//      (k_jpeg_zero_upper / k_jpeg_zero_heads prepare the background it relies on).
 //   4. k_jpeg_dc: DC prediction = prefix sum of the DC differences per component in decode order.
 //   5. k_jpeg_idct: dequantisation + ISLOW IDCT, 8 lanes per block (columns, then rows through LDS) -> component planes.
-//   6. k_jpeg_color: fancy upsampling + colour conversion -> BGR8.
-// The decoder state at a symbol boundary is (byte cursor, bits left in the buffer, zigzag index, block-in-MCU); it is canonical —
-// a function of the true bit position only — because the bit buffer is refilled byte by byte to 32..39 bits before every symbol
-// (enough for the longest code plus the longest run of extra bits), so two decoders that agree on a symbol boundary agree on
-// the whole state.  Restart markers (RSTn) are handled inside the same scheme, see jrefill / jrun.
+//   6. k_jpeg_color: fancy upsampling + colour conversion -> BGR8 (or straight to gray for the pipeline).
+// The decoder state at a symbol boundary is (bit position in the destuffed segment, zigzag index, block-in-MCU): a function of
+// the true bit position only, so two decoders that agree on a symbol boundary agree on everything that follows.  A symbol belongs
+// to the chunk its first bit lies in.  Restart markers are taken out by the host and listed as boundaries, see jrun.
 #include "ofk_internal.h"
 #include <string.h>
 #include <stdlib.h>
@@ -344,14 +346,12 @@ __global__ __launch_bounds__(1024) void k_jpeg_scan(const jpeg_tab *__restrict__
 
 // Coefficients of the block in progress are collected in the thread's LDS row and leave as one wide store when the block is
 // complete (2-byte stores scattered over HBM - partial-line writes - made this kernel 3x slower than the counting pass).  The row
-// holds the first JROW_K zigzag positions only: the pass is bound by the latency of its per-symbol dependency chain, so its speed
-// is its occupancy, and a row of all 64 positions (33 KB of LDS per 256 threads) allowed 3 waves per SIMD, 32 positions allow 6.
-// The few coefficients behind position JROW_K (the high-frequency half: a few per cent at camera qualities) go straight to the
-// zeroed coefficient buffer.  A block that straddles a chunk boundary is shared with the neighbouring thread: its parts are
+// holds the first JROW_K zigzag positions only: a row of all 64 positions (37 KB of LDS per 256 threads) allows 3 waves per SIMD,
+// 32 positions allow 5.  The coefficients behind position JROW_K (the high-frequency half: a few per cent at camera qualities) go
+// straight to the zeroed coefficient buffer - scattered 2-byte stores, which is why shorter rows lose: 1.82 ms per 512 frames with
+// 32 positions, 2.38 with 16, 3.59 with 8 (profiles/r04_exp_jpeg_rows.txt).  A block that straddles a chunk boundary is shared with the neighbouring thread: its parts are
 // scattered element-wise onto the zeroed background instead.
-#ifndef JROW_K
 #define JROW_K 32
-#endif
 #define JBLK_PITCH (JROW_K + 8)                                   // int16 per LDS row: 16-byte aligned (the row moves as b128 reads / writes), 4 dwords of padding spread the lanes over the banks
 struct jemit_store {
     int16_t *row;                                                 // this thread's LDS row (zigzag order, zero between blocks)
@@ -847,7 +847,7 @@ static void jbuild_slot(jpeg_tab *t, int slot, const uint8_t *bits, const uint8_
             uint16_t head = t->S.lut[slot][pre];
             if (!(head & 0x8000u)) {                             // the first long code under this prefix: a second-level table, if one is left
                 head = 0xFFFFu;
-                if (*nsub < JNSUB) {
+                if (*nsub < (g_ofk_tuning.jpeg_sub ? g_ofk_tuning.jpeg_sub - 1 : JNSUB)) {     // ofk_set_tuning("jpeg_sub")
                     head = (uint16_t)(0x8000u | (unsigned)*nsub);
                     for (int f = 0; f < 128; ++f) { t->S.sub[*nsub][f] = invS; t->W.sub[*nsub][f] = invW; }
                     ++*nsub;

@@ -64,6 +64,7 @@ static int *tuning_slot(const char *knob, int *lo, int *hi)
         {"pyr3_chunks", &g_ofk_tuning.pyr3_chunks, 1, 4096},  // row chunks per strip of k_pyr3_stream
         {"pyr_rows", &g_ofk_tuning.pyr_rows, 1, 4096},        // rows per strip of k_pyr_down_stream
         {"jpeg_chunk", &g_ofk_tuning.jpeg_chunk, 64, 1024},   // bytes of entropy data per decoder thread (a power of two)
+        {"jpeg_sub", &g_ofk_tuning.jpeg_sub, 1, 13},          // second-level Huffman look-up tables per image + 1 (1: none - every long code takes the canonical search)
         {"gray_px", &g_ofk_tuning.gray_px, 16, 64},           // experiment: one-wave workgroups of 16 / 32 / 64 pixels per thread in the BGR -> gray conversion
     };
     for (auto &t : tab)

@@ -88,7 +88,7 @@ struct ofk_ctx {
 };
 
 // Launch-geometry knobs of ofk_set_tuning (ofk.h): process-wide, 0 = the built-in choice.  Results never depend on them.
-struct ofk_tuning { int eig_rows, no_pair, no_pyr3, pyr3_chunks, pyr_rows, jpeg_chunk, gray_px; };
+struct ofk_tuning { int eig_rows, no_pair, no_pyr3, pyr3_chunks, pyr_rows, jpeg_chunk, gray_px, jpeg_sub; };
 extern ofk_tuning g_ofk_tuning;
 
 // --- helpers (host)

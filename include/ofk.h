@@ -420,8 +420,9 @@ int ofk_set_overlap(ofk_ctx *ctx, int on);
  * every setting - the knobs move strip lengths and pick between kernels that compute the same thing (tests/test_gpu_image_parity.py
  * runs the parity cases under them).  Knobs: "eig_rows" 8..4096 rows per strip of the streaming response kernels; "no_pair" 1 = one
  * column per lane (k_mineig_stream) where k_mineig_pair would run; "no_pyr3" 1 = pyramid level by level; "pyr3_chunks" row chunks per
- * strip of the three-level pyramid pass; "pyr_rows" rows per strip of the one-level pass; "jpeg_chunk" 64/128/256 bytes of entropy
- * data per decoder thread; "gray_px" 16/32/64 = the BGR -> gray conversion as one-wave workgroups of that many pixels per thread (an
+ * strip of the three-level pyramid pass; "pyr_rows" rows per strip of the one-level pass; "jpeg_chunk" 64/128/256/512/1024 bytes of entropy
+ * data per decoder thread; "jpeg_sub" 1..13 = second-level Huffman look-up tables per image + 1 (1: every code longer than 9 bits takes
+ * the canonical search - a test hook for that path); "gray_px" 16/32/64 = the BGR -> gray conversion as one-wave workgroups of that many pixels per thread (an
  * experiment of DESIGN.md section 8: slower in the pipeline).  (Rounds 1-2 read OFK_* environment variables in the launch code instead.) */
 int ofk_set_tuning(const char *knob, int value);
 int ofk_get_tuning(const char *knob, int *value);

@@ -358,6 +358,6 @@ def test_tuning_knobs_do_not_change_results(gpu_ctx, pkg, ofk):
                     assert np.array_equal(out[key], base_out[key]), (knob, v, key)
             ofk.set_tuning(knob, 0)
     finally:
-        for knob in ("no_pair", "eig_rows", "no_pyr3", "pyr3_chunks", "pyr_rows", "jpeg_chunk", "gray_px"):
+        for knob in ("no_pair", "eig_rows", "no_pyr3", "pyr3_chunks", "pyr_rows", "jpeg_chunk", "jpeg_sub", "gray_px"):
             ofk.set_tuning(knob, 0)
     pipe.close()

@@ -302,18 +302,51 @@ def test_gray_direct_ingest_state_machine(pkg, ofk):
 
 @pytest.mark.gpu
 def test_decoder_chunk_size_does_not_change_pixels(pkg, ofk, gold):
-    """ofk_set_tuning("jpeg_chunk"): 64 / 128 / 256 entropy bytes per decoder thread - other chunk boundaries, other synchronisation
-    histories, the same pixels."""
+    """ofk_set_tuning("jpeg_chunk"): 64 ... 1024 entropy bytes per decoder thread - other chunk boundaries, other synchronisation
+    histories, the same pixels.  "jpeg_sub": fewer second-level Huffman tables than the streams' tables need - the codes left over
+    take the canonical search (k_jpeg.hip jslow), the same pixels."""
     from of_amd import synth
-    streams = [_encode(synth.render_pair(480, 640, 300 + k)["prev"], 85, 2) for k in range(3)]
+    streams = [_encode(synth.render_pair(480, 640, 300 + k)["prev"], q, 2, **o) for k, (q, o) in enumerate(((85, {}), (97, {"optimize": True}), (60, {"restart_marker_rows": 2})))]
     want = [jo.decode(s) for s in streams]
     ctx = ofk.Context(0, 640, 480, 3, 64, 1)
     try:
-        for chunk in (64, 128, 256, 0):
+        for chunk in (64, 128, 256, 512, 1024, 0):
             ofk.set_tuning("jpeg_chunk", chunk)
             out = ctx.jpeg_decode(streams)
             for k in range(3):
                 assert np.array_equal(out[k], want[k]), (chunk, k)
+        for sub in (1, 3, 7, 13):
+            ofk.set_tuning("jpeg_sub", sub)
+            out = ctx.jpeg_decode(streams)
+            for k in range(3):
+                assert np.array_equal(out[k], want[k]), ("jpeg_sub", sub, k)
     finally:
         ofk.set_tuning("jpeg_chunk", 0)
+        ofk.set_tuning("jpeg_sub", 0)
+        ctx.close()
+
+
+@pytest.mark.gpu
+def test_markers_inside_the_entropy_data(pkg, ofk):
+    """The host takes byte stuffing and restart markers out of the entropy segment while it stages it (k_jpeg.hip jdestuff): a marker
+    that is neither ends the data there (libjpeg stops reading at it too), and more RSTn markers than the frame has restart
+    intervals are refused before anything is queued."""
+    from of_amd import synth
+    img = synth.render_pair(240, 320, 77)["prev"]
+    plain = _encode(img, 80, 2)
+    rst = _encode(img, 80, 2, restart_marker_rows=1)
+    ctx = ofk.Context(0, 320, 240, 2, 64, 1)
+    try:
+        assert np.array_equal(ctx.jpeg_decode([rst, plain])[0], jo.decode(rst))
+        sos = plain.index(b"\xff\xda")
+        mid = sos + (len(plain) - sos) // 2
+        while plain[mid - 1] == 0xFF or plain[mid] == 0xFF:      # not inside an FF00 pair
+            mid += 1
+        with pytest.raises(ofk.OfkError, match="truncated|corrupt"):
+            ctx.jpeg_decode([plain[:mid] + b"\xff\xe0" + plain[mid:]])
+        extra = rst[:-2] + b"\xff\xd0" * 40 + rst[-2:]            # 15 intervals, 14 markers + 40
+        with pytest.raises(ofk.OfkError, match="more restart markers"):
+            ctx.jpeg_decode([extra])
+        assert np.array_equal(ctx.jpeg_decode([plain])[0], jo.decode(plain))       # still usable
+    finally:
         ctx.close()
