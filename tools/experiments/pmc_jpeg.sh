@@ -17,7 +17,7 @@ for tag in "ab":
     seen = set()
     for f in fs:
         for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].split("(")[0]
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
             if "jpeg" not in k: continue
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
             key = (f, r["Dispatch_Id"])
@@ -43,7 +43,8 @@ for k, v in summary.items():
                          "valu_instr_per_decode": int(valu), "valu_ginstr_per_s": round(valu / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,
                          "valu_frac_of_1228.8": round(valu / (ms * 1e-3) / 1e9 / 1228.8, 4) if ms > 0 else None,
                          "wait_share_of_wave_cycles": round(v["SQ_WAIT_INST_ANY_in_run"] / max(1, v["SQ_WAVE_CYCLES_in_run"]), 3)}
-out["decoder_ms_per_512_frames"] = round(sum(x["ms_per_512_frames"] for n_, x in out["kernels"].items() if n_.startswith("k_jpeg")), 4)
+# k_jpeg_zero_upper runs on a stream of its own beside the first synchronisation pass: listed, not part of the serial sum
+out["decoder_ms_per_512_frames"] = round(sum(x["ms_per_512_frames"] for n_, x in out["kernels"].items() if n_.startswith("k_jpeg") and n_ != "k_jpeg_zero_upper"), 4)
 json.dump(out, open("$O/${TAG}_jpeg_decoder.json", "w"), indent=1)
 print(json.dumps(out["kernels"], indent=1)); print("decoder ms per 512 frames:", out["decoder_ms_per_512_frames"])
 PY
