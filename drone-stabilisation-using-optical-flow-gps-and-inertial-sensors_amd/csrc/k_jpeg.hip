@@ -85,44 +85,20 @@ __host__ __device__ inline uint32_t jentry(bool write, bool ac, int len, int sym
 // ------------------------------------------------------------------------------------------------ device: entropy decoder
 // The host hands over DESTUFFED entropy segments (FF00 -> FF, RSTn markers taken out and listed), so the decoder's position is a
 // plain bit offset and its state at a symbol boundary (bit position, zigzag index, block in MCU) is canonical by construction.
-// The bits come out of four registers per thread: hi:lo = the 64 stream bits around the cursor (big-endian dwords w, w + 1; c =
-// bits of hi already used, so the next 32 bits are one 64-bit shift away - enough for the longest code, 16, plus the longest run of
-// extra bits, 15), n0 = dword w + 2 and n1 = dword w + 3, requested when the cursor moved into dword w - 1: a symbol step never waits
-// for memory it asked for itself (a byte load per symbol put a round trip into every step of the chain: 83 % of the wave cycles
-// waiting).  Staging the chunks in LDS was measured and bought nothing (42 KB per 128 threads: a third of the occupancy).
 // Every segment starts 256-aligned and is zero-padded up to JPAD(len): no bounds checks.
 #define JPAD(len) (((size_t)(len) + 2 * JCH_MAX + 19) / JCH * JCH)
-__device__ inline uint32_t jld(const uint8_t *d, uint32_t at) { return *reinterpret_cast<const uint32_t *>(d + at); }
 
-// Reader of the write pass: four registers (see above).
-struct jrd {
-    const uint8_t *d; uint32_t hi, lo, n0, n1, nx; int c, k, blk;     // nx: byte offset of dword w + 4
-    __device__ void seek(uint32_t bp)
-    {
-        const uint32_t at = (bp >> 5) * 4u;
-        c = (int)(bp & 31u);
-        hi = __builtin_bswap32(jld(d, at)); lo = __builtin_bswap32(jld(d, at + 4));
-        n0 = jld(d, at + 8); n1 = jld(d, at + 12); nx = at + 16;
-    }
-    __device__ uint32_t pos() const { return (nx - 16u) * 8u + (uint32_t)c; }
-    static constexpr bool uniform = false;
-    __device__ bool refill() { return true; }
-    __device__ uint32_t top() const { return (uint32_t)((((uint64_t)hi << 32 | lo) << c) >> 32); }
-    __device__ void advance(int tot)
-    {
-        c += tot;
-        if (c >= 32) { hi = lo; lo = __builtin_bswap32(n0); n0 = n1; n1 = jld(d, nx); nx += 4; c -= 32; }
-    }
-};
-
-// Reader of the synchronisation passes: a ring of JRING stream dwords per thread in LDS, refilled at wave-uniform times.
-// With the register reader a thread asks for its next dword when it needs room, and - loads and waits being counted per WAVE - every
-// slide of any lane waits for the youngest load of all 64: some lane slides in almost every step and each lane walks through memory of
-// its own, so a wave met an L2 or HBM round trip in nearly every symbol step (2300 clocks per step at 8 waves per SIMD; the pass took
-// as long with 35 instructions per symbol as with 90).  Here every JREFILL steps ALL lanes ask for the 16 bytes behind their ring and
-// take in, if there is room, what they asked for JREFILL steps ago: one wait per JREFILL steps, for a load that old.  A symbol step
-// reads its 64 bits with one ds_read2_b32 (dword 0 is kept a second time behind dword 15: no wrap) - LDS latency instead of memory
-// latency.  A lane that outruns its ring (a burst of > 2 bytes per step) skips steps until the next refill.
+// The reader: a ring of JRING stream dwords per thread in LDS, refilled at wave-uniform times.  A symbol step needs the 64 stream
+// bits at the cursor (big-endian dwords w, w + 1: the next 32 bits are one 64-bit shift away - enough for the longest code, 16, plus
+// the longest run of extra bits, 15).  History: a byte load per symbol put a memory round trip into every step (83 % of the wave
+// cycles waiting); a register window (hi:lo + two read-ahead dwords, the next dword requested at every slide) took the thread's own
+// loads off its chain but not the WAVE's - loads and waits are counted per wave, so every slide of any lane waits for the youngest
+// load of all 64, some lane slides in almost every step, and each lane walks through memory of its own: an L2 or HBM round trip in
+// nearly every symbol step (2300 clocks per step at 8 waves per SIMD; the pass took as long with 35 instructions per symbol as with
+// 90).  Here every JREFILL steps ALL lanes ask for the 16 bytes behind their ring and take in, if there is room, what they asked
+// for JREFILL steps ago: one wait per JREFILL steps, for a load that old.  A symbol step reads its 64 bits with one ds_read2_b32
+// (dword 0 is kept a second time behind dword 15: no wrap) - LDS latency instead of memory latency.  A lane that outruns its ring (a
+// burst of > 2 bytes per step) skips steps until the next refill.  Staging whole chunks in LDS costs two thirds of the occupancy.
 #define JRING 16
 #define JREFILL 8
 struct jring {
@@ -132,10 +108,12 @@ struct jring {
     int k, blk;
     __device__ void put(const uint4 v, uint32_t at)
     {
-        const uint32_t s = (at >> 2) & (JRING - 1);
+        // the ring runs BACKWARDS (stream dword i at slot JRING - (i mod JRING), dword 0 mod JRING also at slot 0): the pair (w + 1, w)
+        // then comes out of one ds_read2_b32 as the low and the high half of a 64-bit register pair, no swap
+        const uint32_t s = JRING - 3 - ((at >> 2) & (JRING - 1));          // slot of dword at + 12
         const uint32_t a = __builtin_bswap32(v.x);
-        rg[s] = a; rg[s + 1] = __builtin_bswap32(v.y); rg[s + 2] = __builtin_bswap32(v.z); rg[s + 3] = __builtin_bswap32(v.w);
-        if (s == 0) rg[JRING] = a;
+        rg[s] = __builtin_bswap32(v.w); rg[s + 1] = __builtin_bswap32(v.z); rg[s + 2] = __builtin_bswap32(v.y); rg[s + 3] = a;
+        if (s == JRING - 3) rg[0] = a;
     }
     __device__ void seek(uint32_t b)
     {
@@ -147,7 +125,6 @@ struct jring {
         in = *reinterpret_cast<const uint4 *>(d + fill);
     }
     __device__ uint32_t pos() const { return bp; }
-    static constexpr bool uniform = true;
     // every JREFILL steps: true = the lane can decode JREFILL symbols (< 4 bytes each) without looking at its ring's fill level
     __device__ bool refill()
     {
@@ -158,8 +135,8 @@ struct jring {
     }
     __device__ uint32_t top() const
     {
-        const uint32_t *p = rg + ((bp >> 5) & (JRING - 1));
-        return (uint32_t)((((uint64_t)p[0] << 32 | p[1]) << (bp & 31u)) >> 32);
+        const uint32_t *p = rg + (~(bp >> 5) & (JRING - 1));                // slots of dwords w + 1, w
+        return (uint32_t)((((uint64_t)p[1] << 32 | p[0]) << (bp & 31u)) >> 32);
     }
     __device__ void advance(int tot) { bp += (uint32_t)tot; }
 };
@@ -196,8 +173,8 @@ __device__ inline uint32_t jslow(const jpeg_tab *t, int slot, uint32_t top, bool
 // interval's padding (1-bits: a proper prefix of every table's longest codes, never a code - T.81 Annex C), so the interval is
 // complete (jdhuff.c process_restart): on to the boundary, next MCU.  A decoder in step is at k = 0, blk = 0 there anyway; one that
 // is out of step is in step from there on.
-template <bool WRITE, bool RST, class Reader, class Emit>
-__device__ inline int jrun(const jfast &T, const jpeg_tab *t, const uint32_t *__restrict__ rst, Reader &r, uint32_t bend, const jpeg_geom &g, int max_blocks, Emit &emit)
+template <bool WRITE, bool RST, class Emit>
+__device__ inline int jrun(const jfast &T, const jpeg_tab *t, const uint32_t *__restrict__ rst, jring &r, uint32_t bend, const jpeg_geom &g, int max_blocks, Emit &emit)
 {
     int done = 0;
     const int ny = g.comp_nb[0], bpm = g.bpm;
@@ -214,17 +191,14 @@ __device__ inline int jrun(const jfast &T, const jpeg_tab *t, const uint32_t *__
         ridx = lo;
         if (ridx < nrst) rl = (int)(rst[ridx] * 8u - bp0);
     }
-    // Ring reader (Reader::uniform): the loop is the WAVE's - every lane stays until the last one is done (a finished or stalled
-    // lane skips the body), so that the refill points are the same for all lanes: JREFILL symbol steps, refill, ...
+    // The loop is the WAVE's - every lane stays until the last one is done (a finished or stalled lane skips the body), so that the
+    // refill points are the same for all lanes: JREFILL symbol steps, refill, ...
     for (;;) {
-        bool go = true;
-        if (Reader::uniform) {
-            if (!__any(rem > 0 && (!WRITE || done < max_blocks))) break;
-            go = r.refill();
-        } else if (!(rem > 0 && (!WRITE || done < max_blocks))) break;
+        if (!__any(rem > 0 && (!WRITE || done < max_blocks))) break;
+        const bool go = r.refill();
 #pragma unroll 1
-        for (int u = 0; u < (Reader::uniform ? JREFILL : 1); ++u) {
-            if (Reader::uniform && !(go && rem > 0 && (!WRITE || done < max_blocks))) continue;
+        for (int u = 0; u < JREFILL; ++u) {
+            if (!(go && rem > 0 && (!WRITE || done < max_blocks))) continue;
             const uint32_t top = r.top();
             uint32_t e = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(lut) + sb + (r.k ? 1024 : 0) + ((top >> 22) & 0x3FEu));
             if (e & 0x8000u) {
@@ -269,7 +243,7 @@ __global__ __launch_bounds__(JTPB) void k_jpeg_sync(const jpeg_tab *__restrict__
 {
     __shared__ jfast T;
     __shared__ uint32_t ring[JTPB][JRING + 1];
-    __shared__ unsigned long long elist[JTPB];
+    __shared__ unsigned long long elist[JTPB];                   // (five waves per SIMD is the optimum: with the lists inside the ring's memory a sixth fits and the passes take 6 % longer, with four 7 %)
     __shared__ uint16_t clist[JTPB];
     __shared__ int wcount[JTPB / 64];
     const int b = blockIdx.y;
@@ -346,8 +320,8 @@ __global__ __launch_bounds__(1024) void k_jpeg_scan(const jpeg_tab *__restrict__
 
 // Coefficients of the block in progress are collected in the thread's LDS row and leave as one wide store when the block is
 // complete (2-byte stores scattered over HBM - partial-line writes - made this kernel 3x slower than the counting pass).  The row
-// holds the first JROW_K zigzag positions only: a row of all 64 positions (37 KB of LDS per 256 threads) allows 3 waves per SIMD,
-// 32 positions allow 5.  The coefficients behind position JROW_K (the high-frequency half: a few per cent at camera qualities) go
+// holds the first JROW_K zigzag positions only (20 KB per 256 threads beside the 17 KB of the readers' rings and 9 KB of tables:
+// three waves per SIMD; all 64 positions would leave two).  The coefficients behind position JROW_K (the high-frequency half: a few per cent at camera qualities) go
 // straight to the zeroed coefficient buffer - scattered 2-byte stores, which is why shorter rows lose: 1.82 ms per 512 frames with
 // 32 positions, 2.38 with 16, 3.59 with 8 (profiles/r04_exp_jpeg_rows.txt).  A block that straddles a chunk boundary is shared with the neighbouring thread: its parts are
 // scattered element-wise onto the zeroed background instead.
@@ -404,6 +378,7 @@ __global__ __launch_bounds__(JTPW) void k_jpeg_write(const jpeg_tab *__restrict_
 {
     __shared__ jfast T;
     __shared__ __attribute__((aligned(16))) int16_t rows[JTPW][JBLK_PITCH];
+    __shared__ uint32_t wring[JTPW][JRING + 1];
     const int b = blockIdx.y;
     const jpeg_tab *t = tabs + b;
     if ((int)(blockIdx.x * JTPW) >= t->nch) return;
@@ -412,8 +387,8 @@ __global__ __launch_bounds__(JTPW) void k_jpeg_write(const jpeg_tab *__restrict_
     if (i >= t->nch) return;
     const int n0 = base[(size_t)b * (nch_max + 1) + i];
     if (n0 >= g.nblk) return;
-    jrd r;
-    r.d = ent + t->ent_off;
+    jring r;                                                      // the ring's 17 KB leave three waves per SIMD where the register window had five: still 15 % faster
+    r.d = ent + t->ent_off; r.rg = wring[threadIdx.x];
     const unsigned long long e = i ? state[(size_t)b * nch_max + i - 1] : 0ull;
     r.k = (int)((e >> 8) & 63); r.blk = (int)(e & 15);
     r.seek((uint32_t)(e >> 32));
