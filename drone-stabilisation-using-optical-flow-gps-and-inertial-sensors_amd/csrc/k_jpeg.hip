@@ -914,6 +914,17 @@ extern "C" int ofk_jpeg_info(const uint8_t *jpeg, size_t nbytes, int *h, int *w,
     return OFK_OK;
 }
 
+extern "C" int ofk_jpeg_destuff(const uint8_t *jpeg, size_t nbytes, uint8_t *out, size_t out_capacity, size_t *out_len, uint32_t *rst, int rst_capacity, int *nrst)
+{
+    jhost j;
+    if (!out || !out_len || !nrst || (rst_capacity > 0 && !rst) || jparse(jpeg, nbytes, &j)) return OFK_E_INVALID;
+    if (out_capacity < j.ent_len) return OFK_E_INVALID;
+    uint32_t n = 0;
+    *out_len = jdestuff(out, j.ent, j.ent_len, j.ri > 0, rst, rst_capacity > 0 ? (uint32_t)rst_capacity : 0u, &n);
+    *nrst = (int)n;
+    return n > (uint32_t)(rst_capacity > 0 ? rst_capacity : 0) ? OFK_E_INVALID : OFK_OK;
+}
+
 static size_t jup(size_t v, size_t a) { return (v + a - 1) / a * a; }
 #define TRY_J(expr) do { int rc_ = (expr); if (rc_ != OFK_OK) return rc_; } while (0)
 

@@ -26,7 +26,7 @@ SYMBOLS = (
     "ofk_version", "ofk_last_error", "ofk_device_count", "ofk_create", "ofk_destroy", "ofk_sync", "ofk_device_sync",
     "ofk_gray_bgr8", "ofk_pyr_down_u8", "ofk_pyramid_u8", "ofk_scharr_s16", "ofk_mineig_response", "ofk_select_corners",
     "ofk_good_features", "ofk_lk_pyr", "ofk_flow_model", "ofk_feasibility", "ofk_velocity_solve", "ofk_imu_propagate",
-    "ofk_post_solve", "ofk_kf_predict_update", "ofk_of_simulation", "ofk_of_simulation_rng", "ofk_noise_normals", "ofk_feas_simulation", "ofk_hist_overlap", "ofk_associate_sensors", "ofk_feature_eval", "ofk_d_split", "ofk_pairs_upload", "ofk_pairs_upload_jpeg", "ofk_jpeg_stage", "ofk_jpeg_stage_error", "ofk_pairs_upload_staged", "ofk_jpeg_info", "ofk_jpeg_decode_bgr8", "ofk_pairs_set_sensors",
+    "ofk_post_solve", "ofk_kf_predict_update", "ofk_of_simulation", "ofk_of_simulation_rng", "ofk_noise_normals", "ofk_feas_simulation", "ofk_hist_overlap", "ofk_associate_sensors", "ofk_feature_eval", "ofk_d_split", "ofk_pairs_upload", "ofk_pairs_upload_jpeg", "ofk_jpeg_stage", "ofk_jpeg_stage_error", "ofk_pairs_upload_staged", "ofk_jpeg_info", "ofk_jpeg_destuff", "ofk_jpeg_decode_bgr8", "ofk_pairs_set_sensors",
     "ofk_pairs_run", "ofk_pairs_download", "ofk_pairs_export_records_f32", "ofk_stream_begin", "ofk_stream_step",
     "ofk_stream_begin_jpeg", "ofk_stream_step_jpeg",
     "ofk_set_streams", "ofk_set_overlap", "ofk_set_tuning", "ofk_get_tuning", "ofk_mark", "ofk_mark_wait", "ofk_profile_enable", "ofk_profile_read", "ofk_resident_pyramid",
@@ -76,6 +76,19 @@ def jpeg_info(stream):
     return h.value, w.value, n.value
 
 
+def jpeg_destuff(stream):
+    """(entropy segment without its byte stuffing and restart markers, offsets behind the removed RSTn markers) - what the ingest's
+    staging hands to the device decoders (host only)."""
+    data = bytes(stream)
+    out = C.create_string_buffer(max(1, len(data)))
+    rst = (C.c_uint32 * (len(data) // 2 + 1))()
+    n, nr = C.c_size_t(), C.c_int()
+    rc = load_library().ofk_jpeg_destuff(data, len(data), out, len(data), C.byref(n), rst, len(rst), C.byref(nr))
+    if rc != 0:
+        raise OfkError(rc, "ofk_jpeg_destuff: not a JPEG stream the decoder supports")
+    return out.raw[:n.value], list(rst[:nr.value])
+
+
 def load_library():
     """Loads libofk.so and declares the signatures.  Raises OfkError if the library is not built."""
     global _lib
@@ -123,6 +136,7 @@ def load_library():
         L.ofk_jpeg_stage.argtypes = [vp, i, vp, vp, i]; L.ofk_pairs_upload_staged.argtypes = [vp, i]
         L.ofk_jpeg_stage_error.restype = C.c_char_p; L.ofk_jpeg_stage_error.argtypes = [vp, i]
         L.ofk_jpeg_info.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
+        L.ofk_jpeg_destuff.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_uint32), i, C.POINTER(i)]
         L.ofk_jpeg_decode_bgr8.argtypes = [vp, vp, vp, i, vp]
         L.ofk_pairs_set_sensors.argtypes = [vp, vp, i]
         L.ofk_pairs_run.argtypes = [vp, C.POINTER(Params)]

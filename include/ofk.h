@@ -365,6 +365,13 @@ int ofk_stream_step_fused_jpeg(ofk_ctx *ctx, const uint8_t *const *jpeg, const s
  * IDCT, fancy upsampling) - what cv::imdecode returns.  Entropy decoding runs on the GPU too (self-synchronising chunked Huffman
  * decoders); truncated or corrupt entropy data is an error, not a partially grey picture. */
 int ofk_jpeg_info(const uint8_t *jpeg, size_t nbytes, int *h, int *w, int *components);
+/* ofk_jpeg_destuff (host only; no context, no GPU): the entropy-coded segment of the stream's scan as the device decoders read it -
+ * byte stuffing removed (FF00 -> FF, what jdhuff.c's fill_bit_buffer does on the fly behind cv::imdecode), the RSTn markers of a
+ * stream with a restart interval taken out and the offsets behind them written to rst[0 .. *nrst) (offsets into `out`), the data
+ * ending at the first other marker.  *out_len = bytes written; OFK_E_INVALID if the stream is not decodable (ofk_jpeg_info), if
+ * out_capacity is smaller than the stuffed segment or rst_capacity smaller than the number of markers.  The staging of the ingest
+ * (ofk_jpeg_stage, ofk_pairs_upload_jpeg ...) runs the same routine; this entry exists so that it can be tested without a GPU. */
+int ofk_jpeg_destuff(const uint8_t *jpeg, size_t nbytes, uint8_t *out, size_t out_capacity, size_t *out_len, uint32_t *rst, int rst_capacity, int *nrst);
 int ofk_jpeg_decode_bgr8(ofk_ctx *ctx, const uint8_t *const *jpeg, const size_t *nbytes, int batch, uint8_t *bgr);
 
 /* ------------------------------------------------- multi-GPU exchange: RCCL over xGMI, no PyTorch

@@ -47,6 +47,66 @@ def test_host_header_parser_matches_oracle(pkg, ofk, gold):
             ofk.jpeg_info(bad)
 
 
+def _scan_data(data):
+    """(offset of the entropy-coded segment, restart interval) of a baseline stream: walk the marker segments up to SOS."""
+    i, ri = 2, 0
+    while True:
+        assert data[i] == 0xFF
+        m, L = data[i + 1], (data[i + 2] << 8) | data[i + 3]
+        if m == 0xDD:
+            ri = (data[i + 4] << 8) | data[i + 5]
+        if m == 0xDA:
+            return i + 2 + L, ri
+        i += 2 + L
+
+
+def _destuff_reference(data):
+    """What the decoders read: FF00 -> FF, RSTn (streams with a restart interval) taken out and the offsets behind them listed, the data
+    ends at any other marker (T.81 B.1.1.5, F.1.2.3; libjpeg jdhuff.c fill_bit_buffer / process_restart)."""
+    e0, ri = _scan_data(data)
+    out, rst, i = bytearray(), [], e0
+    while i < len(data):
+        b = data[i]
+        if b != 0xFF:
+            out.append(b); i += 1
+        elif i + 1 >= len(data):
+            out.append(0xFF); break
+        elif data[i + 1] == 0:
+            out.append(0xFF); i += 2
+        elif ri and 0xD0 <= data[i + 1] <= 0xD7:
+            rst.append(len(out)); i += 2
+        else:
+            break
+    return bytes(out), rst
+
+
+def test_host_destuffing_matches_a_python_restatement(pkg, ofk, gold):
+    """ofk_jpeg_destuff is the routine the staging of the compressed ingest runs (k_jpeg.hip jdestuff), host-only: every golden stream
+    (4:4:4 / 4:2:2 / 4:2:0 / gray, odd sizes, restart intervals, quality 100 = dense stuffing) against a byte-wise restatement, plus
+    streams with a foreign marker or surplus RSTn markers spliced into the entropy data."""
+    seen_ff, seen_rst = 0, 0
+    for n in names(gold):
+        data = gold[f"jpg_{n}"].tobytes()
+        want, want_rst = _destuff_reference(data)
+        got, got_rst = ofk.jpeg_destuff(data)
+        assert got == want and got_rst == want_rst, n
+        e0, _ = _scan_data(data)
+        seen_ff += data[e0:].count(b"\xff\x00"); seen_rst += len(want_rst)
+        assert len(got) == len(data) - e0 - 2 - data[e0:-2].count(b"\xff\x00") - 2 * len(want_rst)      # nothing else is dropped (EOI ends the stream)
+        # a foreign marker in the middle ends the data there; surplus restart markers are listed, not decoded
+        mid = e0 + (len(data) - e0) // 2
+        while data[mid - 1] == 0xFF or data[mid] == 0xFF:
+            mid += 1
+        cut = data[:mid] + b"\xff\xe1" + data[mid:]
+        assert ofk.jpeg_destuff(cut) == _destuff_reference(cut) and len(ofk.jpeg_destuff(cut)[0]) < len(got)
+        if want_rst:
+            more = data[:-2] + b"\xff\xd3\xff\xd4" + data[-2:]
+            assert ofk.jpeg_destuff(more) == _destuff_reference(more) and len(ofk.jpeg_destuff(more)[1]) == len(want_rst) + 2
+    assert seen_ff > 50 and seen_rst > 10          # the fixtures exercise both
+    with pytest.raises(ofk.OfkError):
+        ofk.jpeg_destuff(gold["jpg_progressive"].tobytes())
+
+
 # ------------------------------------------------------------------------------------------------ GPU
 @pytest.mark.gpu
 def test_device_decoder_reproduces_libjpeg_pixels(gpu_ctx, gold):
