@@ -21,8 +21,9 @@
 //   3. k_jpeg_write: every thread decodes its chunk once more from its (now true) entry state and stores the coefficients
 //      (k_jpeg_zero_upper / k_jpeg_zero_heads prepare the background it relies on).
 //   4. k_jpeg_dc: DC prediction = prefix sum of the DC differences per component in decode order.
-//   5. k_jpeg_idct: dequantisation + ISLOW IDCT, 8 lanes per block (columns, then rows through LDS) -> component planes.
-//   6. k_jpeg_color: fancy upsampling + colour conversion -> BGR8 (or straight to gray for the pipeline).
+//   5. k_jpeg_idct<false>: dequantisation + ISLOW IDCT of the chroma blocks, 8 lanes per block (columns, then rows through LDS) -> planes.
+//   6. k_jpeg_idct<true>: the same for the luma blocks, into an LDS tile, then fancy upsampling + colour conversion -> BGR8 (or straight
+//      to gray for the pipeline).
 // The decoder state at a symbol boundary is (bit position in the destuffed segment, zigzag index, block-in-MCU): a function of
 // the true bit position only, so two decoders that agree on a symbol boundary agree on everything that follows.  A symbol belongs
 // to the chunk its first bit lies in.  Restart markers are taken out by the host and listed as boundaries, see jrun.
@@ -528,76 +529,6 @@ __device__ inline uint32_t jrange_limit(int x)
     return (uint32_t)r;
 }
 
-// 8 lanes per block, 32 blocks per step; a workgroup walks along ONE MCU row of one image: the block's place in the planes follows from
-// the step counter with one multiply-shift (the divisions by blocks-per-MCU and MCUs-per-row of a flat block index were 15 % of the
-// kernel's instructions), the quantiser tables are loaded once per row, and the next step's coefficients are in flight during both passes.
-__global__ __launch_bounds__(256) void k_jpeg_idct(const jpeg_tab *__restrict__ tabs, jpeg_geom g, const int16_t *__restrict__ coef,
-                                                   const int16_t *__restrict__ dcarr, uint8_t *__restrict__ planes, unsigned bpm_magic)
-{
-    __shared__ int ws[32][72];
-    __shared__ int16_t cz[32][72];                                // the blocks as stored (zigzag order), one 16-byte load per lane
-    __shared__ uint16_t qs[3][64];
-    const int b = blockIdx.y, mrow = blockIdx.x;
-    const int lb = threadIdx.x >> 3, c = threadIdx.x & 7;
-    if (threadIdx.x < 192) qs[threadIdx.x >> 6][threadIdx.x & 63] = tabs[b].q[threadIdx.x >> 6][threadIdx.x & 63];
-    unsigned zlo = 0, zhi = 0;                                    // zigzag positions of this lane's column, rows 0..3 / 4..7
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { zlo |= (unsigned)c_izz[r * 8 + c] << (8 * r); zhi |= (unsigned)c_izz[(r + 4) * 8 + c] << (8 * r); }
-    const int nrow = g.mcux * g.bpm, ny = g.comp_nb[0];
-    const size_t nbase = (size_t)b * g.nblk + (size_t)mrow * nrow;
-    uint4 nv = make_uint4(0, 0, 0, 0);
-    int16_t ndc = 0;
-    if (lb < nrow) {
-        nv = reinterpret_cast<const uint4 *>(coef + (nbase + lb) * 64)[c];
-        if (c == 0) ndc = dcarr[nbase + lb];
-    }
-    for (int l0 = 0; l0 < nrow; l0 += 32) {
-        const int local = l0 + lb;
-        const bool live = local < nrow;
-        *reinterpret_cast<uint4 *>(&cz[lb][8 * c]) = nv;
-        if (c == 0) cz[lb][0] = ndc;                               // the predicted DC (the block holds the difference)
-        __syncthreads();
-        if (local + 32 < nrow) {
-            nv = reinterpret_cast<const uint4 *>(coef + (nbase + local + 32) * 64)[c];
-            if (c == 0) ndc = dcarr[nbase + local + 32];
-        }
-        int comp = 0, bx = 0, by = 0;
-        if (live) {
-            const int mx = (int)(((unsigned)local * bpm_magic) >> 20), j = local - mx * g.bpm;
-            comp = j < ny ? 0 : j - ny + 1;
-            const int jj = comp == 0 ? j : 0;
-            const int hs = comp == 0 ? g.hmax : 1;                // 1 or 2
-            bx = mx * hs + (jj & (hs - 1));
-            by = mrow * (comp == 0 ? g.vmax : 1) + (jj >> (hs - 1));
-            int in[8], o[8];
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int zp = (int)(((r < 4 ? zlo : zhi) >> (8 * (r & 3))) & 255u);
-                in[r] = __mul24((int)cz[lb][zp], (int)qs[comp][r * 8 + c]);   // 16 x 16 bits: exact in the 24-bit multiplier
-            }
-            jidct8(in, o);
-#pragma unroll
-            for (int r = 0; r < 8; ++r) ws[lb][r * 9 + c] = (o[r] + (1 << 10)) >> 11;
-        }
-        __syncthreads();                                           // (a wave-level fence would do - the eight lanes of a block are lanes of one wave - and measured 6 % slower)
-        if (live) {
-            int in[8], o[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) in[k] = ws[lb][c * 9 + k];                // this lane's row = c
-            jidct8(in, o);
-            uint32_t lo = 0, hi = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                lo |= jrange_limit((o[k] + (1 << 17)) >> 18) << (8 * k);
-                hi |= jrange_limit((o[k + 4] + (1 << 17)) >> 18) << (8 * k);
-            }
-            uint8_t *pl = planes + (size_t)b * g.plane_stride + g.plane_off[comp];
-            uint2 *dst = (uint2 *)(pl + (size_t)(by * 8 + c) * g.pw[comp] + bx * 8);
-            *dst = make_uint2(lo, hi);
-        }
-    }
-}
-
 __device__ inline int jclamp8(int x) { return x < 0 ? 0 : x > 255 ? 255 : x; }
 
 // Chroma of the 8 output pixels x0 .. x0+7 (x0 a multiple of 8) of row y with libjpeg's "fancy" upsampling
@@ -644,19 +575,15 @@ __device__ inline void jchroma8(const uint8_t *__restrict__ pl, int pitch, int c
     }
 }
 
-// eight pixels per thread: 8 bytes of luma in, 24 bytes of BGR out as dwords (bytes when the row pitch is not a dword multiple)
+// Eight pixels of row y from x0 on: luma y8, chroma from the planes with fancy upsampling, fixed-point YCbCr -> BGR (jdcolor.c), 24
+// bytes of BGR out as dwords (bytes when the row pitch is not a dword multiple).
 // as_gray: bgr / bgr2 are gray planes (rows of g.w bytes) and receive what k_gray_bgr8 (k_image.hip: cv2.cvtColor BGR2GRAY) makes of the
 // pixel - the pipeline's first stage fused into the decoder's last, the BGR frame (three times the bytes, written here and read there)
 // never exists.
-__global__ __launch_bounds__(256) void k_jpeg_color(jpeg_geom g, const uint8_t *__restrict__ planes, uint8_t *__restrict__ bgr, uint8_t *__restrict__ bgr2, int split,
-                                                    size_t bgr_stride, int as_gray)
+__device__ inline void jcolor8(const jpeg_geom &g, const uint8_t *__restrict__ pl, uint2 y8, int b, int x0, int y, uint8_t *__restrict__ bgr,
+                               uint8_t *__restrict__ bgr2, int split, size_t bgr_stride, int as_gray)
 {
-    const int b = blockIdx.z;
-    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 8, y = blockIdx.y * 4 + threadIdx.y;
-    if (x0 >= g.w || y >= g.h) return;
-    const uint8_t *pl = planes + (size_t)b * g.plane_stride;
     uint8_t *o = (b < split ? bgr + (size_t)b * bgr_stride : bgr2 + (size_t)(b - split) * bgr_stride) + ((size_t)y * g.w + x0) * 3;   // pairs: previous frames | next frames
-    const uint2 y8 = *(const uint2 *)(pl + g.plane_off[0] + (unsigned)(y * g.pw[0] + x0));           // pw is a multiple of 8
     uint8_t px[24];
     if (g.ncomp == 1) {
 #pragma unroll
@@ -698,6 +625,91 @@ __global__ __launch_bounds__(256) void k_jpeg_color(jpeg_geom g, const uint8_t *
     } else {
         const int n = (g.w - x0 < 8 ? g.w - x0 : 8) * 3;
         for (int k = 0; k < n; ++k) o[k] = px[k];
+    }
+}
+
+// IDCT: 8 lanes per block, 32 blocks per step; a workgroup walks along ONE MCU row of one image (block positions from shifts - the
+// blocks of a kind per MCU are 1, 2 or 4 -, quantiser tables loaded once per row, the next step's coefficients in flight during both
+// passes).  Two launches per decode:
+//   LUMA = false: the chroma blocks -> the Cb / Cr planes (fancy upsampling needs the neighbours of a sample, so chroma goes through HBM);
+//   LUMA = true:  the luma blocks of 32 / (hmax vmax) MCUs -> a tile of 8 vmax rows x 256 / vmax pixels in LDS, then the same 256 threads
+//                 take eight pixels each: chroma from the planes, colour conversion, BGR or gray out (jcolor8).  The Y plane never
+//                 exists: its 8-byte row stores from lanes that sit in different image rows were a quarter of the IDCT's time, and the
+//                 colour pass read it back (k_jpeg_idct + k_jpeg_color 2.65 -> 0.39 + 1.71 ms per 512 frames).
+template <bool LUMA>
+__global__ __launch_bounds__(256) void k_jpeg_idct(const jpeg_tab *__restrict__ tabs, jpeg_geom g, const int16_t *__restrict__ coef,
+                                                   const int16_t *__restrict__ dcarr, uint8_t *__restrict__ planes, uint8_t *__restrict__ bgr,
+                                                   uint8_t *__restrict__ bgr2, int split, size_t bgr_stride, int as_gray)
+{
+    __shared__ int ws[32][72];
+    __shared__ int16_t cz[32][72];                                // the blocks as stored (zigzag order), one 16-byte load per lane
+    __shared__ uint16_t qs[3][64];
+    __shared__ uint2 ytile[LUMA ? 16 : 1][LUMA ? 33 : 1];         // [row][8-pixel group] (+ 1: rows on different banks)
+    const int b = blockIdx.y, mrow = blockIdx.x;
+    const int lb = threadIdx.x >> 3, c = threadIdx.x & 7;
+    if (threadIdx.x < 192) qs[threadIdx.x >> 6][threadIdx.x & 63] = tabs[b].q[threadIdx.x >> 6][threadIdx.x & 63];
+    unsigned zlo = 0, zhi = 0;                                    // zigzag positions of this lane's column, rows 0..3 / 4..7
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { zlo |= (unsigned)c_izz[r * 8 + c] << (8 * r); zhi |= (unsigned)c_izz[(r + 4) * 8 + c] << (8 * r); }
+    const int ny = g.comp_nb[0];
+    const int per = LUMA ? ny : g.bpm - ny, sh = per == 4 ? 2 : per == 2 ? 1 : 0, j0 = LUMA ? 0 : ny;   // blocks of this kind per MCU
+    const int nsel = g.mcux * per;                                // ... in the MCU row
+    const size_t nbase = (size_t)b * g.nblk + (size_t)mrow * g.mcux * g.bpm;
+    auto block_of = [&](int s) { return nbase + (size_t)((s >> sh) * g.bpm + j0 + (s & (per - 1))); };
+    const int hs = g.hmax, vsl = g.vmax == 2 ? 1 : 0;              // tile: 8 << vsl rows of 32 >> vsl groups
+    const uint8_t *pl = planes + (size_t)b * g.plane_stride;
+    uint4 nv = make_uint4(0, 0, 0, 0);
+    int16_t ndc = 0;
+    if (lb < nsel) {
+        const size_t n = block_of(lb);
+        nv = reinterpret_cast<const uint4 *>(coef + n * 64)[c];
+        if (c == 0) ndc = dcarr[n];
+    }
+    for (int l0 = 0; l0 < nsel; l0 += 32) {
+        const int local = l0 + lb;
+        const bool live = local < nsel;
+        *reinterpret_cast<uint4 *>(&cz[lb][8 * c]) = nv;
+        if (c == 0) cz[lb][0] = ndc;                               // the predicted DC (the block holds the difference)
+        __syncthreads();
+        if (local + 32 < nsel) {
+            const size_t n = block_of(local + 32);
+            nv = reinterpret_cast<const uint4 *>(coef + n * 64)[c];
+            if (c == 0) ndc = dcarr[n];
+        }
+        const int mx = local >> sh, jj = local & (per - 1);
+        const int comp = LUMA ? 0 : 1 + jj;
+        if (live) {
+            int in[8], o[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int zp = (int)(((r < 4 ? zlo : zhi) >> (8 * (r & 3))) & 255u);
+                in[r] = __mul24((int)cz[lb][zp], (int)qs[comp][r * 8 + c]);   // 16 x 16 bits: exact in the 24-bit multiplier
+            }
+            jidct8(in, o);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) ws[lb][r * 9 + c] = (o[r] + (1 << 10)) >> 11;
+        }
+        __syncthreads();                                           // (a wave-level fence would do - the eight lanes of a block are lanes of one wave - and measured 6 % slower)
+        if (live) {
+            int in[8], o[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) in[k] = ws[lb][c * 9 + k];                // this lane's row = c
+            jidct8(in, o);
+            uint32_t lo = 0, hi = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                lo |= jrange_limit((o[k] + (1 << 17)) >> 18) << (8 * k);
+                hi |= jrange_limit((o[k + 4] + (1 << 17)) >> 18) << (8 * k);
+            }
+            if (LUMA) ytile[((jj >> (hs - 1)) << 3) + c][((mx - (l0 >> sh)) << (hs - 1)) + (jj & (hs - 1))] = make_uint2(lo, hi);
+            else *(uint2 *)(planes + (size_t)b * g.plane_stride + g.plane_off[comp] + (size_t)(mrow * 8 + c) * g.pw[comp] + mx * 8) = make_uint2(lo, hi);
+        }
+        if (LUMA) {
+            __syncthreads();
+            const int r = threadIdx.x >> (5 - vsl), xg = threadIdx.x & ((32 >> vsl) - 1);
+            const int y = (mrow << (3 + vsl)) + r, x0 = ((l0 >> sh) * hs + xg) * 8;
+            if (x0 < g.w && y < g.h) jcolor8(g, pl, ytile[r][xg], b, x0, y, bgr, bgr2, split, bgr_stride, as_gray);
+        }
     }
 }
 
@@ -1202,8 +1214,8 @@ static int jdecode_staged(ofk_ctx *c, int slot, uint8_t *dst, uint8_t *dst2, int
     hipLaunchKernelGGL(k_jpeg_zero_heads, dim3((nch_max + 63) / 64, batch), dim3(256), 0, st, dt, g, nch_max, state, base, coef);
     hipLaunchKernelGGL(write_pass, dim3((nch_max + JTPW - 1) / JTPW, batch), dim3(JTPW), 0, st, dt, dent, drst, g, nch_max, state, base, coef, dcarr, endinfo);
     hipLaunchKernelGGL(k_jpeg_dc, dim3(batch, g.ncomp), dim3(1024), 0, st, dt, g, dcarr);
-    hipLaunchKernelGGL(k_jpeg_idct, dim3(g.mcuy, batch), dim3(256), 0, st, dt, g, coef, dcarr, planes, (unsigned)(((1u << 20) + g.bpm - 1) / g.bpm));
-    hipLaunchKernelGGL(k_jpeg_color, dim3((g.w + 511) / 512, (g.h + 3) / 4, batch), dim3(64, 4), 0, st, g, planes, dst, dst2, split, dst_stride, as_gray);
+    if (g.ncomp > 1) hipLaunchKernelGGL(k_jpeg_idct<false>, dim3(g.mcuy, batch), dim3(256), 0, st, dt, g, coef, dcarr, planes, dst, dst2, split, dst_stride, as_gray);
+    hipLaunchKernelGGL(k_jpeg_idct<true>, dim3(g.mcuy, batch), dim3(256), 0, st, dt, g, coef, dcarr, planes, dst, dst2, split, dst_stride, as_gray);
     hipLaunchKernelGGL(k_jpeg_ints_to_host, dim3(4), dim3(256), 0, st, endinfo, js->hmap_dev + JMAX_ITERS, 2 * batch);
     hipError_t e = hipStreamSynchronize(st);
     if (e == hipSuccess) e = hipGetLastError();
