@@ -48,7 +48,8 @@ The JSON line also carries
   stages_isolated : every stage alone on the chip (the serial pass), with its HBM fraction and its PMC traffic; a stage whose
                  traffic lies BELOW its algorithmic bytes is flagged: SURVEY's byte count is then not that kernel's minimum.
   ingest_inclusive : pairs/s when the frames are NOT resident: raw BGR over PCIe every step, and JPEG streams decoded on the
-                 device every step (bounded: a few steps each, outside the timed region) with the decoder's own kernel times.
+                 device every step (bounded: a few steps each, outside the timed region) with the decoder's own kernel times;
+                 jpeg_double_buffered.value = 20 batches with the first one's staging unhidden, .steady_state = the loop's period.
   cpu_baseline : the CPU oracle (oracle/, single thread, kind "port") timed on this host over a bounded sample of the
                  same frame pairs (rank 0, N=1 only).
   monte_carlo_sweep (--config c4 only): configs[4]'s Monte-Carlo sweep at 2000 points x 4096 trials per step, device noise and host noise.
@@ -236,13 +237,18 @@ def ingest_inclusive(pipe, prev, nxt, sensors, B, reps=2):
                                         "streams": f"{D} distinct 1080p 4:2:0 quality-80 frames per side, repeated"}
         # the same with the ingest double-buffered (FlowPipeline.run_jpeg_batches): a helper thread parses, stages and uploads batch
         # k + 1 while the GPU decodes batch k and runs its pairs
-        nb = 10                                                  # enough batches for the steady state (the first one stages unhidden)
+        nb = 20                                                  # the first batch stages unhidden: `steady_state` below leaves the ramp out
         pipe.run_jpeg_batches([(jp, jn)] * 2, sensors); pipe.sync()        # warm-up: both staging slots allocate their pinned / device buffers
+        marks = []
         t0 = time.perf_counter()
-        pipe.run_jpeg_batches([(jp, jn)] * nb, sensors)
+        pipe.run_jpeg_batches([(jp, jn)] * nb, sensors, on_step=lambda k: marks.append(time.perf_counter()))
         pipe.sync()
         dt = time.perf_counter() - t0
+        # `value`: all nb batches, the first one's staging not hidden (round 3's definition); `steady_state`: the period between queued
+        # steps once the loop is full (batches 3 .. nb)
+        steady = (marks[-1] - marks[2]) / (len(marks) - 3) if len(marks) > 4 else None
         out["jpeg_double_buffered"] = {"value": round(B * nb / dt, 1), "unit": "frame-pairs/s", "batches": nb,
+                                       "steady_state": round(B / steady, 1) if steady else None,
                                        "how": "ofk_jpeg_stage of batch k+1 on a helper thread (host parse, pinned staging, H2D on the copy stream) "
                                               "while ofk_pairs_upload_staged decodes batch k; both frames of a pair in one decoder batch"}
     except Exception as e:
