@@ -534,6 +534,11 @@ __device__ inline int jclamp8(int x) { return x < 0 ? 0 : x > 255 ? 255 : x; }
 // Chroma of the 8 output pixels x0 .. x0+7 (x0 a multiple of 8) of row y with libjpeg's "fancy" upsampling
 // (jdsample.c h2v1_fancy_upsample / h2v2_fancy_upsample; context rows replicated at the top and bottom edge as jdmainct.c does).
 // The four chroma columns under the pixels come in as one dword per row, their two neighbours as bytes.
+// libjpeg's edge rules - the first output of column 0 and the second of column cw - 1 are the column itself, (4 v + r) >> s - are the
+// general formula (3 v + neighbour + r) >> s with the neighbour replaced by the column: the left neighbour of column 0 and the right
+// one of the group's last column come in replicated by the clamped loads (cl, cr); only where the image's last column sits INSIDE
+// a group of four (cw not a multiple of four: one thread per row) the columns behind it are patched.  No select per output.
+#define JCHROMA_EDGE() do { if (cx0 + 3 > cw - 1) { for (int k = 1; k < 4; ++k) if (cx0 + k > cw - 1) t[k + 1] = t[k]; } } while (0)
 __device__ inline void jchroma8(const uint8_t *__restrict__ pl, int pitch, int cw, int ch, int hmax, int vmax, int x0, int y, int *out)
 {   // (offsets inside a plane are 32-bit: the plane base is uniform, so the loads take it from scalar registers)
     if (hmax == 1) {
@@ -551,11 +556,12 @@ __device__ inline void jchroma8(const uint8_t *__restrict__ pl, int pitch, int c
         t[0] = pl[ro + cl]; t[5] = pl[ro + cr];
 #pragma unroll
         for (int k = 0; k < 4; ++k) t[k + 1] = (m >> (8 * k)) & 255;
+        JCHROMA_EDGE();
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int cx = cx0 + k, v = t[k + 1];
-            out[2 * k] = cx == 0 ? v : (v * 3 + t[k] + 1) >> 2;
-            out[2 * k + 1] = cx == cw - 1 ? v : (v * 3 + t[k + 2] + 2) >> 2;
+            const int v = t[k + 1];
+            out[2 * k] = (v * 3 + t[k] + 1) >> 2;
+            out[2 * k + 1] = (v * 3 + t[k + 2] + 2) >> 2;
         }
         return;
     }
@@ -567,11 +573,12 @@ __device__ inline void jchroma8(const uint8_t *__restrict__ pl, int pitch, int c
     t[0] = pl[o0 + cl] * 3 + pl[o1 + cl]; t[5] = pl[o0 + cr] * 3 + pl[o1 + cr];
 #pragma unroll
     for (int k = 0; k < 4; ++k) t[k + 1] = (int)((m0 >> (8 * k)) & 255) * 3 + (int)((m1 >> (8 * k)) & 255);
+    JCHROMA_EDGE();
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int cx = cx0 + k, v = t[k + 1];
-        out[2 * k] = cx == 0 ? (v * 4 + 8) >> 4 : (v * 3 + t[k] + 8) >> 4;
-        out[2 * k + 1] = cx == cw - 1 ? (v * 4 + 7) >> 4 : (v * 3 + t[k + 2] + 7) >> 4;
+        const int v = t[k + 1];
+        out[2 * k] = (v * 3 + t[k] + 8) >> 4;
+        out[2 * k + 1] = (v * 3 + t[k + 2] + 7) >> 4;
     }
 }
 
