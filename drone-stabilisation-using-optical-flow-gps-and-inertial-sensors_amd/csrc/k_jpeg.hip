@@ -591,10 +591,10 @@ __device__ inline void jcolor8(const jpeg_geom &g, const uint8_t *__restrict__ p
                                uint8_t *__restrict__ bgr2, int split, size_t bgr_stride, int as_gray)
 {
     uint8_t *o = (b < split ? bgr + (size_t)b * bgr_stride : bgr2 + (size_t)(b - split) * bgr_stride) + ((size_t)y * g.w + x0) * 3;   // pairs: previous frames | next frames
-    uint8_t px[24];
+    int pb[8], pg[8], pr[8];                                      // clamped to 0..255
     if (g.ncomp == 1) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) px[3 * k] = px[3 * k + 1] = px[3 * k + 2] = (uint8_t)(((k < 4 ? y8.x : y8.y) >> (8 * (k & 3))) & 255);
+        for (int k = 0; k < 8; ++k) pb[k] = pg[k] = pr[k] = (int)(((k < 4 ? y8.x : y8.y) >> (8 * (k & 3))) & 255);
     } else {
         const int cw = (g.w + g.hmax - 1) >> (g.hmax - 1), ch = (g.h + g.vmax - 1) >> (g.vmax - 1);    // sampling factors are 1 or 2
         int cb[8], cr[8];
@@ -602,12 +602,13 @@ __device__ inline void jcolor8(const jpeg_geom &g, const uint8_t *__restrict__ p
         jchroma8(pl + g.plane_off[2], g.pw[2], cw, ch, g.hmax, g.vmax, x0, y, cr);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int Y = ((k < 4 ? y8.x : y8.y) >> (8 * (k & 3))) & 255, u = cb[k] - 128, v = cr[k] - 128;
-            // jdcolor.c build_ycc_rgb_table: SCALEBITS 16, FIX(1.40200) = 91881, FIX(1.77200) = 116130, FIX(0.71414) = 46802, FIX(0.34414) = 22554
-            // (17-bit constants x 9-bit chroma: exact in the 24-bit multiplier, half the issue cost of v_mul_lo_u32)
-            px[3 * k] = (uint8_t)jclamp8(Y + ((__mul24(116130, u) + 32768) >> 16));
-            px[3 * k + 1] = (uint8_t)jclamp8(Y + ((__mul24(-22554, u) + 32768 + __mul24(-46802, v)) >> 16));
-            px[3 * k + 2] = (uint8_t)jclamp8(Y + ((__mul24(91881, v) + 32768) >> 16));
+            const int Y = (int)(((k < 4 ? y8.x : y8.y) >> (8 * (k & 3))) & 255);
+            // jdcolor.c build_ycc_rgb_table: SCALEBITS 16, FIX(1.40200) = 91881, FIX(1.77200) = 116130, FIX(0.71414) = 46802, FIX(0.34414) = 22554,
+            // applied to cb - 128, cr - 128 and rounded with ONE_HALF: the - 128 and the rounding are folded into the constants (17-bit
+            // constants x 8-bit chroma: exact in the 24-bit multiplier, half the issue cost of v_mul_lo_u32)
+            pb[k] = jclamp8(Y + ((__mul24(116130, cb[k]) + (32768 - 128 * 116130)) >> 16));
+            pg[k] = jclamp8(Y + ((__mul24(-22554, cb[k]) + (32768 + 128 * 22554 + 128 * 46802) + __mul24(-46802, cr[k])) >> 16));
+            pr[k] = jclamp8(Y + ((__mul24(91881, cr[k]) + (32768 - 128 * 91881)) >> 16));
         }
     }
     if (as_gray) {
@@ -615,8 +616,8 @@ __device__ inline void jcolor8(const jpeg_geom &g, const uint8_t *__restrict__ p
         uint32_t lo = 0, hi = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {                               // k_image.hip gray1(): (3735 b + 19235 g + 9798 r + 16384) >> 15
-            lo |= ((px[3 * k] * 3735u + px[3 * k + 1] * 19235u + px[3 * k + 2] * 9798u + 16384u) >> 15) << (8 * k);
-            hi |= ((px[3 * k + 12] * 3735u + px[3 * k + 13] * 19235u + px[3 * k + 14] * 9798u + 16384u) >> 15) << (8 * k);
+            lo |= (((uint32_t)pb[k] * 3735u + (uint32_t)pg[k] * 19235u + (uint32_t)pr[k] * 9798u + 16384u) >> 15) << (8 * k);
+            hi |= (((uint32_t)pb[k + 4] * 3735u + (uint32_t)pg[k + 4] * 19235u + (uint32_t)pr[k + 4] * 9798u + 16384u) >> 15) << (8 * k);
         }
         if ((g.w & 7) == 0 && (bgr_stride & 7) == 0) *(uint2 *)og = make_uint2(lo, hi);
         else {
@@ -625,13 +626,16 @@ __device__ inline void jcolor8(const jpeg_geom &g, const uint8_t *__restrict__ p
         }
         return;
     }
+    uint32_t px[24];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { px[3 * k] = (uint32_t)pb[k]; px[3 * k + 1] = (uint32_t)pg[k]; px[3 * k + 2] = (uint32_t)pr[k]; }
     if ((g.w & 7) == 0 && (bgr_stride & 3) == 0) {
         uint32_t *o4 = (uint32_t *)o;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) o4[k] = px[4 * k] | (px[4 * k + 1] << 8) | (px[4 * k + 2] << 16) | ((uint32_t)px[4 * k + 3] << 24);
+        for (int k = 0; k < 6; ++k) o4[k] = px[4 * k] | (px[4 * k + 1] << 8) | (px[4 * k + 2] << 16) | (px[4 * k + 3] << 24);
     } else {
         const int n = (g.w - x0 < 8 ? g.w - x0 : 8) * 3;
-        for (int k = 0; k < n; ++k) o[k] = px[k];
+        for (int k = 0; k < n; ++k) o[k] = (uint8_t)px[k];
     }
 }
 
