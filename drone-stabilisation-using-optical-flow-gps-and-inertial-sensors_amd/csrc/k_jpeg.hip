@@ -19,7 +19,7 @@
 //      argument, only the run time does.
 //   2. k_jpeg_scan: exclusive prefix sum of the blocks completed per chunk = index of the block a chunk starts in.
 //   3. k_jpeg_write: every thread decodes its chunk once more from its (now true) entry state and stores the coefficients
-//      (k_jpeg_zero_upper / k_jpeg_zero_heads prepare the background it relies on).
+//      (k_jpeg_zero_heads zeroes the few blocks that more than one thread writes).
 //   4. k_jpeg_dc: DC prediction = prefix sum of the DC differences per component in decode order.
 //   5. k_jpeg_idct<false>: dequantisation + ISLOW IDCT of the chroma blocks, 8 lanes per block (columns, then rows through LDS) -> planes.
 //   6. k_jpeg_idct<true>: the same for the luma blocks, into an LDS tile, then fancy upsampling + colour conversion -> BGR8 (or straight
@@ -322,21 +322,33 @@ __global__ __launch_bounds__(1024) void k_jpeg_scan(const jpeg_tab *__restrict__
 // Coefficients of the block in progress are collected in the thread's LDS row and leave as one wide store when the block is
 // complete (2-byte stores scattered over HBM - partial-line writes - made this kernel 3x slower than the counting pass).  The row
 // holds the first JROW_K zigzag positions only (20 KB per 256 threads beside the 17 KB of the readers' rings and 9 KB of tables:
-// three waves per SIMD; all 64 positions would leave two).  The coefficients behind position JROW_K (the high-frequency half: a few per cent at camera qualities) go
-// straight to the zeroed coefficient buffer - scattered 2-byte stores, which is why shorter rows lose: 1.82 ms per 512 frames with
-// 32 positions, 2.38 with 16, 3.59 with 8 (profiles/r04_exp_jpeg_rows.txt).  A block that straddles a chunk boundary is shared with the neighbouring thread: its parts are
-// scattered element-wise onto the zeroed background instead.
+// three waves per SIMD; all 64 positions would leave two).  The coefficients behind position JROW_K (the high-frequency half: a few
+// per cent at camera qualities) go straight to the block's upper half - scattered 2-byte stores, which is why shorter rows lose:
+// 1.82 ms per 512 frames with 32 positions, 2.38 with 16, 3.59 with 8 (profiles/r04_exp_jpeg_rows.txt).  A block that straddles a
+// chunk boundary is shared with the neighbouring thread: its parts are scattered element-wise onto a zeroed block instead.
 #define JROW_K 32
 #define JBLK_PITCH (JROW_K + 8)                                   // int16 per LDS row: 16-byte aligned (the row moves as b128 reads / writes), 4 dwords of padding spread the lanes over the banks
 struct jemit_store {
     int16_t *row;                                                 // this thread's LDS row (zigzag order, zero between blocks)
-    int16_t *out; int n0, nblk; bool head_partial;
+    int16_t *out; int n0, nblk, nfin; bool head_partial;          // nfin: blocks this chunk completes (the one after them straddles)
     int16_t *dc; int cur;                                         // DC differences go to a dense array of their own (k_jpeg_dc scans it)
+    int curdc; bool up;                                           // of the block in progress: DC difference; it has coefficients behind the row
+    // DC entry: bits 0..14 the difference (12 significant bits), bit 15 = the block's upper half holds data (else it is never read)
+    __device__ static int16_t dc_entry(int diff, bool upper) { return (int16_t)((diff & 0x7FFF) | (upper ? 0x8000 : 0)); }
     __device__ void coef(int k, int v)
     {
-        if (k < JROW_K) row[k] = (int16_t)v;
-        else if (n0 + cur < nblk) out[(size_t)(n0 + cur) * 64 + k] = (int16_t)v;
-        if (k == 0 && n0 + cur < nblk) dc[n0 + cur] = (int16_t)v;
+        if (k < JROW_K) { row[k] = (int16_t)v; if (k == 0) curdc = v; }
+        else if (n0 + cur < nblk) {
+            int16_t *blk = out + (size_t)(n0 + cur) * 64;
+            // the first coefficient behind the row: the block's upper half becomes data, on a zero background the thread lays itself -
+            // unless the block straddles a chunk boundary (two threads write it: k_jpeg_zero_heads has zeroed it)
+            if (!up && !((cur == 0 && head_partial) || cur >= nfin)) {
+#pragma unroll
+                for (int q = JROW_K / 8; q < 8; ++q) reinterpret_cast<uint4 *>(blk)[q] = make_uint4(0, 0, 0, 0);
+            }
+            up = true;
+            blk[k] = (int16_t)v;
+        }
     }
     __device__ void scatter(int n)
     {
@@ -357,9 +369,11 @@ struct jemit_store {
     __device__ void block(int done)
     {
         const int n = n0 + done;
-        cur = done + 1;
+        const int diff = curdc; const bool upper = up;
+        cur = done + 1; curdc = 0; up = false;
         if (n >= nblk) return;
-        if (done == 0 && head_partial) { scatter(n); return; }
+        if (done == 0 && head_partial) { scatter(n); return; }       // (its DC entry is the starting thread's)
+        dc[n] = dc_entry(diff, upper);
         drain();
         uint4 *src = reinterpret_cast<uint4 *>(row);
         pend_dst = (uint4 *)(out + (size_t)n * 64);
@@ -396,35 +410,35 @@ __global__ __launch_bounds__(JTPW) void k_jpeg_write(const jpeg_tab *__restrict_
     for (int q = 0; q < JBLK_PITCH / 2; ++q) ((uint32_t *)rows[threadIdx.x])[q] = 0;
     jemit_store em;
     em.row = rows[threadIdx.x]; em.out = coef + (size_t)b * g.nblk * 64; em.n0 = n0; em.nblk = g.nblk; em.head_partial = r.k != 0;
-    em.dc = dcarr + (size_t)b * g.nblk; em.cur = 0; em.pend_dst = nullptr;
+    em.dc = dcarr + (size_t)b * g.nblk; em.cur = 0; em.pend_dst = nullptr; em.curdc = 0; em.up = false;
+    em.nfin = base[(size_t)b * (nch_max + 1) + (i + 1 < t->nch ? i + 1 : nch_max)] - n0;
     const int n = jrun<true, RST>(T, t, rst + t->rst_off, r, (uint32_t)(i + 1) * (uint32_t)g.jch * 8u, g, g.nblk - n0, em);
     em.drain();
-    if (r.k != 0 && n0 + n < g.nblk) em.scatter(n0 + n);          // the block still in progress continues in the next chunk
+    if (r.k != 0 && n0 + n < g.nblk) {                            // the block still in progress continues in the next chunk
+        em.scatter(n0 + n);
+        if (!(n == 0 && em.head_partial)) em.dc[n0 + n] = jemit_store::dc_entry(em.curdc, true);   // it started here: its DC entry, upper half "data" (zeroed)
+    }
     if (n0 + n == g.nblk && n > 0) {                              // this thread finished the last block: where the scan ended
         endinfo[b * 2] = (int)((r.pos() + 7u) >> 3);
         endinfo[b * 2 + 1] = 1;
     }
 }
 
-// The write pass stores the first JROW_K zigzag positions of every block it completes as one 64-byte row and drops the few
-// coefficients behind them onto a zero background: what has to be zero beforehand is the UPPER half of every block (k_jpeg_zero_upper,
-// half the bytes of a plain fill, beside the synchronisation passes) and the lower half of the blocks that straddle a chunk boundary,
-// whose parts two threads scatter element-wise (k_jpeg_zero_heads, a few thousand rows per image, between the scan and the write pass).
-__global__ __launch_bounds__(256) void k_jpeg_zero_upper(uint4 *__restrict__ coef, size_t nblocks)
-{
-    const size_t stride = (size_t)gridDim.x * 256;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nblocks * 4; i += stride) coef[(i >> 2) * 8 + 4 + (i & 3)] = make_uint4(0, 0, 0, 0);
-}
-
+// The write pass stores the first JROW_K zigzag positions of every block it completes as one 64-byte row; the upper half of a block is
+// written - zeros first - only when the block has a coefficient there, and the block's DC entry says so (the IDCT does not read the
+// others).  Blocks that straddle a chunk boundary are scattered element-wise by two or more threads: k_jpeg_zero_heads zeroes those (a
+// few thousand per image, between the scan and the write pass) and they count as "upper half holds data".  No fill of the 3.3 GB
+// coefficient buffer: beside the first synchronisation pass and the previous batch's pipeline run even half of it (the upper halves)
+// cost the double-buffered loop 7 % of its period.
 __global__ __launch_bounds__(256) void k_jpeg_zero_heads(const jpeg_tab *__restrict__ tabs, jpeg_geom g, int nch_max, const unsigned long long *__restrict__ state,
                                                          const int *__restrict__ base, int16_t *__restrict__ coef)
 {
-    const int b = blockIdx.y, i = blockIdx.x * 64 + (threadIdx.x >> 2);
+    const int b = blockIdx.y, i = blockIdx.x * 32 + (threadIdx.x >> 3);
     if (i < 1 || i >= tabs[b].nch) return;
     if (((state[(size_t)b * nch_max + i - 1] >> 8) & 63) == 0) return;        // a block starts with the chunk
     const int n = base[(size_t)b * (nch_max + 1) + i];
     if (n >= g.nblk) return;
-    reinterpret_cast<uint4 *>(coef + ((size_t)b * g.nblk + n) * 64)[threadIdx.x & 3] = make_uint4(0, 0, 0, 0);
+    reinterpret_cast<uint4 *>(coef + ((size_t)b * g.nblk + n) * 64)[threadIdx.x & 7] = make_uint4(0, 0, 0, 0);
 }
 
 // DC prediction: inclusive prefix sum of the DC differences of one component in decode order (one workgroup per image x component),
@@ -444,13 +458,13 @@ __global__ __launch_bounds__(1024) void k_jpeg_dc(const jpeg_tab *__restrict__ t
     for (int j0 = 0; j0 < total; j0 += 4096) {                  // four consecutive blocks per thread: a quarter of the barriers
         const int jb = j0 + 4 * threadIdx.x;
         size_t n[4];
-        int v[4], f[4];
+        int v[4], f[4], up[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int j = jb + i;
             n[i] = 0; v[i] = 0;
             f[i] = seg > 0 && j % seg == 0;
-            if (j < total) { n[i] = (size_t)(j / nbc) * g.bpm + off + j % nbc; v[i] = dc[n[i]]; }
+            if (j < total) { n[i] = (size_t)(j / nbc) * g.bpm + off + j % nbc; const int x = (uint16_t)dc[n[i]]; up[i] = x & 0x8000; v[i] = (int)((unsigned)x << 17) >> 17; }   // bit 15: the upper-half flag, carried through
         }
         int sl[4], gl[4];                                       // sums since the last interval start inside the thread / "one was seen"
         sl[0] = v[0]; gl[0] = f[0];
@@ -472,7 +486,7 @@ __global__ __launch_bounds__(1024) void k_jpeg_dc(const jpeg_tab *__restrict__ t
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             r = gl[i] ? sl[i] : sl[i] + pt;
-            if (jb + i < total) dc[n[i]] = (int16_t)r;
+            if (jb + i < total) dc[n[i]] = (int16_t)((r & 0x7FFF) | up[i]);
         }
         __syncthreads();
         if (threadIdx.x == 1023) carry = r;
@@ -669,24 +683,21 @@ __global__ __launch_bounds__(256) void k_jpeg_idct(const jpeg_tab *__restrict__ 
     auto block_of = [&](int s) { return nbase + (size_t)((s >> sh) * g.bpm + j0 + (s & (per - 1))); };
     const int hs = g.hmax, vsl = g.vmax == 2 ? 1 : 0;              // tile: 8 << vsl rows of 32 >> vsl groups
     const uint8_t *pl = planes + (size_t)b * g.plane_stride;
+    // DC entries (predicted DC in bits 0..14, bit 15: the block's upper half holds data) are read two steps ahead, the coefficients
+    // one step ahead - the lanes of the upper half (c >= 4) only where the entry says so
     uint4 nv = make_uint4(0, 0, 0, 0);
-    int16_t ndc = 0;
-    if (lb < nsel) {
-        const size_t n = block_of(lb);
-        nv = reinterpret_cast<const uint4 *>(coef + n * 64)[c];
-        if (c == 0) ndc = dcarr[n];
-    }
+    int d0 = lb < nsel ? (int)(uint16_t)dcarr[block_of(lb)] : 0, d1 = lb + 32 < nsel ? (int)(uint16_t)dcarr[block_of(lb + 32)] : 0;
+    if (lb < nsel && (c < 4 || (d0 & 0x8000))) nv = reinterpret_cast<const uint4 *>(coef + block_of(lb) * 64)[c];
     for (int l0 = 0; l0 < nsel; l0 += 32) {
         const int local = l0 + lb;
         const bool live = local < nsel;
         *reinterpret_cast<uint4 *>(&cz[lb][8 * c]) = nv;
-        if (c == 0) cz[lb][0] = ndc;                               // the predicted DC (the block holds the difference)
+        if (c == 0) cz[lb][0] = (int16_t)((int)((unsigned)d0 << 17) >> 17);      // the predicted DC (the block holds the difference)
         __syncthreads();
-        if (local + 32 < nsel) {
-            const size_t n = block_of(local + 32);
-            nv = reinterpret_cast<const uint4 *>(coef + n * 64)[c];
-            if (c == 0) ndc = dcarr[n];
-        }
+        nv = make_uint4(0, 0, 0, 0);
+        if (local + 32 < nsel && (c < 4 || (d1 & 0x8000))) nv = reinterpret_cast<const uint4 *>(coef + block_of(local + 32) * 64)[c];
+        d0 = d1;
+        d1 = local + 64 < nsel ? (int)(uint16_t)dcarr[block_of(local + 64)] : 0;
         const int mx = local >> sh, jj = local & (per - 1);
         const int comp = LUMA ? 0 : 1 + jj;
         if (live) {
@@ -968,7 +979,6 @@ struct jstage {
 struct jstages {
     jstage slot[2]; hipStream_t copy;
     hipStream_t dec;                          // the decoder passes of a double-buffered frame-pair ingest: beside the pipeline run of the batch before
-    hipStream_t zero; hipEvent_t zero_go, zeroed;   // the coefficient background is zeroed (HBM-bound fill) beside the VALU-bound synchronisation passes
     int *hmap, *hmap_dev; size_t hmap_ints;   // host memory the device writes its convergence flags / end-of-stream records into (pinned,
                                               // mapped): the host reads them after a stream wait, no copy engine in the round trip - a D2H
                                               // copy queues behind the other slot's 200 MB H2D transfer and stalls the decoder for its length
@@ -999,9 +1009,6 @@ static void jstages_free(jstages *js)
     }
     if (js->copy) hipStreamDestroy(js->copy);
     if (js->dec) hipStreamDestroy(js->dec);
-    if (js->zero) hipStreamDestroy(js->zero);
-    if (js->zero_go) hipEventDestroy(js->zero_go);
-    if (js->zeroed) hipEventDestroy(js->zeroed);
     if (js->hmap) hipHostFree(js->hmap);
     free(js);
 }
@@ -1013,9 +1020,7 @@ static jstages *jstages_of(ofk_ctx *c)
         if (!js) return nullptr;
         bool ok = hipStreamCreateWithFlags(&js->copy, hipStreamNonBlocking) == hipSuccess &&
                   hipStreamCreateWithFlags(&js->dec, hipStreamNonBlocking) == hipSuccess &&
-                  hipStreamCreateWithFlags(&js->zero, hipStreamNonBlocking) == hipSuccess &&
-                  hipEventCreateWithFlags(&js->zero_go, hipEventDisableTiming) == hipSuccess &&
-                  hipEventCreateWithFlags(&js->zeroed, hipEventDisableTiming) == hipSuccess;
+                  true;
         for (int k = 0; k < 2 && ok; ++k) ok = hipEventCreateWithFlags(&js->slot[k].copied, hipEventDisableTiming) == hipSuccess;
         if (!ok) { (void)hipGetLastError(); jstages_free(js); return nullptr; }      // whatever was created so far is released
         c->jstage = js;
@@ -1190,13 +1195,6 @@ static int jdecode_staged(ofk_ctx *c, int slot, uint8_t *dst, uint8_t *dst2, int
     hipStream_t st = own_stream ? js->dec : c->stream;
     for (int k = 0; wait_ev && k < nwait; ++k) if (wait_ev[k]) OFK_HIP(c, hipStreamWaitEvent(st, wait_ev[k], 0));
     OFK_HIP(c, hipMemsetAsync(flags, 0, JMAX_ITERS * 4 + B * 8, st));
-    // 1.65 GB per 1024 frames of 1080p (the upper halves of the coefficient blocks): on a stream of its own from here (the scratch is free: everything before is behind st) until the
-    // write pass, which is the first to touch the coefficients - the fill runs beside the synchronisation passes, which leave HBM idle
-    OFK_HIP(c, hipEventRecord(js->zero_go, st));
-    OFK_HIP(c, hipStreamWaitEvent(js->zero, js->zero_go, 0));
-    hipLaunchKernelGGL(k_jpeg_zero_upper, dim3(8192), dim3(256), 0, js->zero, (uint4 *)coef, B * g.nblk);
-    OFK_HIP(c, hipMemsetAsync(dcarr, 0, B * g.nblk * 2, js->zero));
-    OFK_HIP(c, hipEventRecord(js->zeroed, js->zero));
     OFK_HIP(c, hipStreamWaitEvent(st, J.copied, 0));             // tables and entropy data are on the device from here on
     const dim3 dgrid((nch_max + JTPB - 1) / JTPB, batch);
     TRY_J(jhmap(c, js, JMAX_ITERS + 2 * B));
@@ -1221,8 +1219,7 @@ static int jdecode_staged(ofk_ctx *c, int slot, uint8_t *dst, uint8_t *dst2, int
         if (!converged && iter > nch_max + 2) return ofk_fail(c, OFK_E_INVALID, "ofk_jpeg: entropy decoders did not converge");
     }
     hipLaunchKernelGGL(k_jpeg_scan, dim3(batch), dim3(1024), 0, st, dt, nch_max, count, base);
-    OFK_HIP(c, hipStreamWaitEvent(st, js->zeroed, 0));
-    hipLaunchKernelGGL(k_jpeg_zero_heads, dim3((nch_max + 63) / 64, batch), dim3(256), 0, st, dt, g, nch_max, state, base, coef);
+    hipLaunchKernelGGL(k_jpeg_zero_heads, dim3((nch_max + 31) / 32, batch), dim3(256), 0, st, dt, g, nch_max, state, base, coef);
     hipLaunchKernelGGL(write_pass, dim3((nch_max + JTPW - 1) / JTPW, batch), dim3(JTPW), 0, st, dt, dent, drst, g, nch_max, state, base, coef, dcarr, endinfo);
     hipLaunchKernelGGL(k_jpeg_dc, dim3(batch, g.ncomp), dim3(1024), 0, st, dt, g, dcarr);
     if (g.ncomp > 1) hipLaunchKernelGGL(k_jpeg_idct<false>, dim3(g.mcuy, batch), dim3(256), 0, st, dt, g, coef, dcarr, planes, dst, dst2, split, dst_stride, as_gray);
