@@ -243,9 +243,9 @@ int ofk_pairs_upload_jpeg(ofk_ctx *ctx, const uint8_t *const *prev_jpeg, const s
                           const size_t *next_bytes, int batch);
 /* The same in two phases, so that a camera loop can hide the host's share of the ingest (marker parse, staging copy, PCIe) behind
  * the GPU's work on the batch before:
- *   ofk_jpeg_stage(ctx, slot, jpeg, nbytes, count)   host + copy engine: parses `count` streams, packs tables and entropy segments
- *       into pinned staging slot 0 or 1 and queues ONE asynchronous H2D copy on the context's copy stream; returns when the host
- *       part is done.  It touches nothing but its slot, so it may run on a SECOND THREAD while the context's owner is inside any
+ *   ofk_jpeg_stage(ctx, slot, jpeg, nbytes, count)   host + copy engine: parses `count` streams, packs tables and the entropy segments
+ *       (without their byte stuffing, see ofk_jpeg_destuff) into pinned staging slot 0 or 1 and queues their asynchronous H2D copies
+ *       on the context's copy stream as its worker threads finish their shares; returns when the host part is done.  It touches nothing but its slot, so it may run on a SECOND THREAD while the context's owner is inside any
  *       other entry point - as long as that is not the decode of the same slot.
  *   ofk_pairs_upload_staged(ctx, slot)               device: decodes the 2 B streams staged in `slot` - the B previous frames
  *       first, then the B next frames - into the resident frame-pair buffers (what ofk_pairs_upload_jpeg does after staging
