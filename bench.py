@@ -49,7 +49,7 @@ The JSON line also carries
                  traffic lies BELOW its algorithmic bytes is flagged: SURVEY's byte count is then not that kernel's minimum.
   ingest_inclusive : pairs/s when the frames are NOT resident: raw BGR over PCIe every step, and JPEG streams decoded on the
                  device every step (bounded: a few steps each, outside the timed region) with the decoder's own kernel times;
-                 jpeg_double_buffered.value = 20 batches with the first one's staging unhidden, .steady_state = the loop's period.
+                 jpeg_double_buffered.value = 40 batches with the first one's staging unhidden, .steady_state = the loop's period.
   cpu_baseline : the CPU oracle (oracle/, single thread, kind "port") timed on this host over a bounded sample of the
                  same frame pairs (rank 0, N=1 only).
   monte_carlo_sweep (--config c4 only): configs[4]'s Monte-Carlo sweep at 2000 points x 4096 trials per step, device noise and host noise.
@@ -237,7 +237,7 @@ def ingest_inclusive(pipe, prev, nxt, sensors, B, reps=2):
                                         "streams": f"{D} distinct 1080p 4:2:0 quality-80 frames per side, repeated"}
         # the same with the ingest double-buffered (FlowPipeline.run_jpeg_batches): a helper thread parses, stages and uploads batch
         # k + 1 while the GPU decodes batch k and runs its pairs
-        nb = 20                                                  # the first batch stages unhidden: `steady_state` below leaves the ramp out
+        nb = 40                                                  # 20 k pairs; the first batch stages unhidden: `steady_state` below leaves the ramp out
         pipe.run_jpeg_batches([(jp, jn)] * 2, sensors); pipe.sync()        # warm-up: both staging slots allocate their pinned / device buffers
         marks = []
         t0 = time.perf_counter()
