@@ -361,6 +361,34 @@ def test_gray_direct_ingest_state_machine(pkg, ofk):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ss,h,w", [(0, 250, 332), (1, 480, 640), (1, 123, 201), (None, 250, 332), (2, 123, 201)])
+def test_gray_direct_ingest_other_samplings(pkg, ofk, ss, h, w):
+    """The fused luma-IDCT / colour kernel writes gray for every sampling the decoder accepts - 4:4:4 (tile of 8 rows x 256 pixels),
+    4:2:2, 4:2:0 (16 x 128), gray streams (no chroma pass at all) - and for widths that are no multiple of the tile or of eight
+    pixels: the resident gray level and the pipeline's results equal those of the decoded frames uploaded raw."""
+    from of_amd import synth
+    from of_amd.pipeline import FlowPipeline, PipelineConfig
+    B = 2
+    pairs = [synth.render_pair(h, w, 240 + b) for b in range(B)]
+    as_stream = (lambda img: _encode(np.ascontiguousarray(img[:, :, 1]), 85)) if ss is None else (lambda img: _encode(img, 85, ss))
+    sp, sn = [as_stream(p["prev"]) for p in pairs], [as_stream(p["next"]) for p in pairs]
+    dp, dn = np.stack([jo.decode(s) for s in sp]), np.stack([jo.decode(s) for s in sn])
+    sensors = ofk.make_sensors(B, scaling=pairs[0]["scaling"], cx=pairs[0]["cx"], cy=pairs[0]["cy"])
+    pipe = FlowPipeline(w, h, B, PipelineConfig(max_corners=60, quality=0.03, min_distance=7, max_level=2))
+    try:
+        pipe.upload(dp, dn, sensors)
+        ref = pipe.run()
+        ref_pyr = pipe.ctx.resident_pyramid(0, 1, h, w, 2)
+        pipe.ctx.pairs_upload_jpeg(sp, sn)
+        out = pipe.run()
+        for k in ("counts", "prev_pts", "next_pts", "status", "records"):
+            assert np.array_equal(out[k], ref[k]), k
+        assert all(np.array_equal(a, b) for a, b in zip(pipe.ctx.resident_pyramid(0, 1, h, w, 2), ref_pyr))
+    finally:
+        pipe.close()
+
+
+@pytest.mark.gpu
 def test_decoder_chunk_size_does_not_change_pixels(pkg, ofk, gold):
     """ofk_set_tuning("jpeg_chunk"): 64 ... 1024 entropy bytes per decoder thread - other chunk boundaries, other synchronisation
     histories, the same pixels.  "jpeg_sub": fewer second-level Huffman tables than the streams' tables need - the codes left over
