@@ -100,3 +100,21 @@ def test_bench_algorithmic_bytes_follow_survey_8d():
         assert f"BASELINE configs[{name[1]}]" in c["workload"] and c["batch"] >= 128 and c["streams"] in (1, 2)
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     assert "1920" in base["configs"][1] and "1024" in base["configs"][2] and "3840" in base["configs"][4]
+
+
+def test_decoder_profile_and_the_bench_line_agree():
+    """profiles/<tag>_jpeg_decoder.json (SQ counter passes over the decoder alone) is what bench.py reports as ingest_inclusive.decoder:
+    the per-kernel times add up to the total, the committed bench line of configs[1] carries exactly these numbers, its double-buffered
+    ingest figure names its batch count and a steady-state rate that is not below the ramp-inclusive one."""
+    dec = load("jpeg_decoder")
+    ks = {k: v["ms_per_512_frames"] for k, v in dec["kernels"].items() if k.startswith("k_jpeg")}
+    assert abs(sum(ks.values()) - dec["decoder_ms_per_512_frames"]) < 2e-3 and dec["frames_per_decode"] == 512
+    assert {"k_jpeg_sync", "k_jpeg_write", "k_jpeg_idct", "k_jpeg_dc"} <= set(ks) and "k_jpeg_color" not in ks and "k_jpeg_zero_upper" not in ks
+    p = os.path.join(ROOT, "profiles", f"{TAG}_bench_b512.json")
+    if not os.path.exists(p):
+        pytest.skip("bench line not committed yet")
+    ing = json.load(open(p))["ingest_inclusive"]
+    assert ing["decoder"]["ms_per_512_frames"] == dec["decoder_ms_per_512_frames"] and ing["decoder"]["kernels_ms_per_512_frames"] == ks
+    db = ing["jpeg_double_buffered"]
+    assert db["batches"] >= 20 and db["steady_state"] >= db["value"] > ing["jpeg_decode_on_device"]["value"] > ing["raw_bgr_upload"]["value"]
+
