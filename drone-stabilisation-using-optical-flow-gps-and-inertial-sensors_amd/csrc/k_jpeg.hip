@@ -237,6 +237,7 @@ __device__ inline int jrun(const jfast &T, const jpeg_tab *t, const uint32_t *__
 
 struct jemit_none { __device__ void coef(int, int) const {} __device__ void block(int) const {} };
 
+#define JSYNC_LDS_PAD 2560
 template <bool RST>
 __global__ __launch_bounds__(JTPB) void k_jpeg_sync(const jpeg_tab *__restrict__ tabs, const uint8_t *__restrict__ ent, const uint32_t *__restrict__ rst,
                                                     jpeg_geom g, int nch_max, unsigned long long *__restrict__ state, unsigned long long *__restrict__ used,
@@ -244,16 +245,14 @@ __global__ __launch_bounds__(JTPB) void k_jpeg_sync(const jpeg_tab *__restrict__
 {
     __shared__ jfast T;
     __shared__ uint32_t ring[JTPB][JRING + 1];
-    __shared__ unsigned long long elist[JTPB];                   // (five waves per SIMD is the optimum: with the lists inside the ring's memory a sixth fits and the passes take 6 % longer, with four 7 %)
-    __shared__ uint16_t clist[JTPB];
-    __shared__ int wcount[JTPB / 64];
+    // (26.9 KB of LDS + JSYNC_LDS_PAD bytes at the launch: five workgroups per CU = five waves per SIMD, the optimum - six take 6 % longer, four 7 %)
     const int b = blockIdx.y;
     const jpeg_tab *t = tabs + b;
     if ((int)(blockIdx.x * JTPB) >= t->nch) return;
-    int i = blockIdx.x * JTPB + threadIdx.x;
-    size_t o = (size_t)b * nch_max + i;
-    // who has work?  iteration 0: everybody; later: the chunks whose predecessor published a state they have not started from yet
-    // (chunk 0 started from the truth and never has).  A workgroup without work leaves before it loads the tables.
+    const int i = blockIdx.x * JTPB + threadIdx.x;
+    const size_t o = (size_t)b * nch_max + i;
+    // who has work?  iteration 0: everybody; iteration 1: the chunks whose predecessor published a state they have not started from
+    // (chunk 0 started from the truth and never has).  The later iterations are k_jpeg_sync_tail's.
     unsigned long long e = 0;
     bool work = i < t->nch;
     if (work && iter) {
@@ -261,20 +260,6 @@ __global__ __launch_bounds__(JTPB) void k_jpeg_sync(const jpeg_tab *__restrict__
         if (work) { e = state[o - 1]; work = e != used[o]; }
     }
     if (!__syncthreads_or(work)) return;
-    if (iter >= 2) {
-        // from the third pass on only a fraction of the chunks has work, scattered over the lanes: hand the work to the first
-        // threads of the workgroup, so that whole waves leave instead of idling beside a few busy lanes
-        const unsigned long long bal = __ballot(work);
-        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        if (lane == 0) wcount[wv] = __popcll(bal);
-        __syncthreads();
-        int pre = 0, total = 0;
-        for (int k = 0; k < JTPB / 64; ++k) { if (k < wv) pre += wcount[k]; total += wcount[k]; }
-        if (work) { const int at = pre + __popcll(bal & ((1ull << lane) - 1ull)); clist[at] = (uint16_t)threadIdx.x; elist[at] = e; }
-        __syncthreads();
-        work = (int)threadIdx.x < total;
-        if (work) { i = blockIdx.x * JTPB + clist[threadIdx.x]; o = (size_t)b * nch_max + i; e = elist[threadIdx.x]; }
-    }
     jload_tables(T, &t->S);
     if (!work) return;
     jring r;
@@ -291,6 +276,53 @@ __global__ __launch_bounds__(JTPB) void k_jpeg_sync(const jpeg_tab *__restrict__
     const unsigned long long x = jpack(r.pos(), r.k, r.blk);
     if (iter == 0) state[o] = x;
     else if (x != state[o]) { state[o] = x; flags[iter < JMAX_ITERS ? iter : JMAX_ITERS - 1] = 1; }
+}
+
+// The passes from the third on: a few per cent of the chunks still have work (14 % of the chunks do not fall into step inside their
+// 256 bytes, so 2 %, 0.3 %, ... are still wrong), and the pass costs what ONE chunk's decode takes at whatever occupancy it runs.  Per
+// 256 chunks (k_jpeg_sync) that left every workgroup with one wave of a few lanes - 3584 sparse waves per pass of 512 frames.  Here a
+// workgroup looks at JTAIL chunks of an image and packs those with work into full waves: 4 to 30 times fewer waves, each pass closer
+// to the latency of a single chunk.
+#define JTAIL 2048
+template <bool RST>
+__global__ __launch_bounds__(JTPB) void k_jpeg_sync_tail(const jpeg_tab *__restrict__ tabs, const uint8_t *__restrict__ ent, const uint32_t *__restrict__ rst,
+                                                         jpeg_geom g, int nch_max, unsigned long long *__restrict__ state, unsigned long long *__restrict__ used,
+                                                         int *__restrict__ count, int iter, int *__restrict__ flags)
+{
+    __shared__ jfast T;
+    __shared__ uint32_t ring[JTPB][JRING + 1];
+    __shared__ uint16_t alist[JTAIL];
+    __shared__ int acount;
+    const int b = blockIdx.y, c0 = blockIdx.x * JTAIL;
+    const jpeg_tab *t = tabs + b;
+    if (c0 >= t->nch) return;
+    if (threadIdx.x == 0) acount = 0;
+    __syncthreads();
+    for (int j = threadIdx.x; j < JTAIL; j += JTPB) {
+        const int i = c0 + j;
+        if (i > 0 && i < t->nch && state[(size_t)b * nch_max + i - 1] != used[(size_t)b * nch_max + i]) alist[atomicAdd(&acount, 1)] = (uint16_t)j;
+    }
+    __syncthreads();
+    const int total = acount;
+    if (total == 0) return;
+    jload_tables(T, &t->S);
+    const uint32_t cbits = (uint32_t)g.jch * 8u;
+    for (int a0 = 0; a0 < total; a0 += JTPB) {
+        if (a0 + (int)threadIdx.x >= total) continue;
+        const int i = c0 + alist[a0 + threadIdx.x];
+        const size_t o = (size_t)b * nch_max + i;
+        const unsigned long long e = state[o - 1];                // (may be newer than what the list was built from: whatever it is, `used` records it)
+        jring r;
+        r.d = ent + t->ent_off; r.rg = ring[threadIdx.x];
+        r.k = (int)((e >> 8) & 63); r.blk = (int)(e & 15);
+        r.seek((uint32_t)(e >> 32));
+        used[o] = e;
+        jemit_none em;
+        const int n = jrun<false, RST>(T, t, rst + t->rst_off, r, (uint32_t)(i + 1) * cbits, g, 0x7fffffff, em);
+        count[o] = n;
+        const unsigned long long x = jpack(r.pos(), r.k, r.blk);
+        if (x != state[o]) { state[o] = x; flags[iter < JMAX_ITERS ? iter : JMAX_ITERS - 1] = 1; }
+    }
 }
 
 // exclusive prefix sum of count[b][0..nch) -> base[b][...]; total in base[b][nch_max]
@@ -1185,6 +1217,8 @@ static int jdecode_staged(ofk_ctx *c, int slot, uint8_t *dst, uint8_t *dst2, int
     const uint32_t *drst = (const uint32_t *)((const uint8_t *)J.dev + J.tab_bytes);
     const uint8_t *dent = (const uint8_t *)J.dev + J.tab_bytes + J.rst_bytes;
     auto sync_pass = J.restarts ? k_jpeg_sync<true> : k_jpeg_sync<false>;
+    auto sync_tail = J.restarts ? k_jpeg_sync_tail<true> : k_jpeg_sync_tail<false>;
+    const dim3 tgrid((nch_max + JTAIL - 1) / JTAIL, batch);
     auto write_pass = J.restarts ? k_jpeg_write<true> : k_jpeg_write<false>;
     unsigned long long *state = (unsigned long long *)(S + o_state), *used = (unsigned long long *)(S + o_used);
     int *count = (int *)(S + o_count), *base = (int *)(S + o_base), *flags = (int *)(S + o_flags), *endinfo = flags + JMAX_ITERS;
@@ -1200,7 +1234,7 @@ static int jdecode_staged(ofk_ctx *c, int slot, uint8_t *dst, uint8_t *dst2, int
     TRY_J(jhmap(c, js, JMAX_ITERS + 2 * B));
     volatile int *hflags = js->hmap;
     int iter = 0;
-    hipLaunchKernelGGL(sync_pass, dgrid, dim3(JTPB), 0, st, dt, dent, drst, g, nch_max, state, used, count, iter, flags);
+    hipLaunchKernelGGL(sync_pass, dgrid, dim3(JTPB), JSYNC_LDS_PAD, st, dt, dent, drst, g, nch_max, state, used, count, iter, flags);
     bool converged = nch_max == 1;
     while (!converged) {
         const int first = iter + 1;
@@ -1210,7 +1244,8 @@ static int jdecode_staged(ofk_ctx *c, int slot, uint8_t *dst, uint8_t *dst2, int
         for (int k = 0; k < burst; ++k) {
             ++iter;
             if (iter >= JMAX_ITERS) OFK_HIP(c, hipMemsetAsync(flags + JMAX_ITERS - 1, 0, 4, st));
-            hipLaunchKernelGGL(sync_pass, dgrid, dim3(JTPB), 0, st, dt, dent, drst, g, nch_max, state, used, count, iter, flags);
+            if (iter >= 2) hipLaunchKernelGGL(sync_tail, tgrid, dim3(JTPB), 0, st, dt, dent, drst, g, nch_max, state, used, count, iter, flags);
+            else hipLaunchKernelGGL(sync_pass, dgrid, dim3(JTPB), JSYNC_LDS_PAD, st, dt, dent, drst, g, nch_max, state, used, count, iter, flags);
         }
         hipLaunchKernelGGL(k_jpeg_ints_to_host, dim3(1), dim3(64), 0, st, flags, js->hmap_dev, JMAX_ITERS);
         OFK_HIP(c, hipStreamSynchronize(st));
